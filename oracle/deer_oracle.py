@@ -1,0 +1,386 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A from-scratch restatement (torch-CPU tensor arithmetic, fp32 or fp64) of the
+reference's multimodal-fusion + DEER forward and loss; gradients come from
+torch autograd over this restatement.  Only ``tests/``, ``__graft_entry__.smoke``
+and ``bench.py``'s ``cpu_baseline`` leg may import this module; the product
+package (``mmdeer``) never does and fails loudly without its HIP library.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the reference's
+``fusion.py`` / ``deer.py`` / ``losses.py`` in the build container, loads the
+closed-form parameters of ``mmdeer.synth`` through ``load_state_dict`` and stores
+the reference's outputs, loss components and gradient digests under
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this file against
+them.  Rows the reference itself cannot execute (a4
+``UncertaintyAwareGating`` call site, a9 ``HierarchicalDEERFusion`` as a whole)
+are "parity unpinned" and are not restated here beyond their working pieces.
+
+All ``file:line`` citations are relative to the reference checkout.
+Parameter dictionaries are keyed by the reference's state_dict names with the
+``fusion.`` / ``head.`` prefixes of ``mmdeer.spec.param_table``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+DIM_NAMES = ("valence", "arousal", "dominance")
+
+# torch.linspace(0, 1, 11) in fp32 == float32(i)/10 exactly.
+ECE_EDGES_10 = [float.fromhex(h) for h in (
+    "0x0p+0", "0x1.99999ap-4", "0x1.99999ap-3", "0x1.333334p-2", "0x1.99999ap-2",
+    "0x1p-1", "0x1.333334p-1", "0x1.666666p-1", "0x1.99999ap-1", "0x1.ccccccp-1", "0x1p+0")]
+# torch.linspace(0, 1, 16) in fp32 -- NOT float32(i)/15.
+CAL_EDGES_15 = [float.fromhex(h) for h in (
+    "0x0p+0", "0x1.111112p-4", "0x1.111112p-3", "0x1.99999cp-3", "0x1.111112p-2",
+    "0x1.555556p-2", "0x1.99999cp-2", "0x1.dddde0p-2", "0x1.111110p-1", "0x1.333332p-1",
+    "0x1.555554p-1", "0x1.777778p-1", "0x1.99999ap-1", "0x1.bbbbbcp-1", "0x1.dddddep-1",
+    "0x1p+0")]
+
+
+# --------------------------------------------------------------------------- helpers
+def _lin(x, P, name):
+    """nn.Linear: y = x W^T + b."""
+    return x @ P[name + ".weight"].t() + P[name + ".bias"]
+
+
+def _layer_norm(x, g, b, eps=1e-5):
+    """nn.LayerNorm over the last dim, biased variance, eps inside the sqrt."""
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+def _drop(x, mask, p):
+    """Inverted dropout with an explicit keep-mask (None = eval mode)."""
+    if mask is None:
+        return x
+    return x * mask.to(x.dtype) / (1.0 - p)
+
+
+def _relu_drop_ln(x, P, prefix, mask, p):
+    """nn.Sequential(Linear, ReLU, Dropout, LayerNorm) -- fusion.py:98-103, 216-221, 301-306."""
+    y = _drop(torch.relu(_lin(x, P, prefix + ".0")), mask, p)
+    return _layer_norm(y, P[prefix + ".3.weight"], P[prefix + ".3.bias"]), y
+
+
+# --------------------------------------------------------------------------- fusion
+def av_fusion(P, audio, video, masks=None, p=0.3, heads=8):
+    """AudioVisualFusion.forward -- fusion.py:223-271.
+
+    The shared nn.MultiheadAttention is called with L = S = 1, so softmax over the
+    single key is 1 and each call reduces to out_proj(v_proj(key)); Q and K
+    projections are dead (their gradients are exact zeros).  In train mode torch
+    applies dropout to the (B*heads, 1, 1) attention weights, i.e. one keep/scale
+    factor per (sample, head) on that head's slice of V; the returned weights are
+    the head-mean of the post-dropout weights.
+    """
+    masks = masks or {}
+    pre = "fusion.audio_visual_fusion."
+    ap = _lin(audio, P, pre + "audio_projection")          # :236
+    vp = _lin(video, P, pre + "video_projection")          # :237
+    E = ap.shape[1]
+    hd = E // heads
+    w_in, b_in = P[pre + "cross_attention.in_proj_weight"], P[pre + "cross_attention.in_proj_bias"]
+    w_v, b_v = w_in[2 * E:], b_in[2 * E:]                  # packed rows are [q; k; v]
+
+    def attend(kv, mask):                                  # :244-255
+        v = kv @ w_v.t() + b_v
+        B = v.shape[0]
+        wgt = torch.ones(B, heads, dtype=v.dtype)
+        wgt = _drop(wgt, mask, p)
+        v = (v.view(B, heads, hd) * wgt[:, :, None]).reshape(B, E)
+        out = _lin(v, P, pre + "cross_attention.out_proj")
+        return out, wgt.mean(dim=1, keepdim=True)
+
+    audio_att, w_a2v = attend(vp, masks.get("av_attn_a2v"))  # query=audio, key=value=video
+    video_att, w_v2a = attend(ap, masks.get("av_attn_v2a"))  # query=video, key=value=audio
+    cat = torch.cat([audio_att, video_att], dim=-1)        # :262
+    fused, _ = _relu_drop_ln(cat, P, pre + "fusion_layers", masks.get("av_fuse"), p)  # :263
+    return {"fused_features": fused,
+            "attention_weights": {"audio_to_video": w_a2v, "video_to_audio": w_v2a}}
+
+
+def trimodal_fusion(P, av, text, masks=None, p=0.3, heads=8):
+    """TrimodalFusion.forward -- fusion.py:308-343.
+
+    Self-attention over the 2-token sequence [av_proj, text_proj]:
+    q is scaled by sqrt(1/head_dim) before the product (torch functional
+    multi_head_attention_forward), softmax over the 2 keys, dropout on the
+    probabilities, PV, out_proj; returned weights are the head-mean of the
+    post-dropout probabilities.
+    """
+    masks = masks or {}
+    pre = "fusion.trimodal_fusion."
+    x0 = _lin(av, P, pre + "audiovisual_projection")       # :321
+    x1 = _lin(text, P, pre + "text_projection")            # :322
+    x = torch.stack([x0, x1], dim=1)                       # (B, 2, E)  :325
+    B, T, E = x.shape
+    hd = E // heads
+    qkv = x @ P[pre + "modality_attention.in_proj_weight"].t() + P[pre + "modality_attention.in_proj_bias"]
+    q, k, v = qkv.split(E, dim=-1)
+    q = q.view(B, T, heads, hd).transpose(1, 2) * math.sqrt(1.0 / hd)
+    k = k.view(B, T, heads, hd).transpose(1, 2)
+    v = v.view(B, T, heads, hd).transpose(1, 2)
+    prob = torch.softmax(q @ k.transpose(-1, -2), dim=-1)  # (B, H, 2, 2)
+    prob = _drop(prob, masks.get("tri_attn"), p)
+    o = (prob @ v).transpose(1, 2).reshape(B, T, E)
+    y = _lin(o, P, pre + "modality_attention.out_proj")    # :328-332
+    pooled = y.mean(dim=1)                                 # :335
+    fused, _ = _relu_drop_ln(pooled, P, pre + "final_fusion", masks.get("tri_fuse"), p)  # :338
+    return {"fused_features": fused, "attention_weights": prob.mean(dim=1)}
+
+
+def fusion_forward(P, audio, video, text, masks=None, p=0.3, heads=8):
+    """HierarchicalMultimodalFusion.forward with uncertainties=None -- fusion.py:119-171."""
+    masks = masks or {}
+    av = av_fusion(P, audio, video, masks, p, heads)
+    tri = trimodal_fusion(P, av["fused_features"], text, masks, p, heads)
+    final, _ = _relu_drop_ln(tri["fused_features"], P, "fusion.output_projection",
+                             masks.get("out_proj"), p)    # :162
+    return {"fused_features": final,
+            "audiovisual_features": av["fused_features"],
+            "trimodal_features": tri["fused_features"],
+            "av_attention_weights": av["attention_weights"],
+            "trimodal_attention_weights": tri["attention_weights"],
+            "uncertainty_weights": None}
+
+
+# --------------------------------------------------------------------------- DEER head
+def nig_activations(e):
+    """DEERLayer.forward tail -- deer.py:90-98.  e: (..., 4) = [mu, nu^, alpha^, beta^]."""
+    mu = e[..., 0]
+    nu = F.softplus(e[..., 1]) + 1e-6
+    alpha = F.softplus(e[..., 2]) + 1.0
+    beta = F.softplus(e[..., 3]) + 1e-6
+    alea = beta / (alpha - 1)
+    epis = beta / (nu * (alpha - 1))
+    return mu, nu, alpha, beta, alea, epis, alea + epis
+
+
+def deer_head_forward(P, fused, masks=None, p=0.3):
+    """MultiDimensionalDEER.forward -- deer.py:233-266 (3 x DEERLayer deer.py:68-108)."""
+    masks = masks or {}
+    h = _drop(torch.relu(_lin(fused, P, "head.feature_processor.0")), masks.get("fp0"), p)
+    h = _drop(torch.relu(_lin(h, P, "head.feature_processor.3")), masks.get("fp1"), p)  # :246
+    out: Dict[str, torch.Tensor] = {}
+    keys = ("mu", "nu", "alpha", "beta", "aleatoric_uncertainty", "epistemic_uncertainty", "uncertainty")
+    m0, m1 = masks.get("ev0"), masks.get("ev1")
+    for i, dim in enumerate(DIM_NAMES):
+        pre = f"head.deer_heads.{i}.evidence_net"
+        e = _drop(torch.relu(_lin(h, P, pre + ".0")), None if m0 is None else m0[:, i], p)
+        e = _drop(torch.relu(_lin(e, P, pre + ".3")), None if m1 is None else m1[:, i], p)
+        e = _lin(e, P, pre + ".6").view(h.shape[0], 1, 4)   # deer.py:86-87
+        for key, val in zip(keys, nig_activations(e)):
+            out[f"{dim}_{key}"] = val
+    out["mu_all"] = torch.cat([out[f"{d}_mu"] for d in DIM_NAMES], dim=1)           # :258
+    out["uncertainty_all"] = torch.cat([out[f"{d}_uncertainty"] for d in DIM_NAMES], dim=1)
+    return out
+
+
+def model_forward(P, audio, video, text, masks=None, p=0.3, heads=8):
+    """The Stack-C composite (SURVEY 8b "Definition of MultimodalDEER")."""
+    fo = fusion_forward(P, audio, video, text, masks, p, heads)
+    ho = deer_head_forward(P, fo["fused_features"], masks, p)
+    return fo, ho
+
+
+# --------------------------------------------------------------------------- losses
+def ece_term(gamma, alpha, beta, targets, eps=1e-8, edges: Sequence[float] = ECE_EDGES_10):
+    """losses.DEERLoss._compute_ece_loss -- losses.py:187-226.  Bin i is (lo, hi]."""
+    err = (targets - gamma).abs().flatten()
+    conf = (1.0 / (1.0 + beta / (alpha - 1 + eps))).flatten()
+    n = conf.numel()
+    total = torch.zeros((), dtype=gamma.dtype)
+    counts = []
+    for i in range(len(edges) - 1):
+        lo = torch.tensor(edges[i], dtype=torch.float32).to(conf.dtype)
+        hi = torch.tensor(edges[i + 1], dtype=torch.float32).to(conf.dtype)
+        in_bin = (conf > lo) & (conf <= hi)
+        c = int(in_bin.sum())
+        counts.append(c)
+        if c > 0:
+            total = total + (c / n) * (conf[in_bin].mean() - (1.0 - err[in_bin].mean())).abs()
+    return total, counts
+
+
+def deer_loss_v2(gamma, nu, alpha, beta, targets, reg_w=0.1, kl_w=0.01, ece_w=0.05, eps=1e-8):
+    """losses.DEERLoss.forward -- losses.py:72-130 (terms :132-226)."""
+    if targets.dim() == 1 and gamma.dim() == 2:           # :98-104
+        targets = targets.unsqueeze(-1)
+    elif targets.dim() == 2 and gamma.dim() == 1:
+        gamma, nu, alpha, beta = (t.unsqueeze(-1) for t in (gamma, nu, alpha, beta))
+    err = targets - gamma
+    log_prob = (0.5 * torch.log(nu / (2 * math.pi + eps))
+                + alpha * torch.log(beta + eps)
+                - torch.lgamma(alpha + eps)
+                - (alpha + 0.5) * torch.log(beta + 0.5 * nu * err.pow(2) + eps))   # :144-150
+    nll = -log_prob.mean()
+    e = err.abs()
+    reg = (e.pow(2) * (2 * beta + nu * e.pow(2))).mean()                          # :165-167
+    kl = ((alpha - 1).pow(2)).mean() + 0.1 * ((torch.log(beta + eps) - math.log(1 + eps)).pow(2)).mean()
+    if ece_w > 0:
+        ece, counts = ece_term(gamma, alpha, beta, targets, eps)
+    else:
+        ece, counts = torch.zeros((), dtype=gamma.dtype), []
+    total = nll + reg_w * reg + kl_w * kl + ece_w * ece                           # :121
+    return {"total_loss": total, "nll_loss": nll, "reg_loss": reg, "kl_loss": kl,
+            "ece_loss": ece, "batch_size": gamma.shape[0], "_bin_counts": counts}
+
+
+def multitask_loss(pred, targets, task_weights=(1.0, 1.0, 1.0), cross_w=0.05, **kw):
+    """losses.MultiTaskDEERLoss.forward -- losses.py:268-348."""
+    out: Dict[str, torch.Tensor] = {}
+    total = 0.0
+    for i, dim in enumerate(DIM_NAMES):
+        g = pred[f"{dim}_gamma"] if f"{dim}_gamma" in pred else pred[f"{dim}_mu"]
+        n = pred[f"{dim}_nu"] if f"{dim}_nu" in pred else pred[f"{dim}_lambda"]
+        d = deer_loss_v2(g, n, pred[f"{dim}_alpha"], pred[f"{dim}_beta"], targets[:, i:i + 1], **kw)
+        total = total + task_weights[i] * d["total_loss"]
+        for k, v in d.items():
+            out[f"{dim}_{k}"] = v
+    if cross_w > 0:
+        u = [(pred[f"{d}_beta"] / (pred[f"{d}_alpha"] - 1 + 1e-8)).mean(dim=0) for d in DIM_NAMES]
+        cross, pairs = 0.0, 0
+        for i in range(3):
+            for j in range(i + 1, 3):
+                cross = cross + ((u[i] - u[j]) ** 2).mean()
+                pairs += 1
+        cross = cross / pairs                                                      # :339-346
+        total = total + cross_w * cross
+        out["cross_dim_loss"] = cross
+    out["total_loss"] = total / 3                                                  # :314
+    return out
+
+
+def deer_loss_v1(mu, nu, alpha, beta, targets, evidence_weight=1.0, kl_weight=1.0):
+    """deer.DEERLoss.forward -- deer.py:125-195 (loss variant 1)."""
+    if targets.dim() == 1:
+        targets = targets.unsqueeze(-1)
+    se = (targets - mu) ** 2
+    nll = (0.5 * torch.log(math.pi / nu) - alpha * torch.log(2 * beta) + torch.lgamma(alpha)
+           - torch.lgamma(alpha + 0.5) + (alpha + 0.5) * torch.log(beta + nu * se / 2))
+    reg = (nu * se + 2 * beta * (1 + nu)) / (2 * nu * (1 + nu))
+    kl = (0.5 * (nu - 1) + alpha * torch.log(beta) - torch.lgamma(alpha)
+          + torch.lgamma(alpha + 0.5) - 0.5 * torch.log(2 * math.pi * beta)).clamp(min=0)
+    return {"total_loss": nll.mean() + evidence_weight * reg.mean() + kl_weight * kl.mean(),
+            "nll_loss": nll.mean(), "evidence_reg": reg.mean(), "kl_reg": kl.mean(), "mse": se.mean()}
+
+
+def uncertainty_reg_loss(alpha, beta, diversity_weight=0.1, sparsity_weight=0.01):
+    """losses.UncertaintyRegularizationLoss with flat keys -- losses.py:363-416."""
+    u = beta / (alpha - 1 + 1e-8)
+    div = -torch.log(torch.var(u, dim=0).mean() + 1e-8)      # unbiased variance over the batch
+    spars = u.mean()
+    return {"reg_loss": diversity_weight * div + sparsity_weight * spars,
+            "diversity_loss": div, "sparsity_loss": spars}
+
+
+def calibration_loss(gamma, alpha, beta, targets, edges: Sequence[float] = CAL_EDGES_15):
+    """losses.CalibrationLoss.forward, uniform bins -- losses.py:431-497.
+    Bin i is [lo, hi), the last bin [lo, hi]."""
+    err = (targets - gamma).abs().flatten()
+    conf = (1.0 / (1.0 + beta / (alpha - 1 + 1e-8))).flatten()
+    acc = 1.0 - (err / 2.0).clamp(0, 1)
+    n = conf.numel()
+    nb = len(edges) - 1
+    total = torch.zeros((), dtype=gamma.dtype)
+    for i in range(nb):
+        lo = torch.tensor(edges[i], dtype=torch.float32).to(conf.dtype)
+        hi = torch.tensor(edges[i + 1], dtype=torch.float32).to(conf.dtype)
+        in_bin = (conf >= lo) & ((conf <= hi) if i == nb - 1 else (conf < hi))
+        c = int(in_bin.sum())
+        if c > 0:
+            total = total + (c / n) * (conf[in_bin].mean() - acc[in_bin].mean()).abs()
+    return total
+
+
+# --------------------------------------------------------------------------- side kernels
+def cross_modal_attention(P, audio, video, text, heads=8, prefix=""):
+    """deer.CrossModalAttention.forward -- deer.py:379-425.  Softmax runs over the
+    HEAD axis (dim=1) and the weighted sum collapses heads, giving (B, head_dim)."""
+    B, E = audio.shape
+    hd = E // heads
+    lin = lambda x, n: x @ P[prefix + n + ".weight"].t() + P[prefix + n + ".bias"]
+    q = lin(text, "query_proj").view(B, heads, hd)
+    outs = []
+    for m in (audio, video):
+        k = lin(m, "key_proj").view(B, heads, hd)
+        v = lin(m, "value_proj").view(B, heads, hd)
+        s = (q * k).sum(dim=2) / math.sqrt(hd)
+        a = torch.softmax(s, dim=1)
+        outs.append((a.unsqueeze(2) * v).sum(dim=1))
+    ctx = torch.cat([audio, video, text], dim=1)
+    g = torch.relu(ctx @ P[prefix + "uncertainty_gate.0.weight"].t() + P[prefix + "uncertainty_gate.0.bias"])
+    g = torch.softmax(g @ P[prefix + "uncertainty_gate.2.weight"].t() + P[prefix + "uncertainty_gate.2.bias"], dim=1)
+    return outs[0] * g[:, 0:1], outs[1] * g[:, 1:2]
+
+
+def modality_encoders(P, audio, video, text, prefix=""):
+    """The three ReLU(Linear) encoders of deer.HierarchicalDEERFusion -- deer.py:330-332."""
+    enc = lambda x, n: torch.relu(x @ P[prefix + n + ".weight"].t() + P[prefix + n + ".bias"])
+    return enc(audio, "audio_encoder"), enc(video, "video_encoder"), enc(text, "text_encoder")
+
+
+def lstm_t1_bidir(x, P, prefix, layers=2, hidden=256):
+    """nn.LSTM(bidirectional, batch_first) evaluated at T = 1 with zero initial state
+    (encoders.py:82-89, 380): gates = W_ih x + b_ih + b_hh (W_hh multiplies h0 = 0),
+    c = sigmoid(i) * tanh(g), h = sigmoid(o) * tanh(c); gate row order is [i; f; g; o]."""
+    inp = x
+    for l in range(layers):
+        outs = []
+        for sfx in ("", "_reverse"):
+            g = (inp @ P[f"{prefix}weight_ih_l{l}{sfx}"].t()
+                 + P[f"{prefix}bias_ih_l{l}{sfx}"] + P[f"{prefix}bias_hh_l{l}{sfx}"])
+            i, _f, gg, o = g.split(hidden, dim=-1)
+            c = torch.sigmoid(i) * torch.tanh(gg)
+            outs.append(torch.sigmoid(o) * torch.tanh(c))
+        inp = torch.cat(outs, dim=-1)
+    return inp
+
+
+def audio_encoder_features(P, x, prefix="", hidden=256):
+    """EnhancedAudioEncoder.forward, pre-extracted-feature branch, eval mode --
+    encoders.py:368-389.  x: (B, 84) -> (B, 512).  With T = 1 the attention pool's
+    softmax over time is 1, so pooled == lstm_out[:, 0]."""
+    h = lstm_t1_bidir(x, P, prefix + "lstm.", 2, hidden)
+    y = torch.relu(h @ P[prefix + "output_projection.0.weight"].t() + P[prefix + "output_projection.0.bias"])
+    y = y @ P[prefix + "output_projection.3.weight"].t() + P[prefix + "output_projection.3.bias"]
+    return _layer_norm(y, P[prefix + "output_projection.4.weight"], P[prefix + "output_projection.4.bias"])
+
+
+# --------------------------------------------------------------------------- metric
+def ccc(x, y):
+    """Concordance correlation coefficient, population variance -- metrics.py:85-101."""
+    x = x.double().flatten()
+    y = y.double().flatten()
+    mx, my = x.mean(), y.mean()
+    vx, vy = ((x - mx) ** 2).mean(), ((y - my) ** 2).mean()
+    cov = ((x - mx) * (y - my)).mean()
+    den = vx + vy + (mx - my) ** 2
+    return float(2 * cov / den) if float(den) != 0 else 0.0
+
+
+# --------------------------------------------------------------------------- train step
+def to_params(state: Dict[str, "torch.Tensor"], dtype=torch.float32, requires_grad=False):
+    P = {}
+    for k, v in state.items():
+        t = torch.as_tensor(v).detach().to(dtype).clone()
+        t.requires_grad_(requires_grad)
+        P[k] = t
+    return P
+
+
+def train_step(P, audio, video, text, targets, masks=None, p=0.3, heads=8):
+    """forward + MultiTaskDEERLoss + backward over every parameter (the bench 'step').
+    Returns (fusion_out, head_out, loss_dict, grads keyed like P)."""
+    for t in P.values():
+        t.grad = None
+    fo, ho = model_forward(P, audio, video, text, masks, p, heads)
+    ld = multitask_loss(ho, targets)
+    ld["total_loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()}
+    return fo, ho, ld, grads

@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the IMPORTED reference (build container only).
+
+Run from the repo root:  python tests/golden/make_golden.py
+Needs /root/reference (read-only); writes small .npz fixtures next to this file.
+Nothing here runs on the GPU box: the fixtures + the closed-form generators of
+``mmdeer.synth`` are all that travels.
+
+What is captured (SURVEY 8c golden-vector plan):
+  * stackc_B{1,7,32}.npz  -- HierarchicalMultimodalFusion -> MultiDimensionalDEER ->
+    MultiTaskDEERLoss with closed-form parameters: eval-mode outputs, and
+    dropout=0.0 train-mode loss components + gradient digests.
+  * stackc_missing.npz    -- audio-only / text-only batches (other modalities zeroed).
+  * loss_cases.npz        -- losses.DEERLoss / MultiTaskDEERLoss / CombinedDEERLoss /
+    UncertaintyRegularizationLoss / CalibrationLoss / deer.DEERLoss on hand-made
+    NIG parameters incl. extreme pre-activations and empty / single-element ECE bins.
+  * side_kernels.npz      -- deer.CrossModalAttention, HierarchicalDEERFusion's three
+    encoders, EnhancedAudioEncoder feature branch (eval).
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("MMDEER_REFERENCE", "/root/reference")
+sys.path[:0] = [os.path.join(REF, "src", "models"), os.path.join(REF, "src", "utils")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import deer as ref_deer  # noqa: E402  (reference)
+import fusion as ref_fusion  # noqa: E402  (reference)
+import losses as ref_losses  # noqa: E402  (reference)
+
+from mmdeer import synth  # noqa: E402
+from mmdeer.spec import DIM_NAMES, param_table  # noqa: E402
+
+torch.set_num_threads(4)
+GRAD_SLICE = 48
+
+
+def build_reference(dropout):
+    f = ref_fusion.HierarchicalMultimodalFusion(84, 256, 768, fusion_dim=512, intermediate_dim=256,
+                                                num_attention_heads=8, dropout=dropout,
+                                                use_uncertainty_weighting=True)
+    h = ref_deer.MultiDimensionalDEER(512, emotion_dims=3, hidden_dim=256, dropout=dropout)
+    sd = synth.closed_form_state(include_gate=True)
+    f.load_state_dict({k[len("fusion."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("fusion.")})
+    h.load_state_dict({k[len("head."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("head.")})
+    return f, h
+
+
+def tnp(t):
+    return t.detach().cpu().numpy()
+
+
+def capture_stackc(B, seed, zero=()):
+    batch = synth.make_batch(B, seed=seed)
+    for z in zero:
+        batch[z] = np.zeros_like(batch[z])
+    a, v, t, y = (torch.from_numpy(batch[k]) for k in ("audio", "video", "text", "targets"))
+    out = {}
+    # eval-mode forward
+    f, h = build_reference(0.3)
+    f.eval(); h.eval()
+    with torch.no_grad():
+        fo = f(a, v, t)
+        ho = h(fo["fused_features"])
+    for k in ("fused_features", "audiovisual_features", "trimodal_features", "trimodal_attention_weights"):
+        out["eval." + k] = tnp(fo[k])
+    out["eval.av_attention.audio_to_video"] = tnp(fo["av_attention_weights"]["audio_to_video"])
+    out["eval.av_attention.video_to_audio"] = tnp(fo["av_attention_weights"]["video_to_audio"])
+    for k, val in ho.items():
+        out["eval." + k] = tnp(val)
+    # train-mode, dropout disabled: loss + gradients
+    f, h = build_reference(0.0)
+    f.train(); h.train()
+    loss_fn = ref_losses.MultiTaskDEERLoss()
+    fo = f(a, v, t)
+    ho = h(fo["fused_features"])
+    ld = loss_fn(ho, y)
+    ld["total_loss"].backward()
+    for k, val in ld.items():
+        out["loss." + k] = np.asarray(float(val), dtype=np.float64)
+    named = {"fusion." + n: p for n, p in f.named_parameters()}
+    named.update({"head." + n: p for n, p in h.named_parameters()})
+    for name, _, _ in param_table():
+        g = named[name].grad
+        g = torch.zeros_like(named[name]) if g is None else g
+        out["gnorm." + name] = np.asarray(float(g.double().norm()), dtype=np.float64)
+        out["gsum." + name] = np.asarray(float(g.double().sum()), dtype=np.float64)
+        flat = tnp(g).reshape(-1)
+        out["ghead." + name] = flat[:GRAD_SLICE].copy()
+        out["gtail." + name] = flat[-GRAD_SLICE:].copy()
+    gate = [p.grad for n, p in f.named_parameters() if n.startswith("uncertainty_gate.")]
+    out["gate_grads_all_none"] = np.asarray(all(g is None for g in gate))
+    return out
+
+
+def nig_cases():
+    """Hand-made raw evidence (B,3,4) incl. extremes; targets (B,3)."""
+    rng_u = synth.uniform01(991, 64 * 12).reshape(64, 3, 4) * 6.0 - 3.0
+    e = rng_u.copy()
+    e[0, :, 1:] = 25.0       # softplus threshold (x > 20 -> identity)
+    e[1, :, 1:] = -25.0      # tiny evidence
+    e[2, 0, 2] = -104.0      # alpha-1 underflows to 0 -> inf uncertainty
+    e[3, :, 2] = 19.999      # just under the softplus threshold
+    e[4, :, 2] = 20.001
+    y = np.tanh(synth.normal(992, 64 * 3).reshape(64, 3))
+    return e.astype(np.float32), y.astype(np.float32)
+
+
+def capture_losses():
+    import torch.nn.functional as F
+    out = {}
+    e, y = nig_cases()
+    out["evidence"] = e
+    out["targets"] = y
+    et = torch.from_numpy(e)
+    yt = torch.from_numpy(y)
+    mu = et[..., 0]
+    nu = F.softplus(et[..., 1]) + 1e-6
+    alpha = F.softplus(et[..., 2]) + 1.0
+    beta = F.softplus(et[..., 3]) + 1e-6
+    for nm, val in (("mu", mu), ("nu", nu), ("alpha", alpha), ("beta", beta)):
+        out["nig." + nm] = tnp(val)
+    # regular rows only (5..63) for the finite-loss cases; extremes get their own entry
+    for tag, sl in (("reg", slice(5, 64)), ("all", slice(0, 64)), ("one", slice(7, 8)), ("two", slice(9, 11))):
+        pred = {}
+        for i, d in enumerate(DIM_NAMES):
+            pred[f"{d}_mu"] = mu[sl, i:i + 1]
+            pred[f"{d}_nu"] = nu[sl, i:i + 1]
+            pred[f"{d}_alpha"] = alpha[sl, i:i + 1]
+            pred[f"{d}_beta"] = beta[sl, i:i + 1]
+        ld = ref_losses.MultiTaskDEERLoss()(pred, yt[sl])
+        for k, val in ld.items():
+            out[f"multitask.{tag}.{k}"] = np.asarray(float(val), dtype=np.float64)
+        lc = ref_losses.CombinedDEERLoss()(pred, yt[sl])
+        out[f"combined.{tag}.combined_total_loss"] = np.asarray(float(lc["combined_total_loss"]), dtype=np.float64)
+        # basic losses.DEERLoss on (B,3) tensors and 1-D targets path
+        lb = ref_losses.DEERLoss()({"gamma": mu[sl], "nu": nu[sl], "alpha": alpha[sl], "beta": beta[sl]}, yt[sl])
+        for k, val in lb.items():
+            out[f"basic.{tag}.{k}"] = np.asarray(float(val), dtype=np.float64)
+        l1 = ref_losses.DEERLoss()({"mu": mu[sl, 0], "lambda": nu[sl, 0], "alpha": alpha[sl, 0], "beta": beta[sl, 0]},
+                                   yt[sl, 0:1])
+        out[f"basic1d.{tag}.total_loss"] = np.asarray(float(l1["total_loss"]), dtype=np.float64)
+        # flat-key extras
+        flat = {"gamma": mu[sl], "alpha": alpha[sl], "beta": beta[sl]}
+        if sl.stop - sl.start > 1:
+            ur = ref_losses.UncertaintyRegularizationLoss()(flat, yt[sl])
+            for k, val in ur.items():
+                out[f"unc_reg.{tag}.{k}"] = np.asarray(float(val), dtype=np.float64)
+        out[f"calibration.{tag}"] = np.asarray(float(ref_losses.CalibrationLoss()(flat, yt[sl])), dtype=np.float64)
+        # variant-1 loss (deer.py) per dimension 0, defaults and the self-test's kw=0.1
+        for kw in (1.0, 0.1):
+            l0 = ref_deer.DEERLoss(kl_weight=kw)({"mu": mu[sl, 0:1], "nu": nu[sl, 0:1], "alpha": alpha[sl, 0:1],
+                                                   "beta": beta[sl, 0:1]}, yt[sl, 0])
+            for k, val in l0.items():
+                out[f"v1.kw{kw}.{tag}.{k}"] = np.asarray(float(val), dtype=np.float64)
+    # gradient of the multitask loss wrt raw evidence on the regular rows
+    er = et[5:64].clone().requires_grad_(True)
+    pred = {}
+    for i, d in enumerate(DIM_NAMES):
+        pred[f"{d}_mu"] = er[:, i, 0:1]
+        pred[f"{d}_nu"] = F.softplus(er[:, i, 1:2]) + 1e-6
+        pred[f"{d}_alpha"] = F.softplus(er[:, i, 2:3]) + 1.0
+        pred[f"{d}_beta"] = F.softplus(er[:, i, 3:4]) + 1e-6
+    ref_losses.MultiTaskDEERLoss()(pred, yt[5:64])["total_loss"].backward()
+    out["multitask.reg.devidence"] = tnp(er.grad)
+    out["linspace11"] = tnp(torch.linspace(0, 1, 11))
+    out["linspace16"] = tnp(torch.linspace(0, 1, 16))
+    return out
+
+
+def fill_module(mod, tag):
+    """Closed-form fill of an arbitrary reference module; returns the numpy state."""
+    sd = {}
+    for name, p in mod.state_dict().items():
+        n = p.numel()
+        u = synth.uniform01(synth._stream_of(tag + "." + name), n) * 2.0 - 1.0
+        if p.dim() >= 2:
+            fan_out, fan_in = p.shape[0], p.shape[1]
+            w = u * np.sqrt(6.0 / (fan_in + fan_out))
+        elif name.endswith("weight"):
+            w = 1.0 + 0.1 * u       # LayerNorm gamma
+        else:
+            w = 0.05 * u
+        sd[name] = w.reshape(tuple(p.shape)).astype(np.float32)
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return sd
+
+
+def capture_side():
+    out = {}
+    B = 9
+    x = {k: synth.normal(500 + i, B * 256).reshape(B, 256).astype(np.float32)
+         for i, k in enumerate(("audio", "video", "text"))}
+    cma = ref_deer.CrossModalAttention(256, num_heads=8).eval()
+    fill_module(cma, "cma")
+    with torch.no_grad():
+        wa, wv = cma(*(torch.from_numpy(x[k]) for k in ("audio", "video", "text")))
+    out["cma.audio"], out["cma.video"] = tnp(wa), tnp(wv)
+    for k in x:
+        out["cma.in." + k] = x[k]
+    hd = ref_deer.HierarchicalDEERFusion().eval()
+    fill_module(hd, "hdf")
+    batch = synth.make_batch(B, seed=77)
+    with torch.no_grad():
+        out["hdf.audio_encoded"] = tnp(torch.relu(hd.audio_encoder(torch.from_numpy(batch["audio"]))))
+        out["hdf.video_encoded"] = tnp(torch.relu(hd.video_encoder(torch.from_numpy(batch["video"]))))
+        out["hdf.text_encoded"] = tnp(torch.relu(hd.text_encoder(torch.from_numpy(batch["text"]))))
+    # EnhancedAudioEncoder feature branch: encoders.py imports librosa / cv2 at module
+    # level; neither is installed and neither is touched by the feature branch, so empty
+    # placeholder modules are enough to import the file.
+    for missing in ("librosa", "cv2"):
+        if missing not in sys.modules:
+            m = types.ModuleType(missing)
+            m.__spec__ = __import__("importlib.machinery").machinery.ModuleSpec(missing, None)
+            sys.modules[missing] = m
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        import encoders as ref_enc  # (reference)
+        enc = ref_enc.EnhancedAudioEncoder().eval()
+    fill_module(enc, "aenc")
+    with torch.no_grad():
+        out["aenc.out"] = tnp(enc(torch.from_numpy(batch["audio"])))
+    return out
+
+
+def main():
+    for B in (1, 7, 32):
+        np.savez_compressed(os.path.join(HERE, f"stackc_B{B}.npz"), **capture_stackc(B, seed=42))
+    miss = {}
+    for tag, zero in (("audio_only", ("video", "text")), ("text_only", ("audio", "video"))):
+        for k, v in capture_stackc(8, seed=43, zero=zero).items():
+            if k.startswith("eval.") or k.startswith("loss.") or k.startswith("gnorm."):
+                miss[f"{tag}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "stackc_missing.npz"), **miss)
+    np.savez_compressed(os.path.join(HERE, "loss_cases.npz"), **capture_losses())
+    np.savez_compressed(os.path.join(HERE, "side_kernels.npz"), **capture_side())
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

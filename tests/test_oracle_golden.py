@@ -1,0 +1,215 @@
+"""Pin the CPU oracle against vectors captured from the imported reference
+(tests/golden/make_golden.py).  CPU-only; runs in the build container and on the
+GPU box alike (no /root/reference access)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mmdeer import synth
+from mmdeer.spec import DIM_NAMES, param_table
+from oracle import deer_oracle as O
+
+GRAD_SLICE = 48
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _batch(B, seed, zero=()):
+    b = synth.make_batch(B, seed=seed)
+    for z in zero:
+        b[z] = np.zeros_like(b[z])
+    return [torch.from_numpy(b[k]) for k in ("audio", "video", "text", "targets")]
+
+
+@pytest.mark.parametrize("B", [1, 7, 32])
+def test_stackc_eval_forward(golden_dir, B):
+    g = _load(golden_dir, f"stackc_B{B}.npz")
+    P = O.to_params(synth.closed_form_state())
+    a, v, t, _ = _batch(B, 42)
+    with torch.no_grad():
+        fo, ho = O.model_forward(P, a, v, t)
+    for k in ("fused_features", "audiovisual_features", "trimodal_features", "trimodal_attention_weights"):
+        np.testing.assert_allclose(fo[k].numpy(), g["eval." + k], rtol=1e-5, atol=2e-5, err_msg=k)
+    np.testing.assert_array_equal(fo["av_attention_weights"]["audio_to_video"].numpy(),
+                                  g["eval.av_attention.audio_to_video"])
+    np.testing.assert_array_equal(fo["av_attention_weights"]["video_to_audio"].numpy(),
+                                  g["eval.av_attention.video_to_audio"])
+    for k, val in ho.items():
+        np.testing.assert_allclose(val.numpy(), g["eval." + k], rtol=2e-5, atol=1e-5, err_msg=k)
+    assert fo["uncertainty_weights"] is None
+
+
+@pytest.mark.parametrize("B", [1, 7, 32])
+def test_stackc_loss_and_grads(golden_dir, B):
+    g = _load(golden_dir, f"stackc_B{B}.npz")
+    P = O.to_params(synth.closed_form_state(), requires_grad=True)
+    a, v, t, y = _batch(B, 42)
+    _, _, ld, grads = O.train_step(P, a, v, t, y)
+    for k, val in ld.items():
+        if k.startswith("_") or k.endswith("_bin_counts"):
+            continue
+        assert float(val) == pytest.approx(float(g["loss." + k]), rel=2e-5, abs=2e-6), k
+    for name, _, _ in param_table():
+        gr = grads[name].detach()
+        ref_norm = float(g["gnorm." + name])
+        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=2e-4, abs=1e-7), name
+        flat = gr.numpy().reshape(-1)
+        tol = 2e-5 * max(ref_norm, 1e-3)
+        np.testing.assert_allclose(flat[:GRAD_SLICE], g["ghead." + name], rtol=1e-4, atol=tol, err_msg=name)
+        np.testing.assert_allclose(flat[-GRAD_SLICE:], g["gtail." + name], rtol=1e-4, atol=tol, err_msg=name)
+    assert bool(g["gate_grads_all_none"])
+    # dead AV q/k rows: exact zeros
+    w = grads["fusion.audio_visual_fusion.cross_attention.in_proj_weight"]
+    assert float(w[:512].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tag,zero", [("audio_only", ("video", "text")), ("text_only", ("audio", "video"))])
+def test_stackc_missing_modalities(golden_dir, tag, zero):
+    g = _load(golden_dir, "stackc_missing.npz")
+    P = O.to_params(synth.closed_form_state(), requires_grad=True)
+    a, v, t, y = _batch(8, 43, zero)
+    fo, ho, ld, grads = O.train_step(P, a, v, t, y)
+    assert float(ld["total_loss"]) == pytest.approx(float(g[f"{tag}/loss.total_loss"]), rel=2e-5)
+    with torch.no_grad():
+        fo, ho = O.model_forward(P, a, v, t)
+    np.testing.assert_allclose(ho["mu_all"].numpy(), g[f"{tag}/eval.mu_all"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ho["uncertainty_all"].numpy(), g[f"{tag}/eval.uncertainty_all"], rtol=1e-5, atol=2e-6)
+
+
+def _nig(g):
+    e = torch.from_numpy(g["evidence"])
+    return O.nig_activations(e), torch.from_numpy(g["targets"])
+
+
+def test_nig_activations_and_edges(golden_dir):
+    g = _load(golden_dir, "loss_cases.npz")
+    (mu, nu, alpha, beta, *_), _ = _nig(g)
+    for nm, val in (("mu", mu), ("nu", nu), ("alpha", alpha), ("beta", beta)):
+        np.testing.assert_array_equal(val.numpy(), g["nig." + nm])
+    np.testing.assert_array_equal(np.asarray(O.ECE_EDGES_10, dtype=np.float32), g["linspace11"])
+    np.testing.assert_array_equal(np.asarray(O.CAL_EDGES_15, dtype=np.float32), g["linspace16"])
+    # alpha - 1 underflow row gives an infinite uncertainty, as in the reference
+    assert torch.isinf((beta / (alpha - 1))[2, 0])
+
+
+@pytest.mark.parametrize("tag,sl", [("reg", slice(5, 64)), ("all", slice(0, 64)), ("one", slice(7, 8)), ("two", slice(9, 11))])
+def test_loss_variants(golden_dir, tag, sl):
+    g = _load(golden_dir, "loss_cases.npz")
+    (mu, nu, alpha, beta, *_), y = _nig(g)
+    pred = {}
+    for i, d in enumerate(DIM_NAMES):
+        pred[f"{d}_mu"], pred[f"{d}_nu"] = mu[sl, i:i + 1], nu[sl, i:i + 1]
+        pred[f"{d}_alpha"], pred[f"{d}_beta"] = alpha[sl, i:i + 1], beta[sl, i:i + 1]
+    ld = O.multitask_loss(pred, y[sl])
+
+    def close(val, ref, what):
+        ref = float(ref)
+        if np.isnan(ref) or np.isinf(ref):
+            assert (np.isnan(float(val)) and np.isnan(ref)) or float(val) == ref, what
+        else:
+            assert float(val) == pytest.approx(ref, rel=3e-5, abs=3e-6), what
+
+    for k, val in ld.items():
+        if k.endswith("_bin_counts"):
+            continue
+        close(val, g[f"multitask.{tag}.{k}"], k)
+    # CombinedDEERLoss == MultiTaskDEERLoss on per-dimension keys (both extras return 0)
+    close(ld["total_loss"], g[f"combined.{tag}.combined_total_loss"], "combined")
+    lb = O.deer_loss_v2(mu[sl], nu[sl], alpha[sl], beta[sl], y[sl])
+    for k in ("total_loss", "nll_loss", "reg_loss", "kl_loss", "ece_loss"):
+        close(lb[k], g[f"basic.{tag}.{k}"], "basic." + k)
+    assert lb["batch_size"] == int(g[f"basic.{tag}.batch_size"])
+    l1 = O.deer_loss_v2(mu[sl, 0], nu[sl, 0], alpha[sl, 0], beta[sl, 0], y[sl, 0:1])
+    close(l1["total_loss"], g[f"basic1d.{tag}.total_loss"], "basic1d")
+    if sl.stop - sl.start > 1:
+        ur = O.uncertainty_reg_loss(alpha[sl], beta[sl])
+        for k, val in ur.items():
+            close(val, g[f"unc_reg.{tag}.{k}"], k)
+    close(O.calibration_loss(mu[sl], alpha[sl], beta[sl], y[sl]), g[f"calibration.{tag}"], "calibration")
+    for kw in (1.0, 0.1):
+        l0 = O.deer_loss_v1(mu[sl, 0:1], nu[sl, 0:1], alpha[sl, 0:1], beta[sl, 0:1], y[sl, 0], kl_weight=kw)
+        for k, val in l0.items():
+            close(val, g[f"v1.kw{kw}.{tag}.{k}"], f"v1.{kw}.{k}")
+
+
+def test_loss_gradient_wrt_evidence(golden_dir):
+    g = _load(golden_dir, "loss_cases.npz")
+    e = torch.from_numpy(g["evidence"])[5:64].clone().requires_grad_(True)
+    y = torch.from_numpy(g["targets"])[5:64]
+    mu, nu, alpha, beta, *_ = O.nig_activations(e)
+    pred = {}
+    for i, d in enumerate(DIM_NAMES):
+        pred[f"{d}_mu"], pred[f"{d}_nu"] = mu[:, i:i + 1], nu[:, i:i + 1]
+        pred[f"{d}_alpha"], pred[f"{d}_beta"] = alpha[:, i:i + 1], beta[:, i:i + 1]
+    O.multitask_loss(pred, y)["total_loss"].backward()
+    np.testing.assert_allclose(e.grad.numpy(), g["multitask.reg.devidence"], rtol=2e-4, atol=1e-7)
+
+
+def test_side_kernels(golden_dir):
+    g = _load(golden_dir, "side_kernels.npz")
+
+    def fill(shapes, tag):
+        P = {}
+        for name, shape in shapes.items():
+            n = int(np.prod(shape))
+            u = synth.uniform01(synth._stream_of(tag + "." + name), n) * 2.0 - 1.0
+            if len(shape) >= 2:
+                w = u * np.sqrt(6.0 / (shape[0] + shape[1]))
+            elif name.endswith("weight"):
+                w = 1.0 + 0.1 * u
+            else:
+                w = 0.05 * u
+            P[name] = torch.from_numpy(w.reshape(shape).astype(np.float32))
+        return P
+
+    lin = lambda n, o, i: {n + ".weight": (o, i), n + ".bias": (o,)}
+    shapes = {}
+    for n in ("query_proj", "key_proj", "value_proj", "output_proj"):
+        shapes.update(lin(n, 256, 256))
+    shapes.update(lin("uncertainty_gate.0", 256, 768))
+    shapes.update(lin("uncertainty_gate.2", 2, 256))
+    P = fill(shapes, "cma")
+    wa, wv = O.cross_modal_attention(P, *(torch.from_numpy(g["cma.in." + k]) for k in ("audio", "video", "text")))
+    np.testing.assert_allclose(wa.numpy(), g["cma.audio"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(wv.numpy(), g["cma.video"], rtol=1e-5, atol=1e-6)
+    assert wa.shape == (9, 32)
+
+    # HierarchicalDEERFusion state_dict order: encoders first (fill is name-keyed anyway)
+    shapes = {}
+    shapes.update(lin("audio_encoder", 256, 84)); shapes.update(lin("video_encoder", 256, 256))
+    shapes.update(lin("text_encoder", 256, 768))
+    P = fill(shapes, "hdf")
+    b = synth.make_batch(9, seed=77)
+    ea, ev, et = O.modality_encoders(P, *(torch.from_numpy(b[k]) for k in ("audio", "video", "text")))
+    np.testing.assert_allclose(ea.numpy(), g["hdf.audio_encoded"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ev.numpy(), g["hdf.video_encoded"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(et.numpy(), g["hdf.text_encoded"], rtol=1e-5, atol=1e-6)
+
+    shapes = {}
+    for l, inp in ((0, 84), (1, 512)):
+        for sfx in ("", "_reverse"):
+            shapes[f"lstm.weight_ih_l{l}{sfx}"] = (1024, inp)
+            shapes[f"lstm.weight_hh_l{l}{sfx}"] = (1024, 256)
+            shapes[f"lstm.bias_ih_l{l}{sfx}"] = (1024,)
+            shapes[f"lstm.bias_hh_l{l}{sfx}"] = (1024,)
+    shapes.update(lin("attention.0", 256, 512)); shapes.update(lin("attention.2", 1, 256))
+    shapes.update(lin("output_projection.0", 512, 512)); shapes.update(lin("output_projection.3", 512, 512))
+    shapes.update({"output_projection.4.weight": (512,), "output_projection.4.bias": (512,)})
+    P = fill(shapes, "aenc")
+    out = O.audio_encoder_features(P, torch.from_numpy(b["audio"]))
+    np.testing.assert_allclose(out.numpy(), g["aenc.out"], rtol=1e-4, atol=5e-6)
+
+
+def test_ccc_formula():
+    x = torch.tensor([0.1, 0.4, -0.3, 0.9, 0.0])
+    y = torch.tensor([0.2, 0.35, -0.1, 0.7, 0.05])
+    # independent evaluation of metrics.py:85-101 with numpy
+    xn, yn = x.double().numpy(), y.double().numpy()
+    ref = 2 * np.corrcoef(xn, yn)[0, 1] * np.sqrt(xn.var()) * np.sqrt(yn.var()) / (
+        xn.var() + yn.var() + (xn.mean() - yn.mean()) ** 2)
+    assert O.ccc(x, y) == pytest.approx(ref, rel=1e-12)
+    assert O.ccc(x, x) == pytest.approx(1.0)
