@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- samples/sec of one training step (forward + MultiTaskDEERLoss + backward, gradients
+materialised) of the fusion + DEER path at B = 4096 per GPU, bf16 MFMA / fp32 accumulate
+(BASELINE.json configs[2]; with --gpus N the same per-GPU batch, data parallel: configs[3]).
+
+Contract: W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both
+sides, MAX over ranks, rank 0 prints ONE JSON line.  `roofline` is the trimodal in_proj GEMM
+(M = 2B, K = 512, N = 1536), timed in situ with HIP events recorded around its launch on the launch
+stream.  `cpu_baseline` is the CPU oracle's train step (a port, validated against the imported
+reference by tests/test_oracle_golden.py) on the host cores, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BF16_MFMA_PEAK = 2.5e15   # dense bf16 FLOP/s, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+F32_MFMA_PEAK = 157.3e12
+
+
+def cpu_baseline(batch, seconds=12.0):
+    """Time the oracle's fwd + loss + bwd (torch-CPU fp32) on all host cores for ~`seconds`."""
+    from mmdeer import synth
+    from oracle import deer_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = {k: torch.from_numpy(v) for k, v in synth.make_batch(batch, seed=42).items()}
+    P = O.to_params(synth.reference_init_state(include_gate=False), requires_grad=True)
+    g = torch.Generator().manual_seed(0)
+
+    def masks():
+        k = lambda *s: (torch.rand(*s, generator=g) < 0.7)  # noqa: E731
+        return {"av_attn_a2v": k(batch, 8), "av_attn_v2a": k(batch, 8), "av_fuse": k(batch, 256),
+                "tri_attn": k(batch, 8, 2, 2), "tri_fuse": k(batch, 512), "out_proj": k(batch, 512),
+                "fp0": k(batch, 256), "fp1": k(batch, 256), "ev0": k(batch, 3, 128), "ev1": k(batch, 3, 64)}
+
+    def step():
+        O.train_step(P, b["audio"], b["video"], b["text"], b["targets"], masks=masks(), p=0.3)
+
+    for _ in range(2):
+        step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 3:
+            break
+    return {"value": round(batch * n / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps (fwd + MultiTaskDEERLoss + bwd, dropout masks drawn per step) at B={batch}, "
+                      f"torch-CPU fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="samples per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from mmdeer import synth
+    from mmdeer.model import ModelConfig, MultimodalDEER
+    from mmdeer.parallel import BucketedAllReduce
+
+    B = args.batch
+    model = MultimodalDEER(ModelConfig(compute_dtype=args.dtype, dropout=0.3, seed=42)).to(dev).train()
+    data = synth.make_batch(B, seed=42, row_offset=rank * B)       # rank r owns rows [rB, (r+1)B) of the global stream
+    a, v, t, y = (torch.from_numpy(data[k]).to(dev) for k in ("audio", "video", "text", "targets"))
+    if args.dtype == "bf16":
+        a, v, t = a.bfloat16(), v.bfloat16(), t.bfloat16()         # BASELINE configs 3-5: bf16 feature blocks
+    comm = BucketedAllReduce(device=dev) if world > 1 else None
+    K, W = args.steps, args.warmup
+    prof = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    for e0, e1 in prof:
+        e0.record(); e1.record()
+
+    def one_step(i=None):
+        # parameters change every real training step, so the fp32 -> bf16 weight pack is part of every timed step
+        model._st.packed_key = None
+        ev = comm.events if comm else None
+        ld = model.train_step(a, v, t, y, events=ev, prof_events=prof[i] if i is not None else None)
+        if comm:
+            comm.launch(model.flat_grad())
+            comm.wait()
+        return ld
+
+    for _ in range(W):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        ld = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss = float(ld["total_loss"])
+    assert loss == loss, "loss is NaN"
+
+    if rank == 0:
+        gemm_ms = sorted(e0.elapsed_time(e1) for e0, e1 in prof)
+        avg_ms = sum(gemm_ms) / len(gemm_ms)
+        flops = 2.0 * (2 * B) * 512 * 1536                      # algorithmic: SURVEY 8d, 3.146 MFLOP/sample forward
+        peak = BF16_MFMA_PEAK if args.dtype == "bf16" else F32_MFMA_PEAK
+        achieved = flops / (avg_ms * 1e-3)
+        out = {
+            "metric": "samples/sec fwd+bwd at B=4096 (84/256/768-dim)",
+            "value": round(world * B * K / elapsed, 1),
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"configs[2]: fusion+DEER train step (fwd + MultiTaskDEERLoss + bwd, dropout 0.3, "
+                                   f"weight pack included), B={B}/GPU, (B,84)+(B,256)+(B,768) {args.dtype} feature blocks, "
+                                   f"random-init weights", "global_batch": world * B,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "final_loss": round(loss, 6),
+            "roofline": {"bound": "mfma", "kernel": "gemm_group_kernel (trimodal in_proj, M=2B K=512 N=1536)",
+                         "achieved": round(achieved / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(gemm_ms[len(gemm_ms) // 2] * 1e3, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,183 @@
+/* mmdeer.h -- C ABI of libmmdeer_hip.so: the MI355X (gfx950) implementation of the
+ * multimodal-fusion + DEER forward / loss / backward hot path.
+ *
+ * The reference has no FFI: its boundary is the Python nn.Module protocol
+ * (SURVEY.md 8b).  Each entry point below replaces the torch-op sequence of the
+ * cited reference function; the host-side mirror (mmdeer/model.py: MultimodalDEER,
+ * compute_loss, DEERTrainer) binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; every buffer (inputs, outputs, parameters,
+ *    workspace, gradients) is DEVICE memory owned by the caller.  The library
+ *    allocates nothing and keeps no global state.
+ *  - Every call only ENQUEUES work on `stream` (a hipStream_t passed as void*)
+ *    and never synchronises the device: calls are graph-capturable.
+ *  - Return value: 0 = ok, -1 = error; the message is in mmdeer_last_error()
+ *    (thread-local).  No C++ exception crosses the ABI.
+ *  - Matrices are row-major.  "act dtype" is fp32 when compute_f32 != 0, else bf16.
+ */
+#ifndef MMDEER_H_
+#define MMDEER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMDEER_ABI_VERSION 1
+
+/* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
+#define MMDEER_AUDIO_DIM 84
+#define MMDEER_VIDEO_DIM 256
+#define MMDEER_TEXT_DIM 768
+#define MMDEER_INTER_DIM 256
+#define MMDEER_FUSION_DIM 512
+#define MMDEER_NUM_HEADS 8
+#define MMDEER_HIDDEN_DIM 256
+#define MMDEER_NUM_DIMS 3        /* valence, arousal, dominance */
+#define MMDEER_NUM_PARAMS_ABI 50 /* canonical parameter order: mmdeer_param_name(i) */
+#define MMDEER_LOSS_OUT 17       /* per dim {total,nll,reg,kl,ece} x3, cross_dim, total */
+
+const char* mmdeer_version(void);
+int mmdeer_abi_version(void);
+const char* mmdeer_last_error(void);
+
+/* canonical parameter table (order of `params` / layout of the flat gradient buffer) */
+int mmdeer_num_params(void);
+const char* mmdeer_param_name(int i);          /* reference state_dict key with fusion./head. prefix */
+int mmdeer_param_rows(int i);
+int mmdeer_param_cols(int i);                  /* 1 for vectors */
+long long mmdeer_param_offset(int i);          /* element offset in the flat buffers */
+long long mmdeer_flat_elems(void);             /* elements of the flat gradient buffer */
+
+/* bytes of `workspace` needed for a batch of B samples (holds packed weights, saved activations, scratch) */
+size_t mmdeer_workspace_bytes(int batch, int compute_f32);
+
+typedef struct mmdeer_loss_cfg {
+  float reg_weight;    /* losses.py:52  0.1  */
+  float kl_weight;     /* losses.py:52  0.01 */
+  float ece_weight;    /* losses.py:53  0.05 */
+  float cross_weight;  /* losses.py:239 0.05 */
+  float task_weight[3];/* losses.py:256-259 */
+} mmdeer_loss_cfg;
+
+/* Forward of HierarchicalMultimodalFusion (fusion.py:119-171, uncertainties=None) followed by
+ * MultiDimensionalDEER (deer.py:233-266).  With `targets` the per-block statistics of
+ * MultiTaskDEERLoss (losses.py:268-348) are accumulated in the same pass. */
+typedef struct mmdeer_forward_args {
+  int32_t batch;
+  int32_t compute_f32;      /* 1: exact-fp32 MFMA path (parity config); 0: bf16 MFMA, fp32 accumulate */
+  int32_t training;         /* 1: dropout active (counter-based Philox keyed by seed/offset) */
+  int32_t inputs_bf16;      /* 0: audio/video/text are fp32; 1: bf16 */
+  int32_t repack;           /* 1: parameters changed since the last call with this workspace */
+  float dropout_p;
+  uint64_t seed, offset;
+  const void* audio;        /* [B, 84]  */
+  const void* video;        /* [B, 256] */
+  const void* text;         /* [B, 768] */
+  const void* const* params;/* MMDEER_NUM_PARAMS_ABI fp32 device pointers, canonical order */
+  void* workspace;
+  size_t workspace_bytes;
+  /* fp32 outputs; any may be NULL */
+  float* nig_out;           /* [7][B][3]: mu, nu, alpha, beta, aleatoric, epistemic, uncertainty (deer.py:100-108) */
+  float* fused_features;    /* [B, 512]  fusion.py:165 */
+  float* audiovisual_features; /* [B, 256] */
+  float* trimodal_features; /* [B, 512] */
+  float* av_attention;      /* [B, 2]: audio_to_video, video_to_audio  (fusion.py:267-270) */
+  float* trimodal_attention;/* [B, 2, 2]                               (fusion.py:342) */
+  const float* targets;     /* [B, 3] or NULL */
+  /* optional hipEvent_t pair recorded immediately before / after the trimodal in_proj GEMM launch
+   * (M = 2B, K = 512, N = 1536 -- the roofline kernel of BASELINE.json); NULL = not recorded */
+  void* prof_events[2];
+  void* stream;
+} mmdeer_forward_args;
+
+int mmdeer_forward(const mmdeer_forward_args* a);
+
+/* Backward through the whole path, using the activations `mmdeer_forward` left in `workspace`.
+ *   loss mode  (targets != NULL): d MultiTaskDEERLoss / d parameters; loss_out / bin_counts are filled.
+ *   chain mode (targets == NULL): g_mu/g_nu/g_alpha/g_beta [B,3] are upstream gradients (each may be NULL).
+ * grads: flat fp32 buffer of mmdeer_flat_elems() elements; every live parameter's slice is overwritten. */
+typedef struct mmdeer_backward_args {
+  int32_t batch;
+  int32_t compute_f32;
+  int32_t training;
+  int32_t inputs_bf16;
+  float dropout_p;
+  uint64_t seed, offset;    /* the values given to the matching mmdeer_forward */
+  const void* audio;
+  const void* video;
+  const void* text;
+  void* workspace;
+  size_t workspace_bytes;
+  const float* targets;
+  const float* g_mu;
+  const float* g_nu;
+  const float* g_alpha;
+  const float* g_beta;
+  mmdeer_loss_cfg loss;
+  float* grads;
+  float* loss_out;          /* [MMDEER_LOSS_OUT] or NULL */
+  int32_t* bin_counts;      /* [3][10] ECE bin populations or NULL */
+  /* optional: hipEvent_t handles recorded after gradient buckets complete (for overlapping the DP all-reduce):
+   * bucket 0 = head (params 28..49), 1 = output_projection + trimodal (12..27), 2 = audio-visual (0..11) */
+  void* bucket_events[3];
+  void* stream;
+} mmdeer_backward_args;
+
+int mmdeer_backward(const mmdeer_backward_args* a);
+
+/* bucket boundaries used by bucket_events: elements [mmdeer_bucket_begin(i), mmdeer_bucket_end(i)) of the flat buffer */
+long long mmdeer_bucket_begin(int bucket);
+long long mmdeer_bucket_end(int bucket);
+
+/* ---- single operators (unit tests, and the building blocks of the two calls above) ---------------- */
+
+/* C[M,N] = act(A[M,K] * W[N,K]^T + bias) with optional dropout; the `linear_act` part of SURVEY 8b.
+ * a_f32 / w_f32 / c_f32: storage dtypes (1 fp32, 0 bf16).  trans_a / trans_w: operand stored [K][rows]. */
+typedef struct mmdeer_gemm_args {
+  const void* A; const void* W; void* C; const float* bias; float* bias_grad; const void* Y;
+  int32_t M, N, K, lda, ldw, ldc, ldy;
+  int32_t a_f32, w_f32, c_f32, y_f32, trans_a, trans_w, relu, accumulate;
+  int32_t compute_f32, tile;            /* tile: 0 = 64x64, 1 = 128x64, 2 = 128x128, -1 = auto */
+  int32_t drop_site, drop_shift, regen_site;
+  float dropout_p, mask_scale;
+  uint64_t seed, offset;
+  void* stream;
+} mmdeer_gemm_args;
+int mmdeer_gemm(const mmdeer_gemm_args* a);
+
+/* nn.LayerNorm(N), eps 1e-5 (fusion.py:102, 220, 305) */
+int mmdeer_layernorm_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,
+                         const float* beta, int M, int N, int act_f32, void* stream);
+int mmdeer_layernorm_bwd_nparts(int M);
+int mmdeer_layernorm_bwd(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
+                         void* dz, float* dgamma, float* dbeta, float* partial, int M, int N, int act_f32,
+                         float mask_scale, void* stream);
+
+/* 2-token, 8-head self-attention of TrimodalFusion (fusion.py:325-335) on a [2B,1536] q|k|v matrix */
+int mmdeer_trimodal_attn_fwd(const void* qkv, void* obar, float* probs, float* attn_w, float* av_w, int B,
+                             int act_f32, int training, float dropout_p, uint64_t seed, uint64_t offset, void* stream);
+int mmdeer_trimodal_attn_bwd(const void* qkv, const void* dobar, const float* probs, void* dqkv, int B,
+                             int act_f32, int training, float dropout_p, uint64_t seed, uint64_t offset, void* stream);
+
+/* MultiTaskDEERLoss on given NIG parameters [B,3] (losses.py:268-348); gradients optional (all four or none).
+ * stats: scratch of mmdeer_nig_stats_elems(B) floats. */
+long long mmdeer_nig_stats_elems(int B);
+int mmdeer_nig_loss(const float* gamma, const float* nu, const float* alpha, const float* beta, const float* targets,
+                    float* stats, float* dgamma, float* dnu, float* dalpha, float* dbeta, float* loss_out,
+                    int32_t* bin_counts, int B, const mmdeer_loss_cfg* cfg, void* stream);
+
+/* keep-mask of one dropout site, for test harnesses: out[r*cols + c] in {0,1} */
+int mmdeer_dropout_mask(int site, int rows, int cols, float dropout_p, uint64_t seed, uint64_t offset,
+                        unsigned char* out, void* stream);
+
+/* fp32 <-> bf16 conversion of a contiguous device buffer (n % 4 == 0) */
+int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMDEER_H_ */

@@ -242,6 +242,13 @@ def main():
     np.savez_compressed(os.path.join(HERE, "stackc_missing.npz"), **miss)
     np.savez_compressed(os.path.join(HERE, "loss_cases.npz"), **capture_losses())
     np.savez_compressed(os.path.join(HERE, "side_kernels.npz"), **capture_side())
+    import json
+    f, h = build_reference(0.3)
+    names = {"fusion": list(f.state_dict().keys()), "head": list(h.state_dict().keys()),
+             "shapes": {**{"fusion." + k: list(v.shape) for k, v in f.state_dict().items()},
+                        **{"head." + k: list(v.shape) for k, v in h.state_dict().items()}}}
+    with open(os.path.join(HERE, "state_dict_names.json"), "w") as fh:
+        json.dump(names, fh, indent=0)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -1,0 +1,257 @@
+"""GPU parity of the whole fusion + DEER path (MultimodalDEER through the C ABI) against
+the CPU oracle and the golden vectors captured from the reference.
+
+Tolerances: fp32 config <= 1e-4 abs on mu / nu / alpha / beta (BASELINE north star);
+bf16 config gated on CCC >= 0.999 and a documented absolute band (SURVEY 7 "hard parts").
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mmdeer import _lib, synth  # noqa: E402
+from mmdeer.model import ModelConfig, MultimodalDEER  # noqa: E402
+from mmdeer.spec import DIM_NAMES, param_table  # noqa: E402
+from oracle import deer_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+GRAD_SLICE = 48
+
+
+def make_model(dtype="fp32", dropout=0.3, closed_form=True, seed=42):
+    m = MultimodalDEER(ModelConfig(compute_dtype=dtype, dropout=dropout, seed=seed),
+                       init="closed_form" if closed_form else "reference")
+    return m.to(DEV)
+
+
+def batch(B, seed=42, zero=()):
+    b = synth.make_batch(B, seed=seed)
+    for z in zero:
+        b[z] = np.zeros_like(b[z])
+    return {k: torch.from_numpy(v) for k, v in b.items()}
+
+
+def oracle_params(model, dtype=torch.float32, requires_grad=False):
+    return O.to_params({k: v.detach().cpu() for k, v in model.state_dict().items()}, dtype, requires_grad)
+
+
+@pytest.mark.parametrize("B", [1, 7, 32])
+def test_forward_fp32_matches_golden_and_oracle(golden_dir, B):
+    g = dict(np.load(os.path.join(golden_dir, f"stackc_B{B}.npz")))
+    m = make_model().eval()
+    b = batch(B)
+    with torch.no_grad():
+        out = m(b["audio"].to(DEV), b["video"].to(DEV), b["text"].to(DEV))
+    torch.cuda.synchronize()
+    for k in ("fused_features", "audiovisual_features", "trimodal_features", "trimodal_attention_weights", "mu_all",
+              "uncertainty_all"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), g["eval." + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    for d in DIM_NAMES:
+        for key in ("mu", "nu", "alpha", "beta", "aleatoric_uncertainty", "epistemic_uncertainty", "uncertainty"):
+            v = out[f"{d}_{key}"]
+            assert v.shape == (B, 1)
+            np.testing.assert_allclose(v.cpu().numpy(), g[f"eval.{d}_{key}"], rtol=1e-4, atol=1e-4, err_msg=f"{d}_{key}")
+    assert torch.equal(out["av_attention_weights"]["audio_to_video"].cpu(), torch.ones(B, 1))
+    assert out["uncertainty_weights"] is None
+    assert out["gamma"].shape == (B, 3) and out["predictions"] is out["mu"]
+
+
+def test_config2_fp32_B1024_vs_cpu_oracle():
+    """BASELINE config 2: B=1024 fp32 eval forward, all outputs within 1e-4 of the CPU path; CCC per dimension."""
+    m = make_model(closed_form=False).eval()
+    b = batch(1024, seed=42)
+    with torch.no_grad():
+        out = m(b["audio"].to(DEV), b["video"].to(DEV), b["text"].to(DEV))
+        P = oracle_params(m)
+        fo, ho = O.model_forward(P, b["audio"], b["video"], b["text"])
+    for k in ("mu", "nu", "alpha", "beta"):
+        ref = torch.cat([ho[f"{d}_{k}"] for d in DIM_NAMES], dim=1)
+        err = (out[{"mu": "gamma"}.get(k, k)].cpu() - ref).abs().max().item()
+        assert err < 1e-4, (k, err)
+    assert (out["fused_features"].cpu() - fo["fused_features"]).abs().max().item() < 1e-4
+    for i in range(3):
+        assert O.ccc(out["mu_all"][:, i].cpu(), ho["mu_all"][:, i]) > 0.9999
+
+
+@pytest.mark.parametrize("B", [1, 7, 32])
+def test_train_step_fp32_grads_match_golden(golden_dir, B):
+    g = dict(np.load(os.path.join(golden_dir, f"stackc_B{B}.npz")))
+    m = make_model(dropout=0.0).train()
+    b = batch(B)
+    ld = m.train_step(b["audio"].to(DEV), b["video"].to(DEV), b["text"].to(DEV), b["targets"].to(DEV))
+    torch.cuda.synchronize()
+    for k in ("total_loss", "cross_dim_loss", "valence_nll_loss", "arousal_reg_loss", "dominance_kl_loss", "valence_ece_loss",
+              "arousal_total_loss"):
+        assert float(ld[k]) == pytest.approx(float(g["loss." + k]), rel=2e-4, abs=2e-5), k
+    named = dict(m.named_parameters())
+    for name, _, _ in param_table():
+        gr = named[name].grad
+        assert gr is not None, name
+        gr = gr.detach().cpu()
+        ref_norm = float(g["gnorm." + name])
+        assert float(gr.double().norm()) == pytest.approx(ref_norm, rel=2e-3, abs=1e-6), name
+        flat = gr.numpy().reshape(-1)
+        tol = 2e-4 * max(ref_norm, 1e-3)
+        np.testing.assert_allclose(flat[:GRAD_SLICE], g["ghead." + name], rtol=2e-3, atol=tol, err_msg=name)
+        np.testing.assert_allclose(flat[-GRAD_SLICE:], g["gtail." + name], rtol=2e-3, atol=tol, err_msg=name)
+    w = named["fusion.audio_visual_fusion.cross_attention.in_proj_weight"].grad
+    assert float(w[:512].abs().max()) == 0.0          # dead q/k rows: exact zeros
+    for n, p in m.named_parameters():
+        if "uncertainty_gate" in n:
+            assert p.grad is None
+
+
+def test_autograd_path_equals_fused_step():
+    """compute_loss(model(a,v,t), y)['total_loss'].backward() == train_step()."""
+    b = batch(48, seed=5)
+    a, v, t, y = (b[k].to(DEV) for k in ("audio", "video", "text", "targets"))
+    m1 = make_model(dropout=0.3, seed=9).train()
+    m2 = make_model(dropout=0.3, seed=9).train()
+    ld1 = m1.train_step(a, v, t, y)
+    out = m2(a, v, t)
+    ld2 = m2.compute_loss(out, y)
+    ld2["total_loss"].backward()
+    torch.cuda.synchronize()
+    assert float(ld1["total_loss"]) == pytest.approx(float(ld2["total_loss"]), rel=1e-6)
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p1.grad is None:
+            assert p2.grad is None
+            continue
+        assert torch.allclose(p1.grad, p2.grad, rtol=1e-5, atol=1e-7), n1
+    assert torch.equal(ld1["ece_bin_counts"], ld2["ece_bin_counts"])
+
+
+def dump_masks(m, B, offset):
+    """Regenerate the keep-masks of a training forward (seed, offset) for the oracle."""
+    lib = _lib.load()
+    p, seed = m.dims.dropout, m.config.seed
+    s = torch.cuda.current_stream().cuda_stream
+
+    def mask(site, rows, cols):
+        t = torch.empty(rows, cols, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.mmdeer_dropout_mask(site, rows, cols, p, seed, offset, t.data_ptr(), s))
+        return t
+    av = mask(1, 2 * B, 8)
+    masks = {
+        "av_attn_a2v": av[:B], "av_attn_v2a": av[B:],
+        "av_fuse": mask(2, B, 256), "tri_attn": mask(3, B, 32).view(B, 8, 2, 2), "tri_fuse": mask(4, B, 512),
+        "out_proj": mask(5, B, 512), "fp0": mask(6, B, 256), "fp1": mask(7, B, 256),
+        "ev0": mask(8, B, 384).view(B, 3, 128), "ev1": mask(9, B, 192).view(B, 3, 64),
+    }
+    torch.cuda.synchronize()
+    return {k: v.cpu() for k, v in masks.items()}
+
+
+def test_training_with_dropout_matches_oracle_given_the_same_masks():
+    B = 40
+    m = make_model(dropout=0.3, seed=123).train()
+    b = batch(B, seed=11)
+    ld = m.train_step(b["audio"].to(DEV), b["video"].to(DEV), b["text"].to(DEV), b["targets"].to(DEV))
+    masks = dump_masks(m, B, m._step)
+    P = oracle_params(m, torch.float64, requires_grad=True)
+    fo, ho, ldo, grads = O.train_step(P, b["audio"].double(), b["video"].double(), b["text"].double(),
+                                      b["targets"].double(), masks=masks, p=0.3)
+    out = ld["_outputs"]
+    assert (out["fused_features"].cpu().double() - fo["fused_features"]).abs().max().item() < 1e-4
+    assert (out["trimodal_attention"].cpu().double() - fo["trimodal_attention_weights"]).abs().max().item() < 1e-5
+    assert (out["av_attention"][:, 0:1].cpu().double() - fo["av_attention_weights"]["audio_to_video"]).abs().max().item() < 1e-6
+    assert float(ld["total_loss"]) == pytest.approx(float(ldo["total_loss"]), rel=2e-4)
+    named = dict(m.named_parameters())
+    for name, _, _ in param_table():
+        got, ref = named[name].grad.cpu().double(), grads[name]
+        scale = max(float(ref.abs().max()), 1e-6)
+        assert (got - ref).abs().max().item() < 2e-3 * scale + 1e-7, name
+    keep = np.mean([float(v.float().mean()) for v in masks.values()])
+    assert abs(keep - 0.7) < 0.03
+
+
+@pytest.mark.parametrize("tag,zero", [("audio_only", ("video", "text")), ("text_only", ("audio", "video"))])
+def test_missing_modalities(golden_dir, tag, zero):
+    """BASELINE config 5 semantics: a missing modality is an all-zero feature block."""
+    g = dict(np.load(os.path.join(golden_dir, "stackc_missing.npz")))
+    m = make_model().eval()
+    b = batch(8, seed=43, zero=zero)
+    with torch.no_grad():
+        out = m({"audio": b["audio"].to(DEV), "video": b["video"].to(DEV), "text": b["text"].to(DEV)})
+    np.testing.assert_allclose(out["mu_all"].cpu().numpy(), g[f"{tag}/eval.mu_all"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out["uncertainty_all"].cpu().numpy(), g[f"{tag}/eval.uncertainty_all"], rtol=1e-4, atol=1e-4)
+
+
+def test_bf16_forward_and_step_track_the_fp32_cpu_path():
+    B = 512
+    b = batch(B, seed=3)
+    m = make_model("bf16", closed_form=False, dropout=0.0).train()
+    a, v, t, y = (b[k].to(DEV) for k in ("audio", "video", "text", "targets"))
+    ld = m.train_step(a, v, t, y)
+    P = oracle_params(m, torch.float32, requires_grad=True)
+    fo, ho, ldo, grads = O.train_step(P, b["audio"], b["video"], b["text"], b["targets"])
+    out = ld["_outputs"]["_nig"].cpu()
+    ref = {k: torch.cat([ho[f"{d}_{k}"] for d in DIM_NAMES], dim=1).detach() for k in ("mu", "nu", "alpha", "beta")}
+    for i, k in enumerate(("mu", "nu", "alpha", "beta")):
+        assert (out[i] - ref[k]).abs().max().item() < 5e-2, k
+    for i in range(3):
+        assert O.ccc(out[0][:, i], ref["mu"][:, i]) > 0.999
+    assert float(ld["total_loss"]) == pytest.approx(float(ldo["total_loss"]), rel=2e-2)
+    # gradient direction: cosine similarity per large tensor
+    named = dict(m.named_parameters())
+    for name, shape, _ in param_table():
+        if len(shape) != 2 or "in_proj_weight" in name and "cross_attention" in name:
+            continue
+        gg, rr = named[name].grad.cpu().double().flatten(), grads[name].double().flatten()
+        cos = float((gg @ rr) / (gg.norm() * rr.norm() + 1e-30))
+        assert cos > 0.98, (name, cos)
+    # bf16 user inputs are accepted as-is
+    m.eval()
+    with torch.no_grad():
+        o2 = m(a.bfloat16(), v.bfloat16(), t.bfloat16())
+    assert (o2["mu_all"].cpu() - ref["mu"]).abs().max().item() < 8e-2
+
+
+def test_full_size_properties_B4096():
+    """Size-independent properties at the BASELINE batch size (no oracle run at this size):
+    permutation equivariance over the batch and determinism of the fused step."""
+    B = 4096
+    b = batch(B, seed=8)
+    a, v, t, y = (b[k].to(DEV) for k in ("audio", "video", "text", "targets"))
+    m = make_model("bf16", closed_form=False).eval()
+    with torch.no_grad():
+        o1 = m(a, v, t)["mu_all"].clone()
+        perm = torch.randperm(B, device=DEV)
+        o2 = m(a[perm], v[perm], t[perm])["mu_all"]
+    assert torch.equal(o1[perm], o2)
+    m.train()
+    step0 = m._step
+    l1 = m.train_step(a, v, t, y)
+    g1 = m.flat_grad().clone()
+    m._step = step0
+    l2 = m.train_step(a, v, t, y)
+    assert torch.equal(g1, m.flat_grad())                       # no atomics anywhere: bit-identical reruns
+    assert float(l1["total_loss"]) == float(l2["total_loss"])
+    assert int(l1["ece_bin_counts"].sum()) == 3 * B
+    assert torch.isfinite(g1).all()
+
+
+def test_empty_batch_and_errors():
+    m = make_model().eval()
+    with torch.no_grad():
+        out = m(torch.empty(0, 84, device=DEV), torch.empty(0, 256, device=DEV), torch.empty(0, 768, device=DEV))
+    assert out["mu_all"].shape == (0, 3)
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 83, device=DEV), torch.zeros(2, 256, device=DEV), torch.zeros(2, 768, device=DEV))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 84), torch.zeros(2, 256), torch.zeros(2, 768))   # CPU tensors: no fallback
+
+
+def test_state_dict_roundtrip_and_repack():
+    m1 = make_model(closed_form=False, seed=1).eval()
+    m2 = make_model(closed_form=False, seed=2).eval()
+    b = batch(16)
+    a, v, t = (b[k].to(DEV) for k in ("audio", "video", "text"))
+    with torch.no_grad():
+        o1 = m1(a, v, t)["mu_all"].clone()
+        assert not torch.allclose(o1, m2(a, v, t)["mu_all"])
+        m2.load_state_dict(m1.state_dict())          # in-place copy_ bumps versions -> repack
+        assert torch.equal(o1, m2(a, v, t)["mu_all"])

@@ -1,0 +1,140 @@
+"""ctypes binding of libmmdeer_hip.so (include/mmdeer.h).
+
+There is NO fallback: if the library cannot be loaded (or built from the in-tree
+sources with hipcc) every entry point raises.  The product path never touches
+``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+from . import build as _build
+
+_LIB: Optional[C.CDLL] = None
+_LOCK = threading.Lock()
+
+c_void_p, c_int, c_float, c_u64, c_size_t, c_ll = C.c_void_p, C.c_int32, C.c_float, C.c_uint64, C.c_size_t, C.c_longlong
+
+
+class LossCfg(C.Structure):
+    _fields_ = [("reg_weight", c_float), ("kl_weight", c_float), ("ece_weight", c_float),
+                ("cross_weight", c_float), ("task_weight", c_float * 3)]
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [
+        ("batch", c_int), ("compute_f32", c_int), ("training", c_int), ("inputs_bf16", c_int), ("repack", c_int),
+        ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
+        ("audio", c_void_p), ("video", c_void_p), ("text", c_void_p),
+        ("params", C.POINTER(c_void_p)),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("nig_out", c_void_p), ("fused_features", c_void_p), ("audiovisual_features", c_void_p),
+        ("trimodal_features", c_void_p), ("av_attention", c_void_p), ("trimodal_attention", c_void_p),
+        ("targets", c_void_p), ("prof_events", c_void_p * 2), ("stream", c_void_p),
+    ]
+
+
+class BackwardArgs(C.Structure):
+    _fields_ = [
+        ("batch", c_int), ("compute_f32", c_int), ("training", c_int), ("inputs_bf16", c_int),
+        ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
+        ("audio", c_void_p), ("video", c_void_p), ("text", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("targets", c_void_p), ("g_mu", c_void_p), ("g_nu", c_void_p), ("g_alpha", c_void_p), ("g_beta", c_void_p),
+        ("loss", LossCfg),
+        ("grads", c_void_p), ("loss_out", c_void_p), ("bin_counts", c_void_p),
+        ("bucket_events", c_void_p * 3), ("stream", c_void_p),
+    ]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("bias_grad", c_void_p), ("Y", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldw", c_int), ("ldc", c_int), ("ldy", c_int),
+        ("a_f32", c_int), ("w_f32", c_int), ("c_f32", c_int), ("y_f32", c_int), ("trans_a", c_int), ("trans_w", c_int),
+        ("relu", c_int), ("accumulate", c_int), ("compute_f32", c_int), ("tile", c_int),
+        ("drop_site", c_int), ("drop_shift", c_int), ("regen_site", c_int),
+        ("dropout_p", c_float), ("mask_scale", c_float), ("seed", c_u64), ("offset", c_u64), ("stream", c_void_p),
+    ]
+
+
+# every symbol include/mmdeer.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("mmdeer_version", C.c_char_p, []),
+    ("mmdeer_abi_version", c_int, []),
+    ("mmdeer_last_error", C.c_char_p, []),
+    ("mmdeer_num_params", c_int, []),
+    ("mmdeer_param_name", C.c_char_p, [c_int]),
+    ("mmdeer_param_rows", c_int, [c_int]),
+    ("mmdeer_param_cols", c_int, [c_int]),
+    ("mmdeer_param_offset", c_ll, [c_int]),
+    ("mmdeer_flat_elems", c_ll, []),
+    ("mmdeer_workspace_bytes", c_size_t, [c_int, c_int]),
+    ("mmdeer_forward", c_int, [C.POINTER(ForwardArgs)]),
+    ("mmdeer_backward", c_int, [C.POINTER(BackwardArgs)]),
+    ("mmdeer_bucket_begin", c_ll, [c_int]),
+    ("mmdeer_bucket_end", c_ll, [c_int]),
+    ("mmdeer_gemm", c_int, [C.POINTER(GemmArgs)]),
+    ("mmdeer_layernorm_fwd", c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    ("mmdeer_layernorm_bwd_nparts", c_int, [c_int]),
+    ("mmdeer_layernorm_bwd", c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_void_p]),
+    ("mmdeer_trimodal_attn_fwd", c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p]),
+    ("mmdeer_trimodal_attn_bwd", c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p]),
+    ("mmdeer_nig_stats_elems", c_ll, [c_int]),
+    ("mmdeer_nig_loss", c_int, [c_void_p] * 12 + [c_int, C.POINTER(LossCfg), c_void_p]),
+    ("mmdeer_dropout_mask", c_int, [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p]),
+    ("mmdeer_convert", c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p]),
+]
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load (building first when the in-tree .so is missing or stale)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    with _LOCK:
+        if _LIB is not None:
+            return _LIB
+        path = _build.LIB_PATH
+        if build_if_missing and _build.needs_build():
+            try:
+                _build.build()
+            except Exception as e:  # noqa: BLE001
+                if not os.path.exists(path):
+                    raise RuntimeError(
+                        "libmmdeer_hip.so is missing and could not be built (hipcc --offload-arch=gfx950). "
+                        f"There is no CPU fallback for the mmdeer hot path. Build error: {e}") from e
+        if not os.path.exists(path):
+            raise RuntimeError(f"libmmdeer_hip.so not found at {path}; run `python -m mmdeer.build`. "
+                               "There is no CPU fallback for the mmdeer hot path.")
+        lib = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mmdeer_abi_version() != 1:
+            raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
+        _LIB = lib
+    return _LIB
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError("mmdeer: " + load().mmdeer_last_error().decode())
+
+
+def ptr(t) -> Optional[int]:
+    """data_ptr of a tensor or None."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

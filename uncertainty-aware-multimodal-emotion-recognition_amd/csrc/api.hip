@@ -1,0 +1,620 @@
+// libmmdeer_hip.so -- C ABI (include/mmdeer.h) and the host-side executor that strings the gfx950 kernels into
+// the forward / backward of the fusion + DEER path.  Host code only: every function enqueues on the caller's
+// stream and returns; nothing here allocates device memory or synchronises.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/mmdeer.h"
+#include "attention.h"
+#include "common.h"
+#include "gemm.h"
+#include "nig.h"
+#include "rowops.h"
+
+namespace mmdeer {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+// ------------------------------------------------------------------ parameter table
+struct ParamInfo { const char* name; int rows, cols; long long off; int is_matrix; };
+#define X(idx, ident, rows, cols, off, ismat, name) {name, rows, cols, off, ismat},
+const ParamInfo kParams[] = {
+#include "params.inc"
+};
+#undef X
+enum ParamId {
+#define X(idx, ident, rows, cols, off, ismat, name) ident = idx,
+#include "params.inc"
+#undef X
+};
+static_assert(MMDEER_NUM_PARAMS == MMDEER_NUM_PARAMS_ABI, "parameter table out of sync with the public header");
+
+// short aliases
+constexpr int P_AUD_W = MMDEER_P_AUDIO_VISUAL_AUDIO_PROJECTION_WEIGHT, P_AUD_B = MMDEER_P_AUDIO_VISUAL_AUDIO_PROJECTION_BIAS;
+constexpr int P_VID_W = MMDEER_P_AUDIO_VISUAL_VIDEO_PROJECTION_WEIGHT, P_VID_B = MMDEER_P_AUDIO_VISUAL_VIDEO_PROJECTION_BIAS;
+constexpr int P_AIN_W = MMDEER_P_AUDIO_VISUAL_CROSS_ATTENTION_IN_PROJ_WEIGHT, P_AIN_B = MMDEER_P_AUDIO_VISUAL_CROSS_ATTENTION_IN_PROJ_BIAS;
+constexpr int P_AOUT_W = MMDEER_P_AUDIO_VISUAL_CROSS_ATTENTION_OUT_PROJ_WEIGHT, P_AOUT_B = MMDEER_P_AUDIO_VISUAL_CROSS_ATTENTION_OUT_PROJ_BIAS;
+constexpr int P_AVF_W = MMDEER_P_AUDIO_VISUAL_FUSION_LAYERS_0_WEIGHT, P_AVF_B = MMDEER_P_AUDIO_VISUAL_FUSION_LAYERS_0_BIAS;
+constexpr int P_AVF_G = MMDEER_P_AUDIO_VISUAL_FUSION_LAYERS_3_WEIGHT, P_AVF_BT = MMDEER_P_AUDIO_VISUAL_FUSION_LAYERS_3_BIAS;
+constexpr int P_AVP_W = MMDEER_P_TRIMODAL_AUDIOVISUAL_PROJECTION_WEIGHT, P_AVP_B = MMDEER_P_TRIMODAL_AUDIOVISUAL_PROJECTION_BIAS;
+constexpr int P_TXT_W = MMDEER_P_TRIMODAL_TEXT_PROJECTION_WEIGHT, P_TXT_B = MMDEER_P_TRIMODAL_TEXT_PROJECTION_BIAS;
+constexpr int P_TIN_W = MMDEER_P_TRIMODAL_MODALITY_ATTENTION_IN_PROJ_WEIGHT, P_TIN_B = MMDEER_P_TRIMODAL_MODALITY_ATTENTION_IN_PROJ_BIAS;
+constexpr int P_TOUT_W = MMDEER_P_TRIMODAL_MODALITY_ATTENTION_OUT_PROJ_WEIGHT, P_TOUT_B = MMDEER_P_TRIMODAL_MODALITY_ATTENTION_OUT_PROJ_BIAS;
+constexpr int P_TFF_W = MMDEER_P_TRIMODAL_FINAL_0_WEIGHT, P_TFF_B = MMDEER_P_TRIMODAL_FINAL_0_BIAS;
+constexpr int P_TFF_G = MMDEER_P_TRIMODAL_FINAL_3_WEIGHT, P_TFF_BT = MMDEER_P_TRIMODAL_FINAL_3_BIAS;
+constexpr int P_OP_W = MMDEER_P_OUTP0_WEIGHT, P_OP_B = MMDEER_P_OUTP0_BIAS, P_OP_G = MMDEER_P_OUTP3_WEIGHT, P_OP_BT = MMDEER_P_OUTP3_BIAS;
+constexpr int P_FP0_W = MMDEER_P_FP0_WEIGHT, P_FP0_B = MMDEER_P_FP0_BIAS, P_FP1_W = MMDEER_P_FP3_WEIGHT, P_FP1_B = MMDEER_P_FP3_BIAS;
+constexpr int P_EV0_W = MMDEER_P_HEAD0_EV0_WEIGHT, P_EV0_B = MMDEER_P_HEAD0_EV0_BIAS;
+constexpr int P_EV1_W = MMDEER_P_HEAD0_EV3_WEIGHT, P_EV1_B = MMDEER_P_HEAD0_EV3_BIAS;
+constexpr int P_EV2_W = MMDEER_P_HEAD0_EV6_WEIGHT, P_EV2_B = MMDEER_P_HEAD0_EV6_BIAS;
+
+constexpr int AUD = MMDEER_AUDIO_DIM, VID = MMDEER_VIDEO_DIM, TXT = MMDEER_TEXT_DIM, INTER = MMDEER_INTER_DIM;
+constexpr int FUS = MMDEER_FUSION_DIM, HID = MMDEER_HIDDEN_DIM, EV1 = 128, EV2 = 64;
+
+// ------------------------------------------------------------------ workspace layout
+struct Layout {
+  // packed parameters
+  char* wpack;   // compute dtype, MMDEER_FLAT_ELEMS
+  float* vpack;  // fp32 vectors, MMDEER_FLAT_ELEMS
+  // saved activations (activation dtype unless noted)
+  char *avin, *avv, *cat, *y_a2, *av, *xtok, *qkv, *obar, *pool, *y_t3, *tri, *y_o1, *fused, *h1, *h2, *e1, *e2;
+  float *probs, *evid, *stats;
+  float *mean_a2, *rstd_a2, *mean_t3, *rstd_t3, *mean_o1, *rstd_o1;
+  // backward scratch
+  char *dz2, *de1, *dh2, *dh1, *dfused, *dz_o1, *dtri, *dz_t3, *dpool, *dobar, *dqkv, *dxtok, *dav, *dz_a2, *dcats, *davv, *davin;
+  float *part_ln_o1, *part_ln_t3, *part_ln_a2, *part_w3, *part_b3;
+  size_t bytes;
+};
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+Layout make_layout(void* base, int B, int f32) {
+  Layout L{};
+  const size_t es = f32 ? 4 : 2;
+  size_t off = 0;
+  char* b = reinterpret_cast<char*>(base);
+  auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += align_up(bytes); return p; };
+  const size_t Bz = (size_t)(B > 0 ? B : 1);
+  L.wpack = take((size_t)MMDEER_FLAT_ELEMS * es);
+  L.vpack = reinterpret_cast<float*>(take((size_t)MMDEER_FLAT_ELEMS * 4));
+  auto act = [&](size_t rows, size_t cols) { return take(rows * cols * es); };
+  auto f32buf = [&](size_t n) { return reinterpret_cast<float*>(take(n * 4)); };
+  L.avin = act(2 * Bz, INTER); L.avv = act(2 * Bz, INTER); L.cat = act(Bz, 2 * INTER); L.y_a2 = act(Bz, INTER);
+  L.av = act(Bz, INTER); L.xtok = act(2 * Bz, FUS); L.qkv = act(2 * Bz, 3 * FUS); L.obar = act(Bz, FUS);
+  L.pool = act(Bz, FUS); L.y_t3 = act(Bz, FUS); L.tri = act(Bz, FUS); L.y_o1 = act(Bz, FUS); L.fused = act(Bz, FUS);
+  L.h1 = act(Bz, HID); L.h2 = act(Bz, HID); L.e1 = act(Bz, 3 * EV1); L.e2 = act(Bz, 3 * EV2);
+  L.probs = f32buf(Bz * 8 * 4); L.evid = f32buf(Bz * 12);
+  const size_t nblk = (size_t)nig_nblocks(B);
+  L.stats = f32buf(nblk * 3 * NIG_NSTAT);
+  L.mean_a2 = f32buf(Bz); L.rstd_a2 = f32buf(Bz); L.mean_t3 = f32buf(Bz); L.rstd_t3 = f32buf(Bz);
+  L.mean_o1 = f32buf(Bz); L.rstd_o1 = f32buf(Bz);
+  L.dz2 = act(Bz, 3 * EV2); L.de1 = act(Bz, 3 * EV1); L.dh2 = act(Bz, HID); L.dh1 = act(Bz, HID);
+  L.dfused = act(Bz, FUS); L.dz_o1 = act(Bz, FUS); L.dtri = act(Bz, FUS); L.dz_t3 = act(Bz, FUS);
+  L.dpool = act(Bz, FUS); L.dobar = act(Bz, FUS); L.dqkv = act(2 * Bz, 3 * FUS); L.dxtok = act(2 * Bz, FUS);
+  L.dav = act(Bz, INTER); L.dz_a2 = act(Bz, INTER); L.dcats = act(2 * Bz, INTER); L.davv = act(2 * Bz, INTER);
+  L.davin = act(2 * Bz, INTER);
+  const size_t np = (size_t)ln_bwd_nparts(B);
+  L.part_ln_o1 = f32buf(np * 2 * FUS); L.part_ln_t3 = f32buf(np * 2 * FUS); L.part_ln_a2 = f32buf(np * 2 * INTER);
+  L.part_w3 = f32buf(nblk * 3 * 256); L.part_b3 = f32buf(nblk * 3 * 4);
+  L.bytes = off;
+  return L;
+}
+
+DropCtx make_drop(float p, uint64_t seed, uint64_t offset) {
+  DropCtx d;
+  d.seed = seed;
+  d.offset = offset;
+  double keep = 1.0 - (double)p;
+  if (keep < 0) keep = 0;
+  double t = keep * 4294967296.0;
+  d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+  d.scale = keep > 0 ? (float)(1.0 / keep) : 0.f;
+  return d;
+}
+
+int forced_tile() {
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("MMDEER_TILE");
+    v = e ? atoi(e) : -1;
+  }
+  return v;
+}
+
+// smallest tile that still gives the chip >= ~2 workgroups per CU; otherwise the largest tile count wins
+GemmTile pick_tile(const GemmGroup& g) {
+  const int ft = forced_tile();
+  if (ft >= 0 && ft <= 2) return (GemmTile)ft;
+  static const int bm[3] = {64, 128, 128}, bn[3] = {64, 64, 128};
+  long long tiles[3];
+  for (int t = 0; t < 3; ++t) {
+    tiles[t] = 0;
+    for (int i = 0; i < g.nprob; ++i) {
+      const GemmProblem& p = g.p[i];
+      tiles[t] += (long long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * p.batch;
+    }
+  }
+  if (tiles[2] >= 512) return TILE_128x128;
+  if (tiles[1] >= 512) return TILE_128x64;
+  return TILE_64x64;
+}
+
+// Builder for the executor's GEMM problems.  `es` = bytes of one activation element.
+struct Exec {
+  int B, f32;
+  size_t es;
+  bool drop_on;      // dropout active
+  float mask_scale;  // 1/(1-p) when dropout is active, else 1
+  DropCtx dc;
+  const Layout* L;
+  hipStream_t s;
+
+  const char* W(int pid) const { return L->wpack + (size_t)kParams[pid].off * es; }
+  const float* V(int pid) const { return L->vpack + kParams[pid].off; }
+
+  // Y = X W^T + b: activations in, activations out
+  GemmProblem fwd(const void* A, int a_f32, int lda, int pidW, int pidB, void* C, int ldc, int M, int relu, int site) const {
+    GemmProblem p;
+    gemm_problem_defaults(p);
+    p.A = A; p.a_f32 = a_f32; p.lda = lda;
+    p.B = W(pidW); p.b_f32 = f32; p.ldb = kParams[pidW].cols;
+    p.C = C; p.c_f32 = f32; p.ldc = ldc;
+    p.bias = V(pidB);
+    p.M = M; p.N = kParams[pidW].rows; p.K = kParams[pidW].cols;
+    p.relu = relu;
+    p.drop_site = drop_on ? site : -1;
+    return p;
+  }
+  // dX = dY W, optionally masked by (Yprev > 0) * mask_scale
+  GemmProblem dx(const void* dY, int ldy_in, int pidW, void* dX, int ldx, int M, const void* Ymask, int ldmask) const {
+    GemmProblem p;
+    gemm_problem_defaults(p);
+    p.A = dY; p.a_f32 = f32; p.lda = ldy_in;
+    p.B = W(pidW); p.b_f32 = f32; p.ldb = kParams[pidW].cols; p.trans_b = 1;
+    p.C = dX; p.c_f32 = f32; p.ldc = ldx;
+    p.M = M; p.N = kParams[pidW].cols; p.K = kParams[pidW].rows;
+    p.Y = Ymask; p.y_f32 = f32; p.ldy = ldmask; p.mask_scale = mask_scale;
+    return p;
+  }
+  // dW = dY^T X (+ db = column sums of dY), written into the flat gradient buffer
+  GemmProblem dw(const void* dY, int ldy_in, const void* X, int x_f32, int ldx, int pidW, int pidB, float* grads, int Mred) const {
+    GemmProblem p;
+    gemm_problem_defaults(p);
+    p.A = dY; p.a_f32 = f32; p.lda = ldy_in; p.trans_a = 1;
+    p.B = X; p.b_f32 = x_f32; p.ldb = ldx; p.trans_b = 1;
+    p.C = grads + kParams[pidW].off; p.c_f32 = 1; p.ldc = kParams[pidW].cols;
+    p.bias_grad = grads + kParams[pidB].off;
+    p.M = kParams[pidW].rows; p.N = kParams[pidW].cols; p.K = Mred;
+    return p;
+  }
+  int run(GemmGroup& g) const {
+    g.drop = dc;
+    return launch_gemm_group(g, f32, pick_tile(g), s);
+  }
+  int run1(const GemmProblem& p) const {
+    GemmGroup g{};
+    g.nprob = 1;
+    g.p[0] = p;
+    return run(g);
+  }
+};
+
+#define TRY(x) do { if ((x) != 0) return -1; } while (0)
+
+int check_common(int batch, const void* ws, size_t ws_bytes, int f32) {
+  MMDEER_CHECK(batch >= 0, "batch must be >= 0 (got %d)", batch);
+  MMDEER_CHECK(ws != nullptr, "workspace is NULL");
+  MMDEER_CHECK(((uintptr_t)ws % 256) == 0, "workspace must be 256-byte aligned");
+  const size_t need = mmdeer_workspace_bytes(batch, f32);
+  MMDEER_CHECK(ws_bytes >= need, "workspace too small: %zu bytes given, %zu needed for batch %d", ws_bytes, need, batch);
+  return 0;
+}
+
+}  // namespace
+}  // namespace mmdeer
+
+using namespace mmdeer;
+
+extern "C" {
+
+const char* mmdeer_version(void) { return "mmdeer-hip 0.1.0 (gfx950)"; }
+int mmdeer_abi_version(void) { return MMDEER_ABI_VERSION; }
+const char* mmdeer_last_error(void) { return g_err; }
+int mmdeer_num_params(void) { return MMDEER_NUM_PARAMS; }
+const char* mmdeer_param_name(int i) { return (i >= 0 && i < MMDEER_NUM_PARAMS) ? kParams[i].name : ""; }
+int mmdeer_param_rows(int i) { return (i >= 0 && i < MMDEER_NUM_PARAMS) ? kParams[i].rows : -1; }
+int mmdeer_param_cols(int i) { return (i >= 0 && i < MMDEER_NUM_PARAMS) ? kParams[i].cols : -1; }
+long long mmdeer_param_offset(int i) { return (i >= 0 && i < MMDEER_NUM_PARAMS) ? kParams[i].off : -1; }
+long long mmdeer_flat_elems(void) { return MMDEER_FLAT_ELEMS; }
+
+size_t mmdeer_workspace_bytes(int batch, int compute_f32) { return make_layout(nullptr, batch, compute_f32).bytes; }
+
+long long mmdeer_bucket_begin(int b) {
+  switch (b) { case 0: return kParams[P_FP0_W].off; case 1: return kParams[P_AVP_W].off; case 2: return 0; default: return -1; }
+}
+long long mmdeer_bucket_end(int b) {
+  switch (b) { case 0: return MMDEER_FLAT_ELEMS; case 1: return kParams[P_FP0_W].off; case 2: return kParams[P_AVP_W].off; default: return -1; }
+}
+
+int mmdeer_forward(const mmdeer_forward_args* a) {
+  MMDEER_CHECK(a != nullptr, "args is NULL");
+  const int B = a->batch, f32 = a->compute_f32 ? 1 : 0;
+  TRY(check_common(B, a->workspace, a->workspace_bytes, f32));
+  MMDEER_CHECK(!(f32 && a->inputs_bf16), "bf16 inputs need compute_f32 = 0");
+  MMDEER_CHECK(a->dropout_p >= 0.f && a->dropout_p < 1.f, "dropout_p must be in [0,1) (got %f)", a->dropout_p);
+  hipStream_t s = (hipStream_t)a->stream;
+  const Layout L = make_layout(a->workspace, B, f32);
+  if (a->repack) {
+    MMDEER_CHECK(a->params != nullptr, "params is NULL");
+    PackTable t{};
+    t.nseg = MMDEER_NUM_PARAMS;
+    for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
+      MMDEER_CHECK(a->params[i] != nullptr, "params[%d] (%s) is NULL", i, kParams[i].name);
+      MMDEER_CHECK(((uintptr_t)a->params[i] % 16) == 0, "params[%d] (%s) must be 16-byte aligned", i, kParams[i].name);
+      t.src[i] = reinterpret_cast<const float*>(a->params[i]);
+      t.dst_off[i] = kParams[i].off;
+      t.n[i] = kParams[i].rows * kParams[i].cols;
+      t.is_vec[i] = kParams[i].is_matrix ? 0 : 1;
+    }
+    TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
+  }
+  if (B == 0) return 0;
+  MMDEER_CHECK(a->audio && a->video && a->text, "audio / video / text must be non-NULL");
+  MMDEER_CHECK(a->nig_out != nullptr, "nig_out is NULL");
+
+  Exec X;
+  X.B = B; X.f32 = f32; X.es = f32 ? 4 : 2; X.L = &L; X.s = s;
+  X.drop_on = a->training && a->dropout_p > 0.f;
+  X.dc = make_drop(a->dropout_p, a->seed, a->offset);
+  X.mask_scale = X.drop_on ? X.dc.scale : 1.f;
+  const int in_f32 = a->inputs_bf16 ? 0 : 1;
+  const size_t es = X.es;
+
+  // F1: the three input projections (fusion.py:236-237, 322) in one launch
+  {
+    GemmGroup g{};
+    g.nprob = 3;
+    g.p[0] = X.fwd(a->video, in_f32, VID, P_VID_W, P_VID_B, L.avin, INTER, B, 0, -1);                       // rows [0,B)
+    g.p[1] = X.fwd(a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, L.avin + (size_t)B * INTER * es, INTER, B, 0, -1); // rows [B,2B)
+    g.p[2] = X.fwd(a->text, in_f32, TXT, P_TXT_W, P_TXT_B, L.xtok + (size_t)FUS * es, 2 * FUS, B, 0, -1);     // token 1
+    TRY(X.run(g));
+  }
+  // F2: value projection of the shared AV cross-attention on [video_proj; audio_proj] (fusion.py:244-255;
+  //     L = S = 1 so q/k are dead), attention-weight dropout = one decision per (row, head)
+  {
+    GemmProblem p = X.fwd(L.avin, f32, INTER, P_AIN_W, P_AIN_B, L.avv, INTER, 2 * B, 0, SITE_AV_ATTN);
+    p.B = X.W(P_AIN_W) + (size_t)2 * INTER * INTER * es;   // rows [2E, 3E) of the packed [q;k;v] matrix
+    p.bias = X.V(P_AIN_B) + 2 * INTER;
+    p.N = INTER;
+    p.drop_shift = 5;  // 32 columns = one head
+    TRY(X.run1(p));
+  }
+  // F3: out_proj, batched over the two calls; batch z writes columns [256 z, 256 z + 256) of cat (fusion.py:262)
+  {
+    GemmProblem p = X.fwd(L.avv, f32, INTER, P_AOUT_W, P_AOUT_B, L.cat, 2 * INTER, B, 0, -1);
+    p.batch = 2; p.sA = (long long)B * INTER; p.sC = INTER;
+    TRY(X.run1(p));
+  }
+  // F4-F5: fusion_layers = Linear -> ReLU -> Dropout -> LayerNorm (fusion.py:263)
+  TRY(X.run1(X.fwd(L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, L.y_a2, INTER, B, 1, SITE_AV_FUSE)));
+  TRY(launch_ln_fwd(L.y_a2, L.av, a->audiovisual_features, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), X.V(P_AVF_BT), B, INTER, f32, s));
+  // F6: audiovisual_projection -> token 0 (fusion.py:321, 325)
+  TRY(X.run1(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1)));
+  // F7: packed q|k|v in_proj of the 2-token self-attention (fusion.py:328)
+  if (a->prof_events[0]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[0], s));
+  TRY(X.run1(X.fwd(L.xtok, f32, FUS, P_TIN_W, P_TIN_B, L.qkv, 3 * FUS, 2 * B, 0, -1)));
+  if (a->prof_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[1], s));
+  // F8: 2x2 softmax attention, token-pooled context
+  TRY(launch_tri_attn_fwd(L.qkv, L.obar, L.probs, a->trimodal_attention, a->av_attention, B, f32, X.drop_on ? 1 : 0, X.dc, s));
+  // F9: out_proj on the pooled context (mean over tokens commutes with the linear map; fusion.py:335)
+  TRY(X.run1(X.fwd(L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, L.pool, FUS, B, 0, -1)));
+  // F10-F11: final_fusion (fusion.py:338)
+  TRY(X.run1(X.fwd(L.pool, f32, FUS, P_TFF_W, P_TFF_B, L.y_t3, FUS, B, 1, SITE_TRI_FUSE)));
+  TRY(launch_ln_fwd(L.y_t3, L.tri, a->trimodal_features, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), X.V(P_TFF_BT), B, FUS, f32, s));
+  // F12-F13: output_projection (fusion.py:162)
+  TRY(X.run1(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ)));
+  TRY(launch_ln_fwd(L.y_o1, L.fused, a->fused_features, L.mean_o1, L.rstd_o1, X.V(P_OP_G), X.V(P_OP_BT), B, FUS, f32, s));
+  // F14-F15: feature_processor (deer.py:246)
+  TRY(X.run1(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0)));
+  TRY(X.run1(X.fwd(L.h1, f32, HID, P_FP1_W, P_FP1_B, L.h2, HID, B, 1, SITE_FP1)));
+  // F16: the three DEERLayer first layers stacked into one N = 384 GEMM (deer.py:49)
+  {
+    GemmProblem p = X.fwd(L.h2, f32, HID, P_EV0_W, P_EV0_B, L.e1, 3 * EV1, B, 1, SITE_EV0);
+    p.N = 3 * EV1;
+    TRY(X.run1(p));
+  }
+  // F17: second layers, strided-batched over the heads (deer.py:52)
+  {
+    GemmProblem p = X.fwd(L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, L.e2, 3 * EV2, B, 1, SITE_EV1);
+    p.batch = 3; p.sA = EV1; p.sB = (long long)EV2 * EV1; p.sC = EV2; p.sBias = EV2;
+    TRY(X.run1(p));
+  }
+  // F18: last layer (64 -> 4), NIG activations, uncertainties and -- with targets -- the loss statistics
+  TRY(launch_nig_fwd(L.e2, X.W(P_EV2_W), X.V(P_EV2_B), 64, L.evid, a->nig_out, a->targets, L.stats, B, f32, s));
+  return 0;
+}
+
+int mmdeer_backward(const mmdeer_backward_args* a) {
+  MMDEER_CHECK(a != nullptr, "args is NULL");
+  const int B = a->batch, f32 = a->compute_f32 ? 1 : 0;
+  TRY(check_common(B, a->workspace, a->workspace_bytes, f32));
+  MMDEER_CHECK(B > 0, "backward needs a non-empty batch");
+  MMDEER_CHECK(a->grads != nullptr, "grads is NULL");
+  MMDEER_CHECK(a->audio && a->video && a->text, "audio / video / text must be non-NULL");
+  hipStream_t s = (hipStream_t)a->stream;
+  const Layout L = make_layout(a->workspace, B, f32);
+  Exec X;
+  X.B = B; X.f32 = f32; X.es = f32 ? 4 : 2; X.L = &L; X.s = s;
+  X.drop_on = a->training && a->dropout_p > 0.f;
+  X.dc = make_drop(a->dropout_p, a->seed, a->offset);
+  X.mask_scale = X.drop_on ? X.dc.scale : 1.f;
+  const int in_f32 = a->inputs_bf16 ? 0 : 1;
+  const size_t es = X.es;
+  float* G = a->grads;
+  LossCfg cfg;
+  cfg.reg_w = a->loss.reg_weight; cfg.kl_w = a->loss.kl_weight; cfg.ece_w = a->loss.ece_weight;
+  cfg.cross_w = a->loss.cross_weight;
+  for (int i = 0; i < 3; ++i) cfg.task_w[i] = a->loss.task_weight[i];
+  const bool split_reduce = a->bucket_events[0] || a->bucket_events[1] || a->bucket_events[2];
+  const int nblk = nig_nblocks(B), npl = ln_bwd_nparts(B);
+
+  // the q/k thirds of the AV in_proj never receive a gradient (L = S = 1): exact zeros, as in the reference
+  MMDEER_HIP(hipMemsetAsync(G + kParams[P_AIN_W].off, 0, sizeof(float) * 2 * INTER * INTER, s));
+  MMDEER_HIP(hipMemsetAsync(G + kParams[P_AIN_B].off, 0, sizeof(float) * 2 * INTER, s));
+
+  // B1: last head layer + NIG activations (+ loss gradient)
+  TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
+                     L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
+  auto reduce_head = [&](ReduceTable& t) {
+    int k = t.nseg;
+    t.src[k] = L.part_w3; t.dst[k] = G + kParams[P_EV2_W].off; t.nparts[k] = nblk; t.n[k] = 768; t.stride[k] = 768; ++k;
+    for (int d = 0; d < 3; ++d) {
+      t.src[k] = L.part_b3 + d * 4; t.dst[k] = G + kParams[P_EV2_B + d].off; t.nparts[k] = nblk; t.n[k] = 4; t.stride[k] = 12; ++k;
+    }
+    t.nseg = k;
+  };
+  auto reduce_ln = [&](ReduceTable& t, const float* part, int pidG, int N) {
+    int k = t.nseg;   // gamma and beta slices are adjacent in the flat buffer (N is a multiple of 64)
+    t.src[k] = part; t.dst[k] = G + kParams[pidG].off; t.nparts[k] = npl; t.n[k] = 2 * N; t.stride[k] = 2 * N; ++k;
+    t.nseg = k;
+  };
+  if (split_reduce) { ReduceTable t{}; reduce_head(t); TRY(launch_reduce_partials(t, s)); }
+
+  // B2: evidence_net layer 3 (128 -> 64), batched over heads: dX masked by e1, dW + db
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    GemmProblem p = X.dx(L.dz2, 3 * EV2, P_EV1_W, L.de1, 3 * EV1, B, L.e1, 3 * EV1);
+    p.batch = 3; p.sA = EV2; p.sB = (long long)EV2 * EV1; p.sC = EV1; p.sY = EV1;
+    g.p[0] = p;
+    GemmProblem q = X.dw(L.dz2, 3 * EV2, L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, G, B);
+    q.batch = 3; q.sA = EV2; q.sB = EV1; q.sC = (long long)EV2 * EV1; q.sBiasGrad = EV2;
+    g.p[1] = q;
+    TRY(X.run(g));
+  }
+  // B3: evidence_net layer 0 (256 -> 3 x 128 stacked)
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    GemmProblem p = X.dx(L.de1, 3 * EV1, P_EV0_W, L.dh2, HID, B, L.h2, HID);
+    p.K = 3 * EV1;
+    g.p[0] = p;
+    GemmProblem q = X.dw(L.de1, 3 * EV1, L.h2, f32, HID, P_EV0_W, P_EV0_B, G, B);
+    q.M = 3 * EV1;
+    g.p[1] = q;
+    TRY(X.run(g));
+  }
+  // B4-B5: feature_processor
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    g.p[0] = X.dx(L.dh2, HID, P_FP1_W, L.dh1, HID, B, L.h1, HID);
+    g.p[1] = X.dw(L.dh2, HID, L.h1, f32, HID, P_FP1_W, P_FP1_B, G, B);
+    TRY(X.run(g));
+  }
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    g.p[0] = X.dx(L.dh1, HID, P_FP0_W, L.dfused, FUS, B, nullptr, 0);
+    g.p[1] = X.dw(L.dh1, HID, L.fused, f32, FUS, P_FP0_W, P_FP0_B, G, B);
+    TRY(X.run(g));
+  }
+  if (a->bucket_events[0]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[0], s));
+
+  // B6-B7: output_projection
+  TRY(launch_ln_bwd(L.dfused, L.y_o1, L.mean_o1, L.rstd_o1, X.V(P_OP_G), L.dz_o1, L.part_ln_o1, B, FUS, f32, X.mask_scale, s));
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    g.p[0] = X.dx(L.dz_o1, FUS, P_OP_W, L.dtri, FUS, B, nullptr, 0);
+    g.p[1] = X.dw(L.dz_o1, FUS, L.tri, f32, FUS, P_OP_W, P_OP_B, G, B);
+    TRY(X.run(g));
+  }
+  // B8-B9: final_fusion
+  TRY(launch_ln_bwd(L.dtri, L.y_t3, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), L.dz_t3, L.part_ln_t3, B, FUS, f32, X.mask_scale, s));
+  if (split_reduce) {
+    ReduceTable t{};
+    reduce_ln(t, L.part_ln_o1, P_OP_G, FUS);
+    reduce_ln(t, L.part_ln_t3, P_TFF_G, FUS);
+    TRY(launch_reduce_partials(t, s));
+  }
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    g.p[0] = X.dx(L.dz_t3, FUS, P_TFF_W, L.dpool, FUS, B, nullptr, 0);
+    g.p[1] = X.dw(L.dz_t3, FUS, L.pool, f32, FUS, P_TFF_W, P_TFF_B, G, B);
+    TRY(X.run(g));
+  }
+  // B10: attention out_proj (applied to the pooled context)
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    g.p[0] = X.dx(L.dpool, FUS, P_TOUT_W, L.dobar, FUS, B, nullptr, 0);
+    g.p[1] = X.dw(L.dpool, FUS, L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, G, B);
+    TRY(X.run(g));
+  }
+  // B11: softmax attention backward
+  TRY(launch_tri_attn_bwd(L.qkv, L.dobar, L.probs, L.dqkv, B, f32, X.drop_on ? 1 : 0, X.dc, s));
+  // B12: in_proj
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    g.p[0] = X.dx(L.dqkv, 3 * FUS, P_TIN_W, L.dxtok, FUS, 2 * B, nullptr, 0);
+    g.p[1] = X.dw(L.dqkv, 3 * FUS, L.xtok, f32, FUS, P_TIN_W, P_TIN_B, G, 2 * B);
+    TRY(X.run(g));
+  }
+  // B13: token projections: audiovisual_projection (token 0: dX + dW) and text_projection (token 1: dW only)
+  {
+    GemmGroup g{};
+    g.nprob = 3;
+    g.p[0] = X.dx(L.dxtok, 2 * FUS, P_AVP_W, L.dav, INTER, B, nullptr, 0);
+    g.p[1] = X.dw(L.dxtok, 2 * FUS, L.av, f32, INTER, P_AVP_W, P_AVP_B, G, B);
+    g.p[2] = X.dw(L.dxtok + (size_t)FUS * es, 2 * FUS, a->text, in_f32, TXT, P_TXT_W, P_TXT_B, G, B);
+    TRY(X.run(g));
+  }
+  if (a->bucket_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[1], s));
+
+  // B14-B15: AV fusion_layers; the dX half is written "stacked" ([2B,256]: rows [0,B) = d audio_attended,
+  //          rows [B,2B) = d video_attended) by batching over the two column halves of the weight
+  TRY(launch_ln_bwd(L.dav, L.y_a2, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), L.dz_a2, L.part_ln_a2, B, INTER, f32, X.mask_scale, s));
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    GemmProblem p = X.dx(L.dz_a2, INTER, P_AVF_W, L.dcats, INTER, B, nullptr, 0);
+    p.N = INTER; p.batch = 2; p.sB = INTER; p.sC = (long long)B * INTER;
+    g.p[0] = p;
+    g.p[1] = X.dw(L.dz_a2, INTER, L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, G, B);
+    TRY(X.run(g));
+  }
+  // B16: AV out_proj; dX gets the regenerated attention-dropout factor of F2
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    GemmProblem p = X.dx(L.dcats, INTER, P_AOUT_W, L.davv, INTER, 2 * B, nullptr, 0);
+    if (X.drop_on) { p.regen_site = SITE_AV_ATTN; p.drop_shift = 5; }
+    g.p[0] = p;
+    g.p[1] = X.dw(L.dcats, INTER, L.avv, f32, INTER, P_AOUT_W, P_AOUT_B, G, 2 * B);
+    TRY(X.run(g));
+  }
+  // B17: AV value projection (rows [2E,3E) of in_proj)
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    GemmProblem p = X.dx(L.davv, INTER, P_AIN_W, L.davin, INTER, 2 * B, nullptr, 0);
+    p.B = X.W(P_AIN_W) + (size_t)2 * INTER * INTER * es;
+    p.K = INTER;
+    g.p[0] = p;
+    GemmProblem q = X.dw(L.davv, INTER, L.avin, f32, INTER, P_AIN_W, P_AIN_B, G, 2 * B);
+    q.C = G + kParams[P_AIN_W].off + 2 * INTER * INTER;
+    q.bias_grad = G + kParams[P_AIN_B].off + 2 * INTER;
+    q.M = INTER;
+    g.p[1] = q;
+    TRY(X.run(g));
+  }
+  // B18: input projections (weights only: inputs need no gradient)
+  {
+    GemmGroup g{};
+    g.nprob = 2;
+    g.p[0] = X.dw(L.davin, INTER, a->video, in_f32, VID, P_VID_W, P_VID_B, G, B);
+    g.p[1] = X.dw(L.davin + (size_t)B * INTER * es, INTER, a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, G, B);
+    TRY(X.run(g));
+  }
+  // B19: fold the per-block partials (LayerNorm gamma/beta, last head layer) into the flat gradient buffer
+  {
+    ReduceTable t{};
+    reduce_ln(t, L.part_ln_a2, P_AVF_G, INTER);
+    if (!split_reduce) {
+      reduce_ln(t, L.part_ln_o1, P_OP_G, FUS);
+      reduce_ln(t, L.part_ln_t3, P_TFF_G, FUS);
+      reduce_head(t);
+    }
+    TRY(launch_reduce_partials(t, s));
+  }
+  if (a->bucket_events[2]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[2], s));
+  return 0;
+}
+
+// ------------------------------------------------------------------ single operators
+int mmdeer_gemm(const mmdeer_gemm_args* a) {
+  MMDEER_CHECK(a != nullptr, "args is NULL");
+  GemmGroup g{};
+  g.nprob = 1;
+  GemmProblem& p = g.p[0];
+  gemm_problem_defaults(p);
+  p.A = a->A; p.B = a->W; p.C = a->C; p.bias = a->bias; p.bias_grad = a->bias_grad; p.Y = a->Y;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldw; p.ldc = a->ldc; p.ldy = a->ldy;
+  p.a_f32 = a->a_f32; p.b_f32 = a->w_f32; p.c_f32 = a->c_f32; p.y_f32 = a->y_f32;
+  p.trans_a = a->trans_a; p.trans_b = a->trans_w; p.relu = a->relu; p.accumulate = a->accumulate;
+  p.drop_site = a->drop_site; p.drop_shift = a->drop_shift; p.regen_site = a->regen_site;
+  p.mask_scale = a->mask_scale;
+  MMDEER_CHECK(a->A && a->W && a->C, "gemm: A / W / C must be non-NULL");
+  g.drop = make_drop(a->dropout_p, a->seed, a->offset);
+  GemmTile t = (a->tile >= 0 && a->tile <= 2) ? (GemmTile)a->tile : pick_tile(g);
+  return launch_gemm_group(g, a->compute_f32 ? 1 : 0, t, (hipStream_t)a->stream);
+}
+
+int mmdeer_layernorm_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,
+                         const float* beta, int M, int N, int act_f32, void* stream) {
+  return launch_ln_fwd(y, out, out32, mean, rstd, gamma, beta, M, N, act_f32, (hipStream_t)stream);
+}
+int mmdeer_layernorm_bwd_nparts(int M) { return ln_bwd_nparts(M); }
+int mmdeer_layernorm_bwd(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
+                         void* dz, float* dgamma, float* dbeta, float* partial, int M, int N, int act_f32,
+                         float mask_scale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  TRY(launch_ln_bwd(dout, y, mean, rstd, gamma, dz, partial, M, N, act_f32, mask_scale, s));
+  ReduceTable t{};
+  t.nseg = 2;
+  t.src[0] = partial; t.dst[0] = dgamma; t.nparts[0] = ln_bwd_nparts(M); t.n[0] = N; t.stride[0] = 2 * N;
+  t.src[1] = partial + N; t.dst[1] = dbeta; t.nparts[1] = ln_bwd_nparts(M); t.n[1] = N; t.stride[1] = 2 * N;
+  return launch_reduce_partials(t, s);
+}
+
+int mmdeer_trimodal_attn_fwd(const void* qkv, void* obar, float* probs, float* attn_w, float* av_w, int B,
+                             int act_f32, int training, float dropout_p, uint64_t seed, uint64_t offset, void* stream) {
+  const DropCtx dc = make_drop(dropout_p, seed, offset);
+  return launch_tri_attn_fwd(qkv, obar, probs, attn_w, av_w, B, act_f32, (training && dropout_p > 0.f) ? 1 : 0, dc, (hipStream_t)stream);
+}
+int mmdeer_trimodal_attn_bwd(const void* qkv, const void* dobar, const float* probs, void* dqkv, int B,
+                             int act_f32, int training, float dropout_p, uint64_t seed, uint64_t offset, void* stream) {
+  const DropCtx dc = make_drop(dropout_p, seed, offset);
+  return launch_tri_attn_bwd(qkv, dobar, probs, dqkv, B, act_f32, (training && dropout_p > 0.f) ? 1 : 0, dc, (hipStream_t)stream);
+}
+
+long long mmdeer_nig_stats_elems(int B) { return (long long)nig_nblocks(B) * 3 * NIG_NSTAT; }
+int mmdeer_nig_loss(const float* gamma, const float* nu, const float* alpha, const float* beta, const float* targets,
+                    float* stats, float* dgamma, float* dnu, float* dalpha, float* dbeta, float* loss_out,
+                    int32_t* bin_counts, int B, const mmdeer_loss_cfg* c, void* stream) {
+  MMDEER_CHECK(gamma && nu && alpha && beta && targets && stats && c, "nig_loss: NULL argument");
+  MMDEER_CHECK((dgamma && dnu && dalpha && dbeta) || (!dgamma && !dnu && !dalpha && !dbeta),
+               "nig_loss: pass all four gradient outputs or none");
+  LossCfg cfg;
+  cfg.reg_w = c->reg_weight; cfg.kl_w = c->kl_weight; cfg.ece_w = c->ece_weight; cfg.cross_w = c->cross_weight;
+  for (int i = 0; i < 3; ++i) cfg.task_w[i] = c->task_weight[i];
+  hipStream_t s = (hipStream_t)stream;
+  TRY(launch_nig_loss_stats(gamma, nu, alpha, beta, targets, stats, B, s));
+  return launch_nig_loss_grad(gamma, nu, alpha, beta, targets, stats, dgamma, dnu, dalpha, dbeta, loss_out, bin_counts, B, cfg, s);
+}
+
+int mmdeer_dropout_mask(int site, int rows, int cols, float dropout_p, uint64_t seed, uint64_t offset,
+                        unsigned char* out, void* stream) {
+  MMDEER_CHECK(out != nullptr, "dropout_mask: out is NULL");
+  const DropCtx dc = make_drop(dropout_p, seed, offset);
+  return launch_dropout_mask(dc, site, rows, cols, out, (hipStream_t)stream);
+}
+
+int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream) {
+  return launch_convert(src, src_f32, dst, dst_f32, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// Grouped MFMA GEMM: C = epilogue(A * B^T) for a list of independent problems in ONE launch.
+#pragma once
+#include "common.h"
+
+namespace mmdeer {
+
+// One problem:  C[M,N] (+)= op(A)[M,K] * op(B)[N,K]^T, strided-batched over `batch`.
+//   trans_a == 0 : A stored [M][K]  (K contiguous, leading dim lda)
+//   trans_a == 1 : A stored [K][M]  (M contiguous, leading dim lda)   -- the loader transposes 4xEPC blocks in registers
+//   trans_b      : same for B ([N][K] vs [K][N]).
+// This one kernel therefore serves  Y = X W^T (0,0),  dX = dY W (0,1: W is [N_layer][K_layer]) and
+// dW = dY^T X (1,1) without any transposed copy in HBM.
+struct GemmProblem {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;    // [N] added before activation, or null
+  float* bias_grad;     // dW problems: [M] row sums of op(A) over K (== column sums of dY), or null
+  const void* Y;        // epilogue mask source: C *= (Y > 0) * mask_scale, or null   (ReLU+dropout backward)
+  long long sA, sB, sC, sBias, sBiasGrad, sY;  // batch strides, in elements
+  int M, N, K, batch;
+  int lda, ldb, ldc, ldy;
+  int tiles_m, tiles_n;   // filled by the launcher
+  float mask_scale;
+  int drop_site;        // forward dropout site (after ReLU), -1 = none
+  int drop_shift;       // dropout granularity: one decision per 2^shift columns
+  int regen_site;       // multiply by the REGENERATED keep mask of this site (backward of a no-ReLU dropout), -1 = none
+  unsigned char a_f32, b_f32, c_f32, y_f32;   // storage dtypes (1 = fp32, 0 = bf16)
+  unsigned char trans_a, trans_b, relu, accumulate;
+  unsigned char a_vec16, b_vec16;             // bf16 source rows are 16-byte aligned (else 8-byte loads)
+  unsigned char pad_[2];
+};
+
+constexpr int GEMM_MAX_PROBLEMS = 6;
+
+struct GemmGroup {
+  int nprob;
+  int tile_start[GEMM_MAX_PROBLEMS + 1];
+  DropCtx drop;
+  GemmProblem p[GEMM_MAX_PROBLEMS];
+};
+
+enum GemmTile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2 };
+
+// compute_f32 = 1: fp32 operands in LDS, v_mfma_f32_16x16x4_f32 (exact fp32); 0: bf16 operands, v_mfma_f32_16x16x32_bf16.
+// Enqueues on `stream`, never synchronises.  Returns 0 / -1 (message via mmdeer_last_error()).
+int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t stream);
+
+void gemm_problem_defaults(GemmProblem& p);
+
+}  // namespace mmdeer

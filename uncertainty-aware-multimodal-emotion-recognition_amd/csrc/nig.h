@@ -1,0 +1,45 @@
+// Normal-Inverse-Gamma evidential head (reference deer.py:86-98) and MultiTaskDEERLoss
+// (reference losses.py:72-226, 268-348): forward, loss statistics and the fused backward.
+#pragma once
+#include "common.h"
+
+namespace mmdeer {
+
+constexpr int NIG_NSTAT = 35;      // per (block, dim): 5 sums + 10 bins x {sum conf, sum err, count}
+constexpr int NIG_LOSS_OUT = 17;   // per dim {total, nll, reg, kl, ece} x 3, cross, total
+
+struct LossCfg {
+  float reg_w, kl_w, ece_w, cross_w;   // losses.py:52-53, 239   (0.1, 0.01, 0.05, 0.05)
+  float task_w[3];                     // losses.py:256-259      (1, 1, 1)
+};
+
+inline int nig_nblocks(int B) { return B > 0 ? (B + 255) / 256 : 1; }
+
+// e2: [B,192] activations (post ReLU/dropout of the 128->64 layers, 3 heads side by side)
+// w3: packed weights [3][4][64] (activation dtype), b3: fp32, head stride `b3_stride` elements
+// evid: [B,3,4] fp32 raw evidence (saved for backward)
+// nig_out: [7][B][3] fp32 = mu, nu, alpha, beta, aleatoric, epistemic, total uncertainty
+// targets: [B,3] fp32 or null; stats: [nblk][3][NIG_NSTAT] fp32 block partials (written iff targets)
+int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_stride, float* evid, float* nig_out,
+                   const float* targets, float* stats, int B, int act_f32, hipStream_t s);
+
+// Backward of the head's last layer.  Two modes:
+//   loss mode  (targets != null): gradients of MultiTaskDEERLoss are formed in-kernel from `stats`;
+//                                  loss_out[17] and bin_counts[3][10] are written by block (0,0).
+//   chain mode (targets == null): gmu/gnu/galpha/gbeta [B,3] fp32 (each may be null) are upstream gradients.
+// Outputs: devid [B,3,4] fp32 (may be null), dz2 [B,192] (activation dtype; already multiplied by the
+// ReLU/dropout mask of e2), partial_w [nblk][3][4][64], partial_b [nblk][3][4].
+int launch_nig_bwd(const void* e2, const void* w3, const float* evid, const float* targets, const float* stats,
+                   const float* gmu, const float* gnu, const float* galpha, const float* gbeta,
+                   float* devid, void* dz2, float* partial_w, float* partial_b, float* loss_out, int* bin_counts,
+                   int B, int act_f32, float mask_scale, const LossCfg& cfg, hipStream_t s);
+
+// Standalone loss on given NIG parameters (the `nig_loss` op of the C-ABI): same statistics / gradient code,
+// inputs are gamma, nu, alpha, beta [B,3]; outputs loss_out[17], bin_counts[30] and (optional) d{gamma,nu,alpha,beta}.
+int launch_nig_loss_stats(const float* gamma, const float* nu, const float* alpha, const float* beta,
+                          const float* targets, float* stats, int B, hipStream_t s);
+int launch_nig_loss_grad(const float* gamma, const float* nu, const float* alpha, const float* beta,
+                         const float* targets, const float* stats, float* dgamma, float* dnu, float* dalpha,
+                         float* dbeta, float* loss_out, int* bin_counts, int B, const LossCfg& cfg, hipStream_t s);
+
+}  // namespace mmdeer

@@ -1,0 +1,416 @@
+// NIG evidential head + MultiTaskDEERLoss kernels for gfx950.
+//
+// grid = (ceil(B/256), 3): blockIdx.y is the emotion dimension (valence / arousal / dominance), one thread
+// per sample.  All batch reductions are wave shuffles -> 4-wave LDS combine -> one partial slab per block; the
+// consumer kernel sums the slabs in a fixed order, so loss values and gradients are run-to-run deterministic
+// and the ECE bin COUNTS are exact integers (bit-exact vs the reference's boolean masks for equal inputs).
+#include "nig.h"
+
+namespace mmdeer {
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// torch.linspace(0, 1, 11) in fp32 (== float32(i)/10)
+__device__ const float kEceEdges[11] = {0.0f, 0x1.99999ap-4f, 0x1.99999ap-3f, 0x1.333334p-2f, 0x1.99999ap-2f, 0x1p-1f,
+                                        0x1.333334p-1f, 0x1.666666p-1f, 0x1.99999ap-1f, 0x1.ccccccp-1f, 1.0f};
+constexpr float kEps = 1e-8f;                 // losses.py:53
+constexpr float kTwoPiEps = 6.28318530717958647692f;  // float32(2*pi + 1e-8) (losses.py:144)
+
+struct Nig { float mu, nu, alpha, beta; };
+
+__device__ __forceinline__ float softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus, threshold 20
+__device__ __forceinline__ float softplus_grad(float x) {
+  if (x > 20.f) return 1.f;
+  const float z = expf(x);
+  return z / (z + 1.f);
+}
+__device__ __forceinline__ Nig nig_act(const f32x4& ev) {   // deer.py:90-93
+  Nig n;
+  n.mu = ev.x;
+  n.nu = softplus(ev.y) + 1e-6f;
+  n.alpha = softplus(ev.z) + 1.0f;
+  n.beta = softplus(ev.w) + 1e-6f;
+  return n;
+}
+
+// digamma on [1, inf): recurrence up to x >= 6, then the asymptotic series
+__device__ __forceinline__ float digamma(float x) {
+  float r = 0.f;
+  while (x < 6.f) { r -= 1.f / x; x += 1.f; }
+  const float f = 1.f / (x * x);
+  return r + logf(x) - 0.5f / x
+         - f * (1.f / 12.f - f * (1.f / 120.f - f * (1.f / 252.f - f * (1.f / 240.f - f * (1.f / 132.f)))));
+}
+
+struct Terms { float logprob, reg, kla, klb, u, conf, aerr, err, A, lb; int bin; };
+
+__device__ __forceinline__ Terms loss_terms(const Nig& n, float y) {
+  Terms t;
+  t.err = y - n.mu;
+  const float e2 = t.err * t.err;
+  t.A = n.beta + 0.5f * n.nu * e2 + kEps;
+  t.lb = logf(n.beta + kEps);
+  t.logprob = 0.5f * logf(n.nu / kTwoPiEps) + n.alpha * t.lb - lgammaf(n.alpha + kEps) - (n.alpha + 0.5f) * logf(t.A);
+  t.aerr = fabsf(t.err);
+  t.reg = e2 * (2.f * n.beta + n.nu * e2);
+  const float am1 = n.alpha - 1.f;
+  t.kla = am1 * am1;
+  t.klb = t.lb * t.lb;           // (log(beta+eps) - log(1+eps))^2, log(float32(1 + 1e-8)) == 0
+  t.u = n.beta / (am1 + kEps);
+  t.conf = 1.0f / (1.0f + t.u);
+  t.bin = -1;
+#pragma unroll
+  for (int k = 0; k < 10; ++k)
+    if (t.conf > kEceEdges[k] && t.conf <= kEceEdges[k + 1]) t.bin = k;   // (lo, hi]  losses.py:215
+  return t;
+}
+
+// block-wide reduction of the 35 per-sample statistics into one slab
+__device__ __forceinline__ void block_stats(const Terms& t, bool active, float* slab) {
+  __shared__ float sm[4][NIG_NSTAT];
+  float v[NIG_NSTAT];
+  v[0] = active ? t.logprob : 0.f;
+  v[1] = active ? t.reg : 0.f;
+  v[2] = active ? t.kla : 0.f;
+  v[3] = active ? t.klb : 0.f;
+  v[4] = active ? t.u : 0.f;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const bool in = active && t.bin == k;
+    v[5 + k] = in ? t.conf : 0.f;
+    v[15 + k] = in ? t.aerr : 0.f;
+    v[25 + k] = in ? 1.f : 0.f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NIG_NSTAT; ++i) {
+    const float s = wave_sum(v[i]);
+    if (lane == 0) sm[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NIG_NSTAT)
+    slab[threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// Finals derived from the global statistics; they live in LDS (indexed by runtime dim / bin) and are
+// computed redundantly by every block (a few hundred flops) so no extra launch or grid barrier is needed.
+struct Finals {
+  float sign[3][10];        // sign(mean conf - mean acc) per bin
+  float dcross[3];          // d cross / d ubar_d
+  float out[NIG_LOSS_OUT];  // per dim {total, nll, reg, kl, ece}, cross, total
+  int counts[3][10];
+};
+
+__device__ __forceinline__ void compute_finals(const float* stats, int nblk, int B, const LossCfg& cfg, Finals& F,
+                                               float (*gs)[NIG_NSTAT]) {
+  for (int i = threadIdx.x; i < 3 * NIG_NSTAT; i += blockDim.x) {
+    const int d = i / NIG_NSTAT, k = i - d * NIG_NSTAT;
+    float acc = 0.f;
+    for (int p = 0; p < nblk; ++p) acc += stats[((long long)p * 3 + d) * NIG_NSTAT + k];
+    gs[d][k] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float N = (float)B;
+    float ubar[3];
+    float tot = 0.f;
+    for (int d = 0; d < 3; ++d) {
+      float ece = 0.f;
+      for (int k = 0; k < 10; ++k) {
+        const float cnt = gs[d][25 + k];
+        F.counts[d][k] = (int)cnt;
+        float sg = 0.f;
+        if (cnt > 0.f) {
+          const float diff = gs[d][5 + k] / cnt - (1.0f - gs[d][15 + k] / cnt);   // losses.py:219-224
+          ece += (cnt / N) * fabsf(diff);
+          sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        }
+        F.sign[d][k] = sg;
+      }
+      const float nll = -gs[d][0] / N, reg = gs[d][1] / N;
+      const float kl = gs[d][2] / N + 0.1f * (gs[d][3] / N);
+      const float total = nll + cfg.reg_w * reg + cfg.kl_w * kl + cfg.ece_w * ece;   // losses.py:121
+      F.out[d * 5 + 0] = total; F.out[d * 5 + 1] = nll; F.out[d * 5 + 2] = reg; F.out[d * 5 + 3] = kl; F.out[d * 5 + 4] = ece;
+      ubar[d] = gs[d][4] / N;
+      tot += cfg.task_w[d] * total;
+    }
+    const float d01 = ubar[0] - ubar[1], d02 = ubar[0] - ubar[2], d12 = ubar[1] - ubar[2];
+    const float cross = (d01 * d01 + d02 * d02 + d12 * d12) / 3.f;                  // losses.py:339-346
+    F.dcross[0] = (2.f / 3.f) * (d01 + d02);
+    F.dcross[1] = (2.f / 3.f) * (-d01 + d12);
+    F.dcross[2] = (2.f / 3.f) * (-d02 - d12);
+    if (cfg.cross_w > 0.f) tot += cfg.cross_w * cross;
+    F.out[15] = cross;
+    F.out[16] = tot / 3.f;                                                          // losses.py:314
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void write_loss(const Finals& F, float* loss_out, int* bin_counts) {
+  if (loss_out)
+    for (int i = 0; i < NIG_LOSS_OUT; ++i) loss_out[i] = F.out[i];
+  if (bin_counts)
+    for (int i = 0; i < 30; ++i) bin_counts[i] = F.counts[i / 10][i % 10];
+}
+
+// d loss / d (mu, nu, alpha, beta) of one (sample, dim)
+__device__ __forceinline__ f32x4 loss_grad(const Nig& n, const Terms& t, int d, int B, const LossCfg& cfg, const Finals& F) {
+  const float invN = 1.f / (float)B;
+  const float cd = cfg.task_w[d] / 3.f;
+  const float e2 = t.err * t.err;
+  const float ah = n.alpha + 0.5f;
+  const float sg = (t.bin >= 0) ? F.sign[d][t.bin] : 0.f;
+  const float den = (n.alpha - 1.f) + kEps;
+  const float du_db = 1.f / den, du_da = -t.u / den;
+  const float dconf_du = -t.conf * t.conf;
+  const float serr = t.err > 0.f ? 1.f : (t.err < 0.f ? -1.f : 0.f);
+  const float gu = (cfg.cross_w / 3.f) * F.dcross[d] * invN;      // via ubar_d
+  f32x4 g;
+  // mu
+  g.x = cd * invN * (-(ah * n.nu * t.err) / t.A + cfg.reg_w * (2.f * n.beta + 2.f * n.nu * e2) * (-2.f * t.err)
+                     + cfg.ece_w * sg * (-serr));
+  // nu
+  g.y = cd * invN * (-(0.5f / n.nu - ah * 0.5f * e2 / t.A) + cfg.reg_w * e2 * e2);
+  // alpha
+  g.z = cd * invN * (-(t.lb - digamma(n.alpha + kEps) - logf(t.A)) + cfg.kl_w * 2.f * (n.alpha - 1.f)
+                     + cfg.ece_w * sg * dconf_du * du_da)
+        + gu * du_da;
+  // beta
+  g.w = cd * invN * (-(n.alpha / (n.beta + kEps) - ah / t.A) + cfg.reg_w * 2.f * e2
+                     + cfg.kl_w * 0.2f * t.lb / (n.beta + kEps) + cfg.ece_w * sg * dconf_du * du_db)
+        + gu * du_db;
+  return g;
+}
+
+template <bool F32>
+__device__ __forceinline__ void load_row64(const void* e2, long long idx, float (&x)[64]) {
+  if constexpr (F32) {
+    const float* p = reinterpret_cast<const float*>(e2) + idx;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * i);
+      x[4 * i] = a.x; x[4 * i + 1] = a.y; x[4 * i + 2] = a.z; x[4 * i + 3] = a.w;
+    }
+  } else {
+    const bf16_t* p = reinterpret_cast<const bf16_t*>(e2) + idx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      u32x4 a = *reinterpret_cast<const u32x4*>(p + 8 * i);
+      x[8 * i + 0] = __uint_as_float(a.x << 16); x[8 * i + 1] = __uint_as_float(a.x & 0xFFFF0000u);
+      x[8 * i + 2] = __uint_as_float(a.y << 16); x[8 * i + 3] = __uint_as_float(a.y & 0xFFFF0000u);
+      x[8 * i + 4] = __uint_as_float(a.z << 16); x[8 * i + 5] = __uint_as_float(a.z & 0xFFFF0000u);
+      x[8 * i + 6] = __uint_as_float(a.w << 16); x[8 * i + 7] = __uint_as_float(a.w & 0xFFFF0000u);
+    }
+  }
+}
+
+template <bool F32>
+__device__ __forceinline__ float wload(const void* w, int idx) {
+  if constexpr (F32) return reinterpret_cast<const float*>(w)[idx];
+  else return bf2f(reinterpret_cast<const bf16_t*>(w)[idx]);
+}
+
+// ------------------------------------------------------------------ forward (+ loss statistics)
+template <bool F32>
+__global__ __launch_bounds__(256) void nig_fwd_kernel(const void* e2, const void* w3, const float* b3, int b3_stride,
+                                                      float* evid, float* nig_out, const float* targets, float* stats, int B) {
+  __shared__ float W[4][64];
+  const int d = blockIdx.y, tid = threadIdx.x;
+  W[tid >> 6][tid & 63] = wload<F32>(w3, d * 256 + tid);
+  __syncthreads();
+  const int b = blockIdx.x * 256 + tid;
+  const bool active = b < B;
+  Nig n{0.f, 1.f, 2.f, 1.f};
+  if (active) {
+    float x[64];
+    load_row64<F32>(e2, (long long)b * 192 + d * 64, x);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      a0 = fmaf(x[j], W[0][j], a0); a1 = fmaf(x[j], W[1][j], a1);
+      a2 = fmaf(x[j], W[2][j], a2); a3 = fmaf(x[j], W[3][j], a3);
+    }
+    const float* bb = b3 + d * b3_stride;
+    const f32x4 ev{a0 + bb[0], a1 + bb[1], a2 + bb[2], a3 + bb[3]};
+    *reinterpret_cast<f32x4*>(evid + ((long long)b * 3 + d) * 4) = ev;
+    n = nig_act(ev);
+    const float alea = n.beta / (n.alpha - 1.f);             // deer.py:96-98
+    const float epis = n.beta / (n.nu * (n.alpha - 1.f));
+    const long long o = (long long)b * 3 + d, plane = (long long)B * 3;
+    nig_out[o] = n.mu; nig_out[plane + o] = n.nu; nig_out[2 * plane + o] = n.alpha; nig_out[3 * plane + o] = n.beta;
+    nig_out[4 * plane + o] = alea; nig_out[5 * plane + o] = epis; nig_out[6 * plane + o] = alea + epis;
+  }
+  if (targets) {   // uniform across the grid
+    const float y = active ? targets[(long long)b * 3 + d] : 0.f;
+    const Terms t = loss_terms(n, y);
+    block_stats(t, active, stats + ((long long)blockIdx.x * 3 + d) * NIG_NSTAT);
+  }
+}
+
+// ------------------------------------------------------------------ backward of the last head layer
+template <bool F32>
+__global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void* w3, const float* evid, const float* targets,
+                                                      const float* stats, const float* gmu, const float* gnu,
+                                                      const float* galpha, const float* gbeta, float* devid, void* dz2,
+                                                      float* partial_w, float* partial_b, float* loss_out,
+                                                      int* bin_counts, int B, float mask_scale, LossCfg cfg) {
+  __shared__ float W[4][64];
+  __shared__ float gs[3][NIG_NSTAT];
+  __shared__ f32x4 sdE[256];
+  __shared__ Finals F;
+  const int d = blockIdx.y, tid = threadIdx.x;
+  const int nblk = gridDim.x;
+  W[tid >> 6][tid & 63] = wload<F32>(w3, d * 256 + tid);
+  const bool loss_mode = targets != nullptr;
+  if (loss_mode) {
+    compute_finals(stats, nblk, B, cfg, F, gs);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) write_loss(F, loss_out, bin_counts);
+  }
+  __syncthreads();
+  const int b = blockIdx.x * 256 + tid;
+  const bool active = b < B;
+  f32x4 dE{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const long long o = (long long)b * 3 + d;
+    const f32x4 ev = *reinterpret_cast<const f32x4*>(evid + o * 4);
+    f32x4 g{0.f, 0.f, 0.f, 0.f};
+    if (loss_mode) {
+      const Nig n = nig_act(ev);
+      const Terms t = loss_terms(n, targets[o]);
+      g = loss_grad(n, t, d, B, cfg, F);
+    } else {
+      if (gmu) g.x = gmu[o];
+      if (gnu) g.y = gnu[o];
+      if (galpha) g.z = galpha[o];
+      if (gbeta) g.w = gbeta[o];
+    }
+    dE = f32x4{g.x, g.y * softplus_grad(ev.y), g.z * softplus_grad(ev.z), g.w * softplus_grad(ev.w)};
+    if (devid) *reinterpret_cast<f32x4*>(devid + o * 4) = dE;
+    // d e2 = dE . W3, masked by the ReLU/dropout of e2
+    float x[64];
+    load_row64<F32>(e2, (long long)b * 192 + d * 64, x);
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const float v = dE.x * W[0][j] + dE.y * W[1][j] + dE.z * W[2][j] + dE.w * W[3][j];
+      x[j] = x[j] > 0.f ? v * mask_scale : 0.f;
+    }
+    const long long zo = (long long)b * 192 + d * 64;
+    if constexpr (F32) {
+      float* p = reinterpret_cast<float*>(dz2) + zo;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(p + 4 * i) = f32x4{x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
+    } else {
+      bf16_t* p = reinterpret_cast<bf16_t*>(dz2) + zo;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<u32x4*>(p + 8 * i) = u32x4{pack_bf2(x[8 * i], x[8 * i + 1]), pack_bf2(x[8 * i + 2], x[8 * i + 3]),
+                                                     pack_bf2(x[8 * i + 4], x[8 * i + 5]), pack_bf2(x[8 * i + 6], x[8 * i + 7])};
+    }
+  }
+  sdE[tid] = dE;
+  __syncthreads();
+  // weight-gradient partial of this block: dW3[d][c][j] = sum_s dE[s][c] * e2[s][d*64 + j]
+  {
+    const int c = tid >> 6, j = tid & 63;
+    const int rows = min(256, B - blockIdx.x * 256);
+    float acc = 0.f;
+    for (int s = 0; s < rows; ++s) {
+      const f32x4 e = sdE[s];
+      const float ec = c == 0 ? e.x : (c == 1 ? e.y : (c == 2 ? e.z : e.w));
+      const long long idx = (long long)(blockIdx.x * 256 + s) * 192 + d * 64 + j;
+      const float xv = F32 ? reinterpret_cast<const float*>(e2)[idx] : bf2f(reinterpret_cast<const bf16_t*>(e2)[idx]);
+      acc = fmaf(ec, xv, acc);
+    }
+    partial_w[((long long)blockIdx.x * 3 + d) * 256 + tid] = acc;
+    if (tid < 4) {
+      float bs = 0.f;
+      for (int s = 0; s < rows; ++s) {
+        const f32x4 e = sdE[s];
+        bs += tid == 0 ? e.x : (tid == 1 ? e.y : (tid == 2 ? e.z : e.w));
+      }
+      partial_b[((long long)blockIdx.x * 3 + d) * 4 + tid] = bs;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ standalone loss on given NIG parameters
+__global__ __launch_bounds__(256) void nig_loss_stats_kernel(const float* gamma, const float* nu, const float* alpha,
+                                                             const float* beta, const float* targets, float* stats, int B) {
+  const int d = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+  const bool active = b < B;
+  Nig n{0.f, 1.f, 2.f, 1.f};
+  float y = 0.f;
+  if (active) {
+    const long long o = (long long)b * 3 + d;
+    n = Nig{gamma[o], nu[o], alpha[o], beta[o]};
+    y = targets[o];
+  }
+  const Terms t = loss_terms(n, y);
+  block_stats(t, active, stats + ((long long)blockIdx.x * 3 + d) * NIG_NSTAT);
+}
+
+__global__ __launch_bounds__(256) void nig_loss_grad_kernel(const float* gamma, const float* nu, const float* alpha,
+                                                            const float* beta, const float* targets, const float* stats,
+                                                            float* dgamma, float* dnu, float* dalpha, float* dbeta,
+                                                            float* loss_out, int* bin_counts, int B, LossCfg cfg) {
+  __shared__ float gs[3][NIG_NSTAT];
+  __shared__ Finals F;
+  compute_finals(stats, gridDim.x, B, cfg, F, gs);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) write_loss(F, loss_out, bin_counts);
+  const int d = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B || !dgamma) return;
+  const long long o = (long long)b * 3 + d;
+  const Nig n{gamma[o], nu[o], alpha[o], beta[o]};
+  const Terms t = loss_terms(n, targets[o]);
+  const f32x4 g = loss_grad(n, t, d, B, cfg, F);
+  dgamma[o] = g.x; dnu[o] = g.y; dalpha[o] = g.z; dbeta[o] = g.w;
+}
+
+}  // namespace
+
+int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_stride, float* evid, float* nig_out,
+                   const float* targets, float* stats, int B, int act_f32, hipStream_t s) {
+  if (B == 0) return 0;
+  dim3 grid(nig_nblocks(B), 3);
+  if (act_f32) hipLaunchKernelGGL(nig_fwd_kernel<true>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B);
+  else hipLaunchKernelGGL(nig_fwd_kernel<false>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_nig_bwd(const void* e2, const void* w3, const float* evid, const float* targets, const float* stats,
+                   const float* gmu, const float* gnu, const float* galpha, const float* gbeta,
+                   float* devid, void* dz2, float* partial_w, float* partial_b, float* loss_out, int* bin_counts,
+                   int B, int act_f32, float mask_scale, const LossCfg& cfg, hipStream_t s) {
+  MMDEER_CHECK(B > 0, "nig backward needs a non-empty batch");
+  dim3 grid(nig_nblocks(B), 3);
+  if (act_f32)
+    hipLaunchKernelGGL(nig_bwd_kernel<true>, grid, dim3(256), 0, s, e2, w3, evid, targets, stats, gmu, gnu, galpha, gbeta,
+                       devid, dz2, partial_w, partial_b, loss_out, bin_counts, B, mask_scale, cfg);
+  else
+    hipLaunchKernelGGL(nig_bwd_kernel<false>, grid, dim3(256), 0, s, e2, w3, evid, targets, stats, gmu, gnu, galpha, gbeta,
+                       devid, dz2, partial_w, partial_b, loss_out, bin_counts, B, mask_scale, cfg);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_nig_loss_stats(const float* gamma, const float* nu, const float* alpha, const float* beta,
+                          const float* targets, float* stats, int B, hipStream_t s) {
+  MMDEER_CHECK(B > 0, "nig loss needs a non-empty batch");
+  hipLaunchKernelGGL(nig_loss_stats_kernel, dim3(nig_nblocks(B), 3), dim3(256), 0, s, gamma, nu, alpha, beta, targets, stats, B);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_nig_loss_grad(const float* gamma, const float* nu, const float* alpha, const float* beta,
+                         const float* targets, const float* stats, float* dgamma, float* dnu, float* dalpha,
+                         float* dbeta, float* loss_out, int* bin_counts, int B, const LossCfg& cfg, hipStream_t s) {
+  MMDEER_CHECK(B > 0, "nig loss needs a non-empty batch");
+  hipLaunchKernelGGL(nig_loss_grad_kernel, dim3(nig_nblocks(B), 3), dim3(256), 0, s, gamma, nu, alpha, beta, targets, stats,
+                     dgamma, dnu, dalpha, dbeta, loss_out, bin_counts, B, cfg);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mmdeer

@@ -1,0 +1,51 @@
+// Row-wise (HBM-bound) kernels: parameter pack/cast, LayerNorm forward/backward, partial-sum reduction.
+#pragma once
+#include "common.h"
+
+namespace mmdeer {
+
+constexpr int PACK_MAX_SEGMENTS = 56;
+struct PackTable {
+  int nseg;
+  int total_chunks;                 // sum over segments of ceil(n/4)
+  const float* src[PACK_MAX_SEGMENTS];
+  long long dst_off[PACK_MAX_SEGMENTS];   // element offset in the packed buffer (multiple of 64)
+  int n[PACK_MAX_SEGMENTS];               // elements (multiple of 4)
+  int chunk_start[PACK_MAX_SEGMENTS + 1];
+  unsigned char is_vec[PACK_MAX_SEGMENTS]; // 1: bias / LayerNorm vector -> fp32 buffer; 0: weight matrix -> compute-dtype buffer
+};
+// fp32 parameter tensors -> packed buffers: matrices go to `wdst` in the compute dtype (fp32 copy or bf16 RNE
+// cast), vectors go to `vdst` in fp32.  Both buffers use the same flat element offsets.
+int launch_pack_params(PackTable& t, void* wdst, int w_f32, float* vdst, hipStream_t s);
+
+// out = LayerNorm(y) * gamma + beta over the last dim (eps 1e-5, biased variance); stats = {mean, rstd} per row.
+// y / out are activations of dtype `act_f32`; out32 (optional) receives an fp32 copy for user-visible features.
+int launch_ln_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,
+                  const float* beta, int M, int N, int act_f32, hipStream_t s);
+
+// LayerNorm backward fused with the ReLU+dropout mask that precedes it in nn.Sequential(Linear, ReLU, Dropout, LN):
+//   dy = LN'(dout) ; dz = (y > 0) ? dy * mask_scale : 0
+// partial: [nparts][2][N] fp32 (dgamma then dbeta rows) -- reduced later by launch_reduce_partials.
+int ln_bwd_nparts(int M);
+int launch_ln_bwd(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
+                  void* dz, float* partial, int M, int N, int act_f32, float mask_scale, hipStream_t s);
+
+constexpr int REDUCE_MAX_SEGMENTS = 8;
+struct ReduceTable {
+  int nseg;
+  const float* src[REDUCE_MAX_SEGMENTS];  // part p of element j at src[p * stride + j]
+  float* dst[REDUCE_MAX_SEGMENTS];        // [n]
+  int nparts[REDUCE_MAX_SEGMENTS];
+  int n[REDUCE_MAX_SEGMENTS];
+  int stride[REDUCE_MAX_SEGMENTS];
+  int start[REDUCE_MAX_SEGMENTS + 1];     // prefix of n
+};
+int launch_reduce_partials(ReduceTable& t, hipStream_t s);
+
+// keep-mask dump for the test harness: out[r*cols + c] = keep(site, r, c) ? 1 : 0   (c already in site granularity)
+int launch_dropout_mask(const DropCtx& d, int site, int rows, int cols, unsigned char* out, hipStream_t s);
+
+// plain dtype conversion of a contiguous buffer (n % 4 == 0)
+int launch_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, hipStream_t s);
+
+}  // namespace mmdeer

@@ -1,0 +1,282 @@
+// Row-wise HBM-bound kernels for gfx950: every global access is an 8- or 16-byte vector per lane,
+// one wave (64 lanes) owns one row, reductions are wave shuffles (no LDS on the per-row path).
+#include "rowops.h"
+
+namespace mmdeer {
+
+namespace {
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// kernel arguments live in the constant address space; indexing them through this pointer (instead of the
+// by-value parameter) keeps descriptor tables out of scratch when the index is a runtime value.
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T& karg() {
+  return *(const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+template <bool F32>
+__device__ __forceinline__ f32x4 load4(const void* base, long long idx) {
+  if constexpr (F32) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+  } else {
+    u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(base) + idx);
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u),
+                 __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u)};
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void store4(void* base, long long idx, f32x4 v) {
+  if constexpr (F32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+  } else {
+    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(base) + idx) = u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+  }
+}
+
+// ------------------------------------------------------------------ parameter pack
+template <bool DST_F32>
+__global__ __launch_bounds__(256) void pack_params_kernel(const PackTable t, void* wdst, float* vdst) {
+  const auto& T = karg<PackTable>();
+  const int total = T.total_chunks, nseg = T.nseg;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < total; c += gridDim.x * 256) {
+    int lo = 0, hi = nseg - 1;  // last segment whose chunk_start <= c
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (T.chunk_start[mid] <= c) lo = mid; else hi = mid - 1;
+    }
+    const int e = (c - T.chunk_start[lo]) * 4;
+    const float* src = (const float*)T.src[lo];
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + e);
+    if (T.is_vec[lo]) store4<true>(vdst, T.dst_off[lo] + e, v);
+    else store4<DST_F32>(wdst, T.dst_off[lo] + e, v);
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm forward
+constexpr int LN_MAX_VEC = 4;  // N <= 4 * 256 = 1024
+
+template <bool F32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* y, void* out, float* out32, float* mean, float* rstd,
+                                                     const float* gamma, const float* beta, int M, int N) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;  // whole wave exits together
+  const long long base = (long long)row * N;
+  f32x4 x[LN_MAX_VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < N) {
+      x[i] = load4<F32>(y, base + c);
+      s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+    } else {
+      x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mu = wave_sum(s) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < N) {
+      f32x4 d = x[i] - mu;
+      q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+  }
+  const float var = wave_sum(q) / (float)N;
+  const float rs = 1.0f / sqrtf(var + 1e-5f);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < N) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 o = (x[i] - mu) * rs * g + b;
+      store4<F32>(out, base + c, o);
+      if (out32) *reinterpret_cast<f32x4*>(out32 + base + c) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward (+ ReLU/dropout mask)
+template <bool F32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dout, const void* y, const float* mean, const float* rstd,
+                                                     const float* gamma, void* dz, float* partial, int M, int N,
+                                                     float mask_scale) {
+  __shared__ float red[4][2 * LN_MAX_VEC * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 g[LN_MAX_VEC], dg[LN_MAX_VEC], db[LN_MAX_VEC];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int c = lane * 4 + i * 256;
+    g[i] = (c < N) ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const long long base = (long long)row * N;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[LN_MAX_VEC], gd[LN_MAX_VEC], yv[LN_MAX_VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < N) {
+        yv[i] = load4<F32>(y, base + c);
+        f32x4 d = load4<F32>(dout, base + c);
+        xh[i] = (yv[i] - mu) * rs;
+        gd[i] = d * g[i];
+        dg[i] += d * xh[i];
+        db[i] += d;
+        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+        f32x4 t = gd[i] * xh[i];
+        s2 += (t.x + t.y) + (t.z + t.w);
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)N, m2 = wave_sum(s2) / (float)N;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < N) {
+        f32x4 dy = (gd[i] - m1 - xh[i] * m2) * rs;
+        f32x4 o;
+        o.x = yv[i].x > 0.f ? dy.x * mask_scale : 0.f;
+        o.y = yv[i].y > 0.f ? dy.y * mask_scale : 0.f;
+        o.z = yv[i].z > 0.f ? dy.z * mask_scale : 0.f;
+        o.w = yv[i].w > 0.f ? dy.w * mask_scale : 0.f;
+        store4<F32>(dz, base + c, o);
+      }
+    }
+  }
+  // combine the 4 waves' column partials, one [2][N] slab per workgroup (deterministic; summed by reduce_partials)
+#pragma unroll
+  for (int i = 0; i < LN_MAX_VEC; ++i) {
+    const int c = lane * 4 + i * 256;
+    *reinterpret_cast<f32x4*>(&red[wave][c]) = dg[i];
+    *reinterpret_cast<f32x4*>(&red[wave][LN_MAX_VEC * 256 + c]) = db[i];
+  }
+  __syncthreads();
+  float* slab = partial + (long long)blockIdx.x * 2 * N;
+  for (int c = threadIdx.x; c < N; c += 256) {
+    slab[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    const int o = LN_MAX_VEC * 256 + c;
+    slab[N + c] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+  }
+}
+
+// ------------------------------------------------------------------ partial-sum reduction
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceTable t) {
+  const auto& T = karg<ReduceTable>();
+  const int total = T.start[T.nseg];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    int sgm = 0;
+#pragma unroll
+    for (int i = 1; i < REDUCE_MAX_SEGMENTS; ++i)
+      if (i < T.nseg && e >= T.start[i]) sgm = i;
+    const int j = e - T.start[sgm], st = T.stride[sgm], np = T.nparts[sgm];
+    const float* src = (const float*)T.src[sgm];
+    float acc = 0.f;
+    for (int pidx = 0; pidx < np; ++pidx) acc += src[(long long)pidx * st + j];
+    ((float*)T.dst[sgm])[j] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(DropCtx d, int site, int rows, int cols, unsigned char* out) {
+  const long long total = (long long)rows * cols;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const unsigned r = (unsigned)(e / cols), c = (unsigned)(e - (long long)r * cols);
+    out[e] = drop_keep(d, site, r, c) ? 1 : 0;
+  }
+}
+
+template <bool SF32, bool DF32>
+__global__ __launch_bounds__(256) void convert_kernel(const void* src, void* dst, long long n4) {
+  for (long long c = blockIdx.x * 256ll + threadIdx.x; c < n4; c += gridDim.x * 256ll)
+    store4<DF32>(dst, c * 4, load4<SF32>(src, c * 4));
+}
+
+inline int grid_for(long long work, int per_block = 256, int cap = 2048) {
+  long long g = (work + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+int launch_pack_params(PackTable& t, void* wdst, int w_f32, float* vdst, hipStream_t s) {
+  MMDEER_CHECK(t.nseg >= 1 && t.nseg <= PACK_MAX_SEGMENTS, "pack: bad segment count %d", t.nseg);
+  int chunks = 0;
+  for (int i = 0; i < t.nseg; ++i) {
+    MMDEER_CHECK(t.n[i] % 4 == 0 && t.src[i] != nullptr, "pack: segment %d: n=%d must be a multiple of 4 and src non-null", i, t.n[i]);
+    t.chunk_start[i] = chunks;
+    chunks += t.n[i] / 4;
+  }
+  t.chunk_start[t.nseg] = chunks;
+  t.total_chunks = chunks;
+  const int grid = grid_for(t.total_chunks);
+  if (w_f32) hipLaunchKernelGGL(pack_params_kernel<true>, dim3(grid), dim3(256), 0, s, t, wdst, vdst);
+  else hipLaunchKernelGGL(pack_params_kernel<false>, dim3(grid), dim3(256), 0, s, t, wdst, vdst);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_ln_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,
+                  const float* beta, int M, int N, int act_f32, hipStream_t s) {
+  MMDEER_CHECK(N % 4 == 0 && N <= LN_MAX_VEC * 256, "layernorm: N=%d unsupported (multiple of 4, <= 1024)", N);
+  if (M == 0) return 0;
+  const int grid = (M + 3) / 4;
+  if (act_f32) hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, y, out, out32, mean, rstd, gamma, beta, M, N);
+  else hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, y, out, out32, mean, rstd, gamma, beta, M, N);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int ln_bwd_nparts(int M) {
+  int g = (M + 15) / 16;
+  if (g < 1) g = 1;
+  return g > 256 ? 256 : g;
+}
+
+int launch_ln_bwd(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
+                  void* dz, float* partial, int M, int N, int act_f32, float mask_scale, hipStream_t s) {
+  MMDEER_CHECK(N % 4 == 0 && N <= LN_MAX_VEC * 256, "layernorm: N=%d unsupported (multiple of 4, <= 1024)", N);
+  const int grid = ln_bwd_nparts(M);
+  if (act_f32) hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, dout, y, mean, rstd, gamma, dz, partial, M, N, mask_scale);
+  else hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, dout, y, mean, rstd, gamma, dz, partial, M, N, mask_scale);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_reduce_partials(ReduceTable& t, hipStream_t s) {
+  MMDEER_CHECK(t.nseg >= 1 && t.nseg <= REDUCE_MAX_SEGMENTS, "reduce: bad segment count %d", t.nseg);
+  int total = 0;
+  for (int i = 0; i < t.nseg; ++i) { t.start[i] = total; total += t.n[i]; }
+  for (int i = t.nseg; i <= REDUCE_MAX_SEGMENTS; ++i) t.start[i] = total;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(total)), dim3(256), 0, s, t);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_dropout_mask(const DropCtx& d, int site, int rows, int cols, unsigned char* out, hipStream_t s) {
+  if ((long long)rows * cols == 0) return 0;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((long long)rows * cols)), dim3(256), 0, s, d, site, rows, cols, out);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, hipStream_t s) {
+  MMDEER_CHECK(n % 4 == 0, "convert: n=%lld must be a multiple of 4", n);
+  if (n == 0) return 0;
+  const int grid = grid_for(n / 4);
+  if (src_f32 && dst_f32) hipLaunchKernelGGL((convert_kernel<true, true>), dim3(grid), dim3(256), 0, s, src, dst, n / 4);
+  else if (src_f32) hipLaunchKernelGGL((convert_kernel<true, false>), dim3(grid), dim3(256), 0, s, src, dst, n / 4);
+  else if (dst_f32) hipLaunchKernelGGL((convert_kernel<false, true>), dim3(grid), dim3(256), 0, s, src, dst, n / 4);
+  else hipLaunchKernelGGL((convert_kernel<false, false>), dim3(grid), dim3(256), 0, s, src, dst, n / 4);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mmdeer

@@ -1,0 +1,453 @@
+"""Host-side mirror of the reference's module protocol for the fusion + DEER path.
+
+``MultimodalDEER`` is the composite SURVEY 8b defines (the reference has no class
+of that name):
+
+    HierarchicalMultimodalFusion(84, 256, 768, fusion 512, inter 256, 8 heads, p 0.3)   fusion.py:47-106
+      -> MultiDimensionalDEER(512, 3 dims, hidden 256)                                  deer.py:201-231
+      -> compute_loss == MultiTaskDEERLoss() defaults                                   losses.py:237-240
+
+with the union of the calling conventions of the reference's script, trainer and
+evaluator (``model(audio, video, text)``, ``model({'audio':..,'video':..,'text':..})``,
+``compute_loss``, ``get_predictions_and_uncertainties``) and the reference's
+``state_dict`` parameter names.  All arithmetic runs in libmmdeer_hip.so; this file
+only owns parameters, buffers and the autograd glue.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib, synth
+from .spec import DEFAULT_DIMS, DIM_NAMES, Dims, gate_param_table, param_offsets, param_table
+
+LOSS_KEYS = ("total_loss", "nll_loss", "reg_loss", "kl_loss", "ece_loss")
+
+
+@dataclass
+class ModelConfig:
+    """Field names follow the reference's ModelConfig (complete_project.py:33-58)."""
+
+    audio_dim: int = 84
+    video_dim: int = 256
+    text_dim: int = 768
+    encoder_dim: int = 256
+    fusion_dim: int = 512
+    emotion_dims: int = 3
+    attention_heads: int = 8
+    encoder_layers: int = 3
+    dropout: float = 0.3
+    evidence_weight: float = 1.0
+    kl_weight: float = 0.1
+    learning_rate: float = 1e-4
+    weight_decay: float = 1e-5
+    gradient_clip: float = 1.0
+    # build-specific knobs (not in the reference)
+    compute_dtype: str = "fp32"   # "fp32": exact-fp32 MFMA (parity config); "bf16": bf16 MFMA, fp32 accumulate
+    seed: int = 42
+
+
+class _ParamTree(nn.Module):
+    """Container whose parameters are registered under dotted (reference) names."""
+
+    def add(self, dotted: str, tensor: torch.Tensor) -> nn.Parameter:
+        parts = dotted.split(".")
+        mod: nn.Module = self
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, _ParamTree())
+            mod = mod._modules[p]
+        prm = nn.Parameter(tensor)
+        mod.register_parameter(parts[-1], prm)
+        return prm
+
+
+def _as_cuda_f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"mmdeer: {what} must be a CUDA (ROCm) tensor; the hot path has no CPU implementation")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    return t.contiguous()
+
+
+class _State:
+    """Per-model launch state shared by the autograd functions."""
+
+    def __init__(self):
+        self.workspaces: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self.generation = 0
+        self.packed_key = None
+
+
+class _ForwardFn(torch.autograd.Function):
+    """One call == mmdeer_forward; backward == mmdeer_backward in chain mode."""
+
+    @staticmethod
+    def forward(ctx, model: "MultimodalDEER", audio, video, text, targets, *params):
+        out = model._launch_forward(audio, video, text, targets)
+        ctx.model = model
+        ctx.generation = model._st.generation
+        ctx.inputs = (audio, video, text)
+        ctx.meta = out["_meta"]
+        nig = out["_nig"]
+        res = tuple(nig[i] for i in range(7)) + (out["fused_features"], out["audiovisual_features"],
+                                                 out["trimodal_features"], out["av_attention"],
+                                                 out["trimodal_attention"])
+        ctx.save_for_backward(nig)
+        ctx.mark_non_differentiable(*res[7:])
+        return res
+
+    @staticmethod
+    def backward(ctx, g_mu, g_nu, g_alpha, g_beta, g_alea, g_epis, g_unc, *_unused):
+        model = ctx.model
+        (nig,) = ctx.saved_tensors
+        # fold gradients that arrive through the derived uncertainties (deer.py:96-98) into nu / alpha / beta
+        if g_alea is not None or g_epis is not None or g_unc is not None:
+            nu, alpha, beta = nig[1], nig[2], nig[3]
+            am1 = alpha - 1
+            ga = (g_alea if g_alea is not None else 0) + (g_unc if g_unc is not None else 0)
+            ge = (g_epis if g_epis is not None else 0) + (g_unc if g_unc is not None else 0)
+            zero = torch.zeros_like(nu)
+            ga = ga if torch.is_tensor(ga) else zero
+            ge = ge if torch.is_tensor(ge) else zero
+            d_beta = ga / am1 + ge / (nu * am1)
+            d_alpha = -ga * beta / (am1 * am1) - ge * beta / (nu * am1 * am1)
+            d_nu = -ge * beta / (nu * nu * am1)
+            g_beta = d_beta if g_beta is None else g_beta + d_beta
+            g_alpha = d_alpha if g_alpha is None else g_alpha + d_alpha
+            g_nu = d_nu if g_nu is None else g_nu + d_nu
+        grads = model._launch_backward(ctx, None, g_mu, g_nu, g_alpha, g_beta)
+        return (None, None, None, None, None) + tuple(grads)
+
+
+class _LossFn(torch.autograd.Function):
+    """MultiTaskDEERLoss on (gamma, nu, alpha, beta): one pass computes the loss components and the
+    gradients wrt the four inputs (mmdeer_nig_loss)."""
+
+    @staticmethod
+    def forward(ctx, gamma, nu, alpha, beta, targets, cfg: "_lib.LossCfg"):
+        lib = _lib.load()
+        B = gamma.shape[0]
+        dev = gamma.device
+        g, n, a, b = (t.contiguous().float() for t in (gamma, nu, alpha, beta))
+        y = targets.contiguous().float()
+        stats = torch.empty(lib.mmdeer_nig_stats_elems(B), dtype=torch.float32, device=dev)
+        grads = torch.empty(4, B, 3, dtype=torch.float32, device=dev)
+        loss_out = torch.empty(17, dtype=torch.float32, device=dev)
+        bins = torch.empty(30, dtype=torch.int32, device=dev)
+        _lib.check(lib.mmdeer_nig_loss(g.data_ptr(), n.data_ptr(), a.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                       stats.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
+                                       grads[2].data_ptr(), grads[3].data_ptr(), loss_out.data_ptr(),
+                                       bins.data_ptr(), B, C.byref(cfg), _lib.current_stream()))
+        ctx.save_for_backward(grads)
+        ctx.mark_non_differentiable(bins)
+        return loss_out, bins
+
+    @staticmethod
+    def backward(ctx, g_loss_out, _g_bins):
+        (grads,) = ctx.saved_tensors
+        # only total_loss (element 16) is a training objective; the components are reported values
+        s = g_loss_out[16]
+        return grads[0] * s, grads[1] * s, grads[2] * s, grads[3] * s, None, None
+
+
+def make_loss_cfg(reg_weight=0.1, kl_weight=0.01, ece_weight=0.05, cross_dim_weight=0.05,
+                  task_weights=(1.0, 1.0, 1.0)) -> "_lib.LossCfg":
+    cfg = _lib.LossCfg()
+    cfg.reg_weight, cfg.kl_weight, cfg.ece_weight, cfg.cross_weight = reg_weight, kl_weight, ece_weight, cross_dim_weight
+    for i in range(3):
+        cfg.task_weight[i] = float(task_weights[i])
+    return cfg
+
+
+def loss_dict_from(loss_out: torch.Tensor, batch_size: int) -> Dict[str, torch.Tensor]:
+    """Reference key layout of MultiTaskDEERLoss.forward (losses.py:303-318)."""
+    d: Dict[str, torch.Tensor] = {}
+    for i, dim in enumerate(DIM_NAMES):
+        for j, k in enumerate(LOSS_KEYS):
+            d[f"{dim}_{k}"] = loss_out[i * 5 + j]
+        d[f"{dim}_batch_size"] = batch_size
+    d["cross_dim_loss"] = loss_out[15]
+    d["total_loss"] = loss_out[16]
+    # keys the reference trainer accumulates when present (training.py:187-190)
+    d["deer_loss"] = loss_out[16]
+    d["nll_loss"] = (loss_out[1] + loss_out[6] + loss_out[11]) / 3
+    d["evidence_reg"] = (loss_out[2] + loss_out[7] + loss_out[12]) / 3
+    d["kl_reg"] = (loss_out[3] + loss_out[8] + loss_out[13]) / 3
+    return d
+
+
+class MultimodalDEER(nn.Module):
+    def __init__(self, config: Optional[ModelConfig] = None, init: str = "reference"):
+        super().__init__()
+        self.config = config or ModelConfig()
+        c = self.config
+        d = DEFAULT_DIMS
+        if (c.audio_dim, c.video_dim, c.text_dim, c.fusion_dim, c.emotion_dims, c.attention_heads) != (
+                d.audio, d.video, d.text, d.fusion, d.ndim, d.heads):
+            raise NotImplementedError(
+                "libmmdeer_hip.so is specialised for the reference geometry 84/256/768 -> 512, 8 heads, 3 dims "
+                f"(got {c})")
+        if c.compute_dtype not in ("fp32", "bf16"):
+            raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
+        self.dims = Dims(dropout=c.dropout)
+        self.fusion = _ParamTree()
+        self.head = _ParamTree()
+        state = (synth.reference_init_state(self.dims, seed=c.seed) if init == "reference"
+                 else synth.closed_form_state(self.dims, include_gate=True))
+        self._live = []
+        for name, _shape, _ in param_table(self.dims):
+            tree, sub = (self.fusion, name[len("fusion."):]) if name.startswith("fusion.") else (self.head, name[len("head."):])
+            self._live.append(tree.add(sub, torch.from_numpy(state[name].copy())))
+        # kept for state_dict compatibility only: unreachable in the reference, never gets a gradient
+        for name, _shape, _ in gate_param_table(self.dims):
+            self.fusion.add(name[len("fusion."):], torch.from_numpy(state[name].copy()))
+        self._offsets, self._flat_elems = param_offsets(self.dims)
+        self.loss_cfg = make_loss_cfg()
+        self._st = _State()
+        self._step = 0          # dropout counter offset: advanced once per training forward
+        self._flat_grad: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def compute_f32(self) -> int:
+        return 1 if self.config.compute_dtype == "fp32" else 0
+
+    def live_parameters(self):
+        return list(self._live)
+
+    def load_reference_state_dicts(self, fusion_sd: Dict[str, torch.Tensor], head_sd: Dict[str, torch.Tensor]):
+        """Load state_dicts saved from the reference's HierarchicalMultimodalFusion / MultiDimensionalDEER."""
+        self.fusion.load_state_dict(fusion_sd)
+        self.head.load_state_dict(head_sd)
+
+    def load_numpy_state(self, state) -> None:
+        sd = {k: torch.as_tensor(v) for k, v in state.items()}
+        own = self.state_dict()
+        for k in own:
+            if k in sd:
+                own[k].copy_(sd[k])
+
+    def _workspace(self, B: int, dev: torch.device) -> torch.Tensor:
+        key = (B, self.compute_f32, dev.index if dev.index is not None else 0)
+        ws = self._st.workspaces.get(key)
+        if ws is None:
+            nbytes = _lib.load().mmdeer_workspace_bytes(B, self.compute_f32)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._st.workspaces[key] = ws
+            self._st.packed_key = None
+        return ws
+
+    def _param_key(self, ws: torch.Tensor):
+        return (ws.data_ptr(),) + tuple((p.data_ptr(), p._version) for p in self._live)
+
+    def _launch_forward(self, audio, video, text, targets, prof_events=None):
+        lib = _lib.load()
+        audio, video, text = (_as_cuda_f32(t, n) for t, n in ((audio, "audio"), (video, "video"), (text, "text")))
+        B = audio.shape[0]
+        if audio.shape != (B, self.dims.audio) or video.shape != (B, self.dims.video) or text.shape != (B, self.dims.text):
+            raise ValueError(f"expected (B,84) (B,256) (B,768), got {tuple(audio.shape)} {tuple(video.shape)} {tuple(text.shape)}")
+        in_bf16 = audio.dtype == torch.bfloat16
+        if not (audio.dtype == video.dtype == text.dtype):
+            raise ValueError("audio / video / text must share one dtype")
+        if in_bf16 and self.compute_f32:
+            audio, video, text = audio.float(), video.float(), text.float()
+            in_bf16 = False
+        dev = audio.device
+        for p in self._live:
+            if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("mmdeer: parameters must be contiguous fp32 tensors on the inputs' device")
+        ws = self._workspace(B, dev)
+        key = self._param_key(ws)
+        repack = key != self._st.packed_key
+        training = self.training
+        if training:
+            self._step += 1
+        a = _lib.ForwardArgs()
+        a.batch, a.compute_f32, a.training, a.inputs_bf16, a.repack = B, self.compute_f32, int(training), int(in_bf16), int(repack)
+        a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), int(self._step)
+        a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
+        arr = (C.c_void_p * len(self._live))(*[p.data_ptr() for p in self._live])
+        a.params = arr
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        f32 = dict(dtype=torch.float32, device=dev)
+        nig = torch.empty(7, B, 3, **f32)
+        fused = torch.empty(B, self.dims.fusion, **f32)
+        avf = torch.empty(B, self.dims.inter, **f32)
+        trif = torch.empty(B, self.dims.fusion, **f32)
+        avw = torch.empty(B, 2, **f32)
+        triw = torch.empty(B, 2, 2, **f32)
+        a.nig_out, a.fused_features, a.audiovisual_features = nig.data_ptr(), fused.data_ptr(), avf.data_ptr()
+        a.trimodal_features, a.av_attention, a.trimodal_attention = trif.data_ptr(), avw.data_ptr(), triw.data_ptr()
+        if targets is not None:
+            targets = targets.contiguous().float()
+            a.targets = targets.data_ptr()
+        if prof_events is not None:
+            a.prof_events[0], a.prof_events[1] = prof_events[0].cuda_event, prof_events[1].cuda_event
+        a.stream = _lib.current_stream()
+        _lib.check(lib.mmdeer_forward(C.byref(a)))
+        self._st.packed_key = key
+        self._st.generation += 1
+        meta = dict(B=B, training=int(training), in_bf16=int(in_bf16), offset=int(self._step), ws=ws,
+                    inputs=(audio, video, text), targets=targets)
+        return {"_nig": nig, "_meta": meta, "fused_features": fused, "audiovisual_features": avf,
+                "trimodal_features": trif, "av_attention": avw, "trimodal_attention": triw}
+
+    def _launch_backward(self, ctx_or_meta, targets, g_mu=None, g_nu=None, g_alpha=None, g_beta=None,
+                         loss_out=None, bin_counts=None, events=None):
+        lib = _lib.load()
+        if isinstance(ctx_or_meta, dict):
+            meta = ctx_or_meta
+        else:
+            meta = ctx_or_meta.meta
+            if ctx_or_meta.generation != self._st.generation:
+                raise RuntimeError("mmdeer: the activations of this forward were overwritten by a later forward of the "
+                                   "same model; call backward() before the next forward (one workspace per batch size)")
+        B = meta["B"]
+        dev = meta["ws"].device
+        flat = torch.empty(self._flat_elems, dtype=torch.float32, device=dev)
+        a = _lib.BackwardArgs()
+        a.batch, a.compute_f32, a.training, a.inputs_bf16 = B, self.compute_f32, meta["training"], meta["in_bf16"]
+        a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), meta["offset"]
+        audio, video, text = meta["inputs"]
+        a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
+        a.workspace, a.workspace_bytes = meta["ws"].data_ptr(), meta["ws"].numel()
+        keep = []
+        if targets is not None:
+            a.targets = targets.data_ptr()
+        else:
+            for name, g in (("g_mu", g_mu), ("g_nu", g_nu), ("g_alpha", g_alpha), ("g_beta", g_beta)):
+                if g is not None:
+                    g = g.contiguous().float()
+                    keep.append(g)
+                    setattr(a, name, g.data_ptr())
+        a.loss = self.loss_cfg
+        a.grads = flat.data_ptr()
+        a.loss_out = _lib.ptr(loss_out)
+        a.bin_counts = _lib.ptr(bin_counts)
+        if events is not None:
+            for i, ev in enumerate(events):
+                a.bucket_events[i] = ev.cuda_event
+        a.stream = _lib.current_stream()
+        _lib.check(lib.mmdeer_backward(C.byref(a)))
+        self._flat_grad = flat
+        views = []
+        for p, off in zip(self._live, self._offsets):
+            views.append(flat[off:off + p.numel()].view(p.shape))
+        return views
+
+    # ------------------------------------------------------------------ reference-facing API
+    def forward(self, audio_features, video_features=None, text_features=None, targets=None) -> Dict[str, torch.Tensor]:
+        """``model(audio[B,84], video[B,256], text[B,768])`` (training.py:207, evaluation.py:171) or
+        ``model({'audio':..., 'video':..., 'text':...})`` (run_multimodal_deer.py:414-427)."""
+        if isinstance(audio_features, dict):
+            d = audio_features
+            audio_features = d.get("audio", d.get("audio_features"))
+            video_features = d.get("video", d.get("video_features"))
+            text_features = d.get("text", d.get("text_features"))
+        if audio_features is None or video_features is None or text_features is None:
+            raise ValueError("audio, video and text features are all required")
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._live)
+        if need_grad:
+            res = _ForwardFn.apply(self, audio_features, video_features, text_features, targets, *self._live)
+            mu, nu, alpha, beta, alea, epis, unc, fused, avf, trif, avw, triw = res
+        else:
+            o = self._launch_forward(audio_features, video_features, text_features, targets)
+            mu, nu, alpha, beta, alea, epis, unc = (o["_nig"][i] for i in range(7))
+            fused, avf, trif, avw, triw = (o["fused_features"], o["audiovisual_features"], o["trimodal_features"],
+                                           o["av_attention"], o["trimodal_attention"])
+        out: Dict[str, torch.Tensor] = {}
+        per_dim = (("mu", mu), ("nu", nu), ("alpha", alpha), ("beta", beta), ("aleatoric_uncertainty", alea),
+                   ("epistemic_uncertainty", epis), ("uncertainty", unc))
+        for i, dim in enumerate(DIM_NAMES):           # deer.py:254-255 -- (B,1) tensors
+            for key, val in per_dim:
+                out[f"{dim}_{key}"] = val[:, i:i + 1]
+        out["mu_all"] = mu                            # deer.py:258-264
+        out["uncertainty_all"] = unc
+        # script / evaluator conventions (run_multimodal_deer.py:430,721; evaluation.py:175-176)
+        out["gamma"], out["nu"], out["alpha"], out["beta"] = mu, nu, alpha, beta
+        out["mu"] = out["predictions"] = mu
+        out["uncertainties"] = out["total_uncertainty"] = unc
+        out["aleatoric_uncertainty"], out["epistemic_uncertainty"] = alea, epis
+        # fusion extras (fusion.py:164-171)
+        out["fused_features"] = fused
+        out["audiovisual_features"] = avf
+        out["trimodal_features"] = trif
+        out["av_attention_weights"] = {"audio_to_video": avw[:, 0:1], "video_to_audio": avw[:, 1:2]}
+        out["trimodal_attention_weights"] = triw
+        out["uncertainty_weights"] = None
+        return out
+
+    def get_predictions_and_uncertainties(self, outputs: Dict[str, torch.Tensor]):
+        """complete_project.py:590-602."""
+        return outputs["mu_all"], outputs.get("calibrated_uncertainty", outputs["uncertainty_all"])
+
+    def compute_loss(self, predictions: Dict[str, torch.Tensor], targets: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """The trainer hook (training.py:210): MultiTaskDEERLoss defaults, dict with a backprop-able 'total_loss'."""
+        return multitask_deer_loss(predictions, targets, self.loss_cfg)
+
+    def train_step(self, audio, video, text, targets, events=None, prof_events=None) -> Dict[str, torch.Tensor]:
+        """Fused forward + MultiTaskDEERLoss + backward: two library calls, gradients land in one flat buffer
+        (``.grad`` of every live parameter is a view of it).  Equivalent to
+        ``compute_loss(model(a, v, t), y)['total_loss'].backward()``."""
+        o = self._launch_forward(audio, video, text, targets, prof_events)
+        meta = o["_meta"]
+        dev = meta["ws"].device
+        loss_out = torch.empty(17, dtype=torch.float32, device=dev)
+        bins = torch.empty(30, dtype=torch.int32, device=dev)
+        views = self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, events=events)
+        for p, g in zip(self._live, views):
+            p.grad = g
+        d = loss_dict_from(loss_out, meta["B"])
+        d["ece_bin_counts"] = bins.view(3, 10)
+        d["_outputs"] = o
+        return d
+
+    def flat_grad(self) -> Optional[torch.Tensor]:
+        return self._flat_grad
+
+
+def _stack_pred(predictions: Dict[str, torch.Tensor], names) -> torch.Tensor:
+    for n in names:
+        if n in predictions and torch.is_tensor(predictions[n]) and predictions[n].dim() == 2 and predictions[n].shape[1] == 3:
+            return predictions[n]
+    cols = []
+    for dim in DIM_NAMES:
+        for n in names:
+            k = f"{dim}_{n}"
+            if k in predictions:
+                cols.append(predictions[k].reshape(-1, 1))
+                break
+        else:
+            raise ValueError(f"Missing required NIG parameters in predictions ({dim}: {names})")
+    return torch.cat(cols, dim=1)
+
+
+def multitask_deer_loss(predictions: Dict[str, torch.Tensor], targets: torch.Tensor,
+                        cfg: Optional["_lib.LossCfg"] = None) -> Dict[str, torch.Tensor]:
+    """MultiTaskDEERLoss.forward (losses.py:268-318) on a prediction dict, key aliases of losses.py:286-291."""
+    cfg = cfg or make_loss_cfg()
+    gamma = _stack_pred(predictions, ("gamma", "mu"))
+    nu = _stack_pred(predictions, ("nu", "lambda"))
+    alpha = _stack_pred(predictions, ("alpha",))
+    beta = _stack_pred(predictions, ("beta",))
+    if targets.dim() != 2 or targets.shape[1] != 3:
+        raise ValueError("targets must be (B, 3)")
+    loss_out, bins = _LossFn.apply(gamma, nu, alpha, beta, targets, cfg)
+    d = loss_dict_from(loss_out, gamma.shape[0])
+    d["ece_bin_counts"] = bins.view(3, 10)
+    return d
+
+
+# names the reference's script imports (run_multimodal_deer.py:72-82)
+CompleteDEERModel = MultimodalDEER
+
+
+def create_model(config: Optional[ModelConfig] = None, device: Optional[str] = None) -> MultimodalDEER:
+    m = MultimodalDEER(config)
+    return m.to(device) if device else m
