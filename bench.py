@@ -25,11 +25,23 @@ BF16_MFMA_PEAK = 2.5e15   # dense bf16 FLOP/s, MI355X_MICROARCH.md "Peak BF16/FP
 F32_MFMA_PEAK = 157.3e12
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(batch, seconds=12.0):
     """Time the oracle's fwd + loss + bwd (torch-CPU fp32) on all host cores for ~`seconds`."""
     from mmdeer import synth
     from oracle import deer_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     b = {k: torch.from_numpy(v) for k, v in synth.make_batch(batch, seed=42).items()}
     P = O.to_params(synth.reference_init_state(include_gate=False), requires_grad=True)

@@ -145,6 +145,11 @@ typedef struct mmdeer_gemm_args {
   int32_t drop_site, drop_shift, regen_site;
   float dropout_p, mask_scale;
   uint64_t seed, offset;
+  /* split-K (weight-gradient shapes: few output tiles, long reduction): splitk > 1 reduces K in slices whose fp32
+   * partials go to `slab` (splitk * (M*N + M) floats, rounded up to a multiple of 4 per slice) and are then
+   * summed in a fixed order; needs an fp32 C and no epilogue. */
+  int32_t splitk;
+  float* slab;
   void* stream;
 } mmdeer_gemm_args;
 int mmdeer_gemm(const mmdeer_gemm_args* a);

@@ -31,7 +31,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 def run_gemm(A, W, M, N, K, *, bias=None, relu=0, trans_a=0, trans_w=0, compute_f32=1, tile=-1, Y=None,
              mask_scale=1.0, bias_grad=None, c_dtype=None, drop_site=-1, drop_shift=0, regen_site=-1, p=0.0,
-             seed=1, offset=0, lda=None, ldw=None, accumulate=0, C_init=None):
+             seed=1, offset=0, lda=None, ldw=None, accumulate=0, C_init=None, splitk=1):
     lib = _lib.load()
     c_dtype = c_dtype or (torch.float32 if compute_f32 else torch.bfloat16)
     Cm = torch.zeros(M, N, dtype=c_dtype, device=dev()) if C_init is None else C_init.clone()
@@ -53,6 +53,10 @@ def run_gemm(A, W, M, N, K, *, bias=None, relu=0, trans_a=0, trans_w=0, compute_
     a.compute_f32, a.tile = compute_f32, tile
     a.drop_site, a.drop_shift, a.regen_site = drop_site, drop_shift, regen_site
     a.dropout_p, a.mask_scale, a.seed, a.offset = p, mask_scale, seed, offset
+    slab = None
+    if splitk > 1:
+        slab = torch.full((splitk * ((M * N + M + 3) // 4 * 4),), float("nan"), device=dev())
+        a.splitk, a.slab = splitk, slab.data_ptr()
     a.stream = stream()
     _lib.check(lib.mmdeer_gemm(C.byref(a)))
     torch.cuda.synchronize()
@@ -110,9 +114,10 @@ def test_gemm_dx(compute_f32, tile, M, N, K):
 
 
 @pytest.mark.parametrize("compute_f32", [1, 0])
+@pytest.mark.parametrize("splitk", [1, 3, 8])
 @pytest.mark.parametrize("tile", [0, 1, 2])
-@pytest.mark.parametrize("Bt,Nl,Kl", [(64, 128, 64), (100, 256, 84), (7, 64, 256), (513, 384, 256)])
-def test_gemm_dw_and_bias_grad(compute_f32, tile, Bt, Nl, Kl):
+@pytest.mark.parametrize("Bt,Nl,Kl", [(64, 128, 64), (100, 256, 84), (7, 64, 256), (513, 384, 256), (1100, 64, 128)])
+def test_gemm_dw_and_bias_grad(compute_f32, splitk, tile, Bt, Nl, Kl):
     """dW[Nl,Kl] = dY[Bt,Nl]^T X[Bt,Kl] and db = column sums of dY (both operands transposed by the loader)."""
     dY, X = rnd(Bt, Nl, seed=10), rnd(Bt, Kl, seed=11)
     if not compute_f32:
@@ -121,7 +126,7 @@ def test_gemm_dw_and_bias_grad(compute_f32, tile, Bt, Nl, Kl):
     # X stays fp32 in bf16 mode for the Kl=84 case: the loader converts (first-layer inputs are user fp32 tensors)
     Xs = X if (compute_f32 or Kl % 8) else bf(X)
     out = run_gemm(dY, Xs, Nl, Kl, Bt, trans_a=1, trans_w=1, compute_f32=compute_f32, tile=tile, bias_grad=dbias,
-                   c_dtype=torch.float32, lda=Nl, ldw=Kl)
+                   c_dtype=torch.float32, lda=Nl, ldw=Kl, splitk=splitk)
     Xr = Xs.double() if compute_f32 else bf(Xs).double()
     ref = dY.double().t() @ Xr
     tol = 1e-4 if compute_f32 else 2e-2

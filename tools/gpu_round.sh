@@ -19,3 +19,9 @@ step pytest_ops 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -p no:cache
 step pytest_model 600 python -m pytest tests/test_gpu_model.py -m gpu -q -p no:cacheprovider
 step smoke 300 python __graft_entry__.py smoke
 step bench 600 python bench.py --steps 20 --warmup 5
+step gemm_bench 600 python tools/gemm_bench.py
+head -70 gpurun_out/gemm_bench.log
+ROOT=$(pwd)
+export TMPDIR=/tmp
+( cd /tmp && step_dir=$ROOT/gpurun_out && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?" | tee -a $ROOT/gpurun_out/round.log )
+find gpurun_out/prof -name "*stats*" | head; tail -n 5 gpurun_out/rocprof.log

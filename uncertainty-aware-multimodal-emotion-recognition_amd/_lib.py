@@ -11,6 +11,11 @@ import os
 import threading
 from typing import Optional
 
+# torch must be imported BEFORE libmmdeer_hip.so is dlopen'ed: the PyTorch-ROCm wheel ships its own
+# libamdhip64.so, and the library has to bind to that already-loaded runtime (one HIP runtime per process,
+# shared streams and device pointers) rather than pull in a second copy from /opt/rocm/lib.
+import torch  # noqa: F401
+
 from . import build as _build
 
 _LIB: Optional[C.CDLL] = None
@@ -57,7 +62,8 @@ class GemmArgs(C.Structure):
         ("a_f32", c_int), ("w_f32", c_int), ("c_f32", c_int), ("y_f32", c_int), ("trans_a", c_int), ("trans_w", c_int),
         ("relu", c_int), ("accumulate", c_int), ("compute_f32", c_int), ("tile", c_int),
         ("drop_site", c_int), ("drop_shift", c_int), ("regen_site", c_int),
-        ("dropout_p", c_float), ("mask_scale", c_float), ("seed", c_u64), ("offset", c_u64), ("stream", c_void_p),
+        ("dropout_p", c_float), ("mask_scale", c_float), ("seed", c_u64), ("offset", c_u64),
+        ("splitk", c_int), ("slab", c_void_p), ("stream", c_void_p),
     ]
 
 

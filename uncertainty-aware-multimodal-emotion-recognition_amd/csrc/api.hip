@@ -60,6 +60,7 @@ constexpr int P_EV2_W = MMDEER_P_HEAD0_EV6_WEIGHT, P_EV2_B = MMDEER_P_HEAD0_EV6_
 
 constexpr int AUD = MMDEER_AUDIO_DIM, VID = MMDEER_VIDEO_DIM, TXT = MMDEER_TEXT_DIM, INTER = MMDEER_INTER_DIM;
 constexpr int FUS = MMDEER_FUSION_DIM, HID = MMDEER_HIDDEN_DIM, EV1 = 128, EV2 = 64;
+constexpr int SPLITK_MAX = 8;
 
 // ------------------------------------------------------------------ workspace layout
 struct Layout {
@@ -73,6 +74,7 @@ struct Layout {
   // backward scratch
   char *dz2, *de1, *dh2, *dh1, *dfused, *dz_o1, *dtri, *dz_t3, *dpool, *dobar, *dqkv, *dxtok, *dav, *dz_a2, *dcats, *davv, *davin;
   float *part_ln_o1, *part_ln_t3, *part_ln_a2, *part_w3, *part_b3;
+  float* slab;   // split-K partial weight gradients: [SPLITK_MAX][MMDEER_FLAT_ELEMS] fp32
   size_t bytes;
 };
 
@@ -106,6 +108,7 @@ Layout make_layout(void* base, int B, int f32) {
   const size_t np = (size_t)ln_bwd_nparts(B);
   L.part_ln_o1 = f32buf(np * 2 * FUS); L.part_ln_t3 = f32buf(np * 2 * FUS); L.part_ln_a2 = f32buf(np * 2 * INTER);
   L.part_w3 = f32buf(nblk * 3 * 256); L.part_b3 = f32buf(nblk * 3 * 4);
+  L.slab = f32buf((size_t)SPLITK_MAX * MMDEER_FLAT_ELEMS);
   L.bytes = off;
   return L;
 }
@@ -120,6 +123,17 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset) {
   d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
   d.scale = keep > 0 ? (float)(1.0 / keep) : 0.f;
   return d;
+}
+
+// target number of K-tiles per split-K slice of a weight-gradient problem (MMDEER_KSTEPS overrides)
+int ksteps_target() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MMDEER_KSTEPS");
+    v = e ? atoi(e) : 16;
+    if (v < 1) v = 1;
+  }
+  return v;
 }
 
 int forced_tile() {
@@ -186,7 +200,8 @@ struct Exec {
     p.Y = Ymask; p.y_f32 = f32; p.ldy = ldmask; p.mask_scale = mask_scale;
     return p;
   }
-  // dW = dY^T X (+ db = column sums of dY), written into the flat gradient buffer
+  // dW = dY^T X (+ db = column sums of dY), written into the flat gradient buffer.  The reduction runs over the
+  // batch (K = Mred rows): it is split into K-slices of ~ksteps_target() K-tiles whose partials go to the slab.
   GemmProblem dw(const void* dY, int ldy_in, const void* X, int x_f32, int ldx, int pidW, int pidB, float* grads, int Mred) const {
     GemmProblem p;
     gemm_problem_defaults(p);
@@ -195,7 +210,34 @@ struct Exec {
     p.C = grads + kParams[pidW].off; p.c_f32 = 1; p.ldc = kParams[pidW].cols;
     p.bias_grad = grads + kParams[pidB].off;
     p.M = kParams[pidW].rows; p.N = kParams[pidW].cols; p.K = Mred;
+    set_split(p, grads);
     return p;
+  }
+  // (re)derive the split-K fields from p.K and the final destinations p.C / p.bias_grad
+  void set_split(GemmProblem& p, float* grads) const {
+    const int nk = gemm_ktiles(p.K, f32);
+    int sk = (nk + ksteps_target() - 1) / ksteps_target();
+    if (sk > SPLITK_MAX) sk = SPLITK_MAX;
+    if (sk < 1) sk = 1;
+    p.splitk = sk;
+    p.slab_stride = MMDEER_FLAT_ELEMS;
+    p.slab_c = L->slab + (reinterpret_cast<float*>(p.C) - grads);
+    p.slab_b = p.bias_grad ? L->slab + (p.bias_grad - grads) : nullptr;
+  }
+  // segments that fold a split-K problem's slabs into its final destinations
+  static void add_slab_segments(ReduceTable& t, const GemmProblem& p, const float* slab, float* grads) {
+    if (p.splitk <= 1) return;
+    const long long csz = (long long)(p.batch - 1) * p.sC + (long long)(p.M - 1) * p.ldc + p.N;   // extent of C incl. batches
+    int k = t.nseg;
+    t.src[k] = p.slab_c; t.dst[k] = reinterpret_cast<float*>(p.C); t.nparts[k] = p.splitk;
+    t.n[k] = (int)((csz + 3) / 4 * 4); t.stride[k] = p.slab_stride; ++k;
+    if (p.bias_grad) {
+      const long long bsz = (long long)(p.batch - 1) * p.sBiasGrad + p.M;
+      t.src[k] = p.slab_b; t.dst[k] = p.bias_grad; t.nparts[k] = p.splitk;
+      t.n[k] = (int)((bsz + 3) / 4 * 4); t.stride[k] = p.slab_stride; ++k;
+    }
+    t.nseg = k;
+    (void)slab; (void)grads;
   }
   int run(GemmGroup& g) const {
     g.drop = dc;
@@ -365,16 +407,16 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   cfg.reg_w = a->loss.reg_weight; cfg.kl_w = a->loss.kl_weight; cfg.ece_w = a->loss.ece_weight;
   cfg.cross_w = a->loss.cross_weight;
   for (int i = 0; i < 3; ++i) cfg.task_w[i] = a->loss.task_weight[i];
-  const bool split_reduce = a->bucket_events[0] || a->bucket_events[1] || a->bucket_events[2];
   const int nblk = nig_nblocks(B), npl = ln_bwd_nparts(B);
 
   // the q/k thirds of the AV in_proj never receive a gradient (L = S = 1): exact zeros, as in the reference
   MMDEER_HIP(hipMemsetAsync(G + kParams[P_AIN_W].off, 0, sizeof(float) * 2 * INTER * INTER, s));
   MMDEER_HIP(hipMemsetAsync(G + kParams[P_AIN_B].off, 0, sizeof(float) * 2 * INTER, s));
 
-  // B1: last head layer + NIG activations (+ loss gradient)
-  TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
-                     L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
+  // Backward = a chain of dX GEMMs (each M = batch rows, plenty of tiles) and, per gradient bucket, ONE grouped
+  // launch of all the bucket's weight-gradient problems (few output tiles each, reduction over the batch, split
+  // over K into slabs) followed by one deterministic slab reduction.  A bucket's event is recorded right after
+  // its reduction so the data-parallel all-reduce of that bucket overlaps the rest of the chain.
   auto reduce_head = [&](ReduceTable& t) {
     int k = t.nseg;
     t.src[k] = L.part_w3; t.dst[k] = G + kParams[P_EV2_W].off; t.nparts[k] = nblk; t.n[k] = 768; t.stride[k] = 768; ++k;
@@ -388,157 +430,111 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     t.src[k] = part; t.dst[k] = G + kParams[pidG].off; t.nparts[k] = npl; t.n[k] = 2 * N; t.stride[k] = 2 * N; ++k;
     t.nseg = k;
   };
-  if (split_reduce) { ReduceTable t{}; reduce_head(t); TRY(launch_reduce_partials(t, s)); }
+  auto run_dw_bucket = [&](GemmGroup& g, ReduceTable& t) -> int {
+    if (X.run(g) != 0) return -1;
+    for (int i = 0; i < g.nprob; ++i) Exec::add_slab_segments(t, g.p[i], L.slab, G);
+    return launch_reduce_partials(t, s);
+  };
 
-  // B2: evidence_net layer 3 (128 -> 64), batched over heads: dX masked by e1, dW + db
+  // ================= bucket 0: DEER head =================
+  // B1: last head layer + NIG activations (+ loss gradient)
+  TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
+                     L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
+  // evidence_net layer 3 (128 -> 64), batched over heads: dX masked by e1
   {
-    GemmGroup g{};
-    g.nprob = 2;
     GemmProblem p = X.dx(L.dz2, 3 * EV2, P_EV1_W, L.de1, 3 * EV1, B, L.e1, 3 * EV1);
     p.batch = 3; p.sA = EV2; p.sB = (long long)EV2 * EV1; p.sC = EV1; p.sY = EV1;
-    g.p[0] = p;
-    GemmProblem q = X.dw(L.dz2, 3 * EV2, L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, G, B);
-    q.batch = 3; q.sA = EV2; q.sB = EV1; q.sC = (long long)EV2 * EV1; q.sBiasGrad = EV2;
-    g.p[1] = q;
-    TRY(X.run(g));
+    TRY(X.run1(p));
   }
-  // B3: evidence_net layer 0 (256 -> 3 x 128 stacked)
+  // evidence_net layer 0 (256 -> 3 x 128 stacked)
   {
-    GemmGroup g{};
-    g.nprob = 2;
     GemmProblem p = X.dx(L.de1, 3 * EV1, P_EV0_W, L.dh2, HID, B, L.h2, HID);
     p.K = 3 * EV1;
-    g.p[0] = p;
-    GemmProblem q = X.dw(L.de1, 3 * EV1, L.h2, f32, HID, P_EV0_W, P_EV0_B, G, B);
-    q.M = 3 * EV1;
-    g.p[1] = q;
-    TRY(X.run(g));
+    TRY(X.run1(p));
   }
-  // B4-B5: feature_processor
+  // feature_processor
+  TRY(X.run1(X.dx(L.dh2, HID, P_FP1_W, L.dh1, HID, B, L.h1, HID)));
+  TRY(X.run1(X.dx(L.dh1, HID, P_FP0_W, L.dfused, FUS, B, nullptr, 0)));
   {
     GemmGroup g{};
-    g.nprob = 2;
-    g.p[0] = X.dx(L.dh2, HID, P_FP1_W, L.dh1, HID, B, L.h1, HID);
-    g.p[1] = X.dw(L.dh2, HID, L.h1, f32, HID, P_FP1_W, P_FP1_B, G, B);
-    TRY(X.run(g));
-  }
-  {
-    GemmGroup g{};
-    g.nprob = 2;
-    g.p[0] = X.dx(L.dh1, HID, P_FP0_W, L.dfused, FUS, B, nullptr, 0);
-    g.p[1] = X.dw(L.dh1, HID, L.fused, f32, FUS, P_FP0_W, P_FP0_B, G, B);
-    TRY(X.run(g));
+    g.nprob = 4;
+    GemmProblem q = X.dw(L.dz2, 3 * EV2, L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, G, B);
+    q.batch = 3; q.sA = EV2; q.sB = EV1; q.sC = (long long)EV2 * EV1; q.sBiasGrad = EV2;
+    g.p[0] = q;
+    GemmProblem r = X.dw(L.de1, 3 * EV1, L.h2, f32, HID, P_EV0_W, P_EV0_B, G, B);
+    r.M = 3 * EV1;
+    g.p[1] = r;
+    g.p[2] = X.dw(L.dh2, HID, L.h1, f32, HID, P_FP1_W, P_FP1_B, G, B);
+    g.p[3] = X.dw(L.dh1, HID, L.fused, f32, FUS, P_FP0_W, P_FP0_B, G, B);
+    ReduceTable t{};
+    reduce_head(t);
+    TRY(run_dw_bucket(g, t));
   }
   if (a->bucket_events[0]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[0], s));
 
-  // B6-B7: output_projection
+  // ================= bucket 1: output_projection + trimodal fusion =================
   TRY(launch_ln_bwd(L.dfused, L.y_o1, L.mean_o1, L.rstd_o1, X.V(P_OP_G), L.dz_o1, L.part_ln_o1, B, FUS, f32, X.mask_scale, s));
+  TRY(X.run1(X.dx(L.dz_o1, FUS, P_OP_W, L.dtri, FUS, B, nullptr, 0)));
+  TRY(launch_ln_bwd(L.dtri, L.y_t3, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), L.dz_t3, L.part_ln_t3, B, FUS, f32, X.mask_scale, s));
+  TRY(X.run1(X.dx(L.dz_t3, FUS, P_TFF_W, L.dpool, FUS, B, nullptr, 0)));
+  TRY(X.run1(X.dx(L.dpool, FUS, P_TOUT_W, L.dobar, FUS, B, nullptr, 0)));      // attention out_proj (pooled context)
+  TRY(launch_tri_attn_bwd(L.qkv, L.dobar, L.probs, L.dqkv, B, f32, X.drop_on ? 1 : 0, X.dc, s));
+  TRY(X.run1(X.dx(L.dqkv, 3 * FUS, P_TIN_W, L.dxtok, FUS, 2 * B, nullptr, 0)));  // in_proj
+  TRY(X.run1(X.dx(L.dxtok, 2 * FUS, P_AVP_W, L.dav, INTER, B, nullptr, 0)));     // token 0 -> audiovisual features
   {
     GemmGroup g{};
-    g.nprob = 2;
-    g.p[0] = X.dx(L.dz_o1, FUS, P_OP_W, L.dtri, FUS, B, nullptr, 0);
-    g.p[1] = X.dw(L.dz_o1, FUS, L.tri, f32, FUS, P_OP_W, P_OP_B, G, B);
-    TRY(X.run(g));
-  }
-  // B8-B9: final_fusion
-  TRY(launch_ln_bwd(L.dtri, L.y_t3, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), L.dz_t3, L.part_ln_t3, B, FUS, f32, X.mask_scale, s));
-  if (split_reduce) {
+    g.nprob = 6;
+    g.p[0] = X.dw(L.dz_o1, FUS, L.tri, f32, FUS, P_OP_W, P_OP_B, G, B);
+    g.p[1] = X.dw(L.dz_t3, FUS, L.pool, f32, FUS, P_TFF_W, P_TFF_B, G, B);
+    g.p[2] = X.dw(L.dpool, FUS, L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, G, B);
+    g.p[3] = X.dw(L.dqkv, 3 * FUS, L.xtok, f32, FUS, P_TIN_W, P_TIN_B, G, 2 * B);
+    g.p[4] = X.dw(L.dxtok, 2 * FUS, L.av, f32, INTER, P_AVP_W, P_AVP_B, G, B);                          // token 0
+    g.p[5] = X.dw(L.dxtok + (size_t)FUS * es, 2 * FUS, a->text, in_f32, TXT, P_TXT_W, P_TXT_B, G, B);   // token 1
     ReduceTable t{};
     reduce_ln(t, L.part_ln_o1, P_OP_G, FUS);
     reduce_ln(t, L.part_ln_t3, P_TFF_G, FUS);
-    TRY(launch_reduce_partials(t, s));
-  }
-  {
-    GemmGroup g{};
-    g.nprob = 2;
-    g.p[0] = X.dx(L.dz_t3, FUS, P_TFF_W, L.dpool, FUS, B, nullptr, 0);
-    g.p[1] = X.dw(L.dz_t3, FUS, L.pool, f32, FUS, P_TFF_W, P_TFF_B, G, B);
-    TRY(X.run(g));
-  }
-  // B10: attention out_proj (applied to the pooled context)
-  {
-    GemmGroup g{};
-    g.nprob = 2;
-    g.p[0] = X.dx(L.dpool, FUS, P_TOUT_W, L.dobar, FUS, B, nullptr, 0);
-    g.p[1] = X.dw(L.dpool, FUS, L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, G, B);
-    TRY(X.run(g));
-  }
-  // B11: softmax attention backward
-  TRY(launch_tri_attn_bwd(L.qkv, L.dobar, L.probs, L.dqkv, B, f32, X.drop_on ? 1 : 0, X.dc, s));
-  // B12: in_proj
-  {
-    GemmGroup g{};
-    g.nprob = 2;
-    g.p[0] = X.dx(L.dqkv, 3 * FUS, P_TIN_W, L.dxtok, FUS, 2 * B, nullptr, 0);
-    g.p[1] = X.dw(L.dqkv, 3 * FUS, L.xtok, f32, FUS, P_TIN_W, P_TIN_B, G, 2 * B);
-    TRY(X.run(g));
-  }
-  // B13: token projections: audiovisual_projection (token 0: dX + dW) and text_projection (token 1: dW only)
-  {
-    GemmGroup g{};
-    g.nprob = 3;
-    g.p[0] = X.dx(L.dxtok, 2 * FUS, P_AVP_W, L.dav, INTER, B, nullptr, 0);
-    g.p[1] = X.dw(L.dxtok, 2 * FUS, L.av, f32, INTER, P_AVP_W, P_AVP_B, G, B);
-    g.p[2] = X.dw(L.dxtok + (size_t)FUS * es, 2 * FUS, a->text, in_f32, TXT, P_TXT_W, P_TXT_B, G, B);
-    TRY(X.run(g));
+    TRY(run_dw_bucket(g, t));
   }
   if (a->bucket_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[1], s));
 
-  // B14-B15: AV fusion_layers; the dX half is written "stacked" ([2B,256]: rows [0,B) = d audio_attended,
-  //          rows [B,2B) = d video_attended) by batching over the two column halves of the weight
+  // ================= bucket 2: audio-visual fusion =================
   TRY(launch_ln_bwd(L.dav, L.y_a2, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), L.dz_a2, L.part_ln_a2, B, INTER, f32, X.mask_scale, s));
+  // fusion_layers dX, written "stacked" ([2B,256]: rows [0,B) = d audio_attended, rows [B,2B) = d video_attended)
+  // by batching over the two column halves of the weight
   {
-    GemmGroup g{};
-    g.nprob = 2;
     GemmProblem p = X.dx(L.dz_a2, INTER, P_AVF_W, L.dcats, INTER, B, nullptr, 0);
     p.N = INTER; p.batch = 2; p.sB = INTER; p.sC = (long long)B * INTER;
-    g.p[0] = p;
-    g.p[1] = X.dw(L.dz_a2, INTER, L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, G, B);
-    TRY(X.run(g));
+    TRY(X.run1(p));
   }
-  // B16: AV out_proj; dX gets the regenerated attention-dropout factor of F2
+  // AV out_proj; dX gets the regenerated attention-dropout factor of the forward value projection
   {
-    GemmGroup g{};
-    g.nprob = 2;
     GemmProblem p = X.dx(L.dcats, INTER, P_AOUT_W, L.davv, INTER, 2 * B, nullptr, 0);
     if (X.drop_on) { p.regen_site = SITE_AV_ATTN; p.drop_shift = 5; }
-    g.p[0] = p;
-    g.p[1] = X.dw(L.dcats, INTER, L.avv, f32, INTER, P_AOUT_W, P_AOUT_B, G, 2 * B);
-    TRY(X.run(g));
+    TRY(X.run1(p));
   }
-  // B17: AV value projection (rows [2E,3E) of in_proj)
+  // AV value projection (rows [2E,3E) of in_proj)
   {
-    GemmGroup g{};
-    g.nprob = 2;
     GemmProblem p = X.dx(L.davv, INTER, P_AIN_W, L.davin, INTER, 2 * B, nullptr, 0);
     p.B = X.W(P_AIN_W) + (size_t)2 * INTER * INTER * es;
     p.K = INTER;
-    g.p[0] = p;
+    TRY(X.run1(p));
+  }
+  {
+    GemmGroup g{};
+    g.nprob = 5;
+    g.p[0] = X.dw(L.dz_a2, INTER, L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, G, B);
+    g.p[1] = X.dw(L.dcats, INTER, L.avv, f32, INTER, P_AOUT_W, P_AOUT_B, G, 2 * B);
     GemmProblem q = X.dw(L.davv, INTER, L.avin, f32, INTER, P_AIN_W, P_AIN_B, G, 2 * B);
     q.C = G + kParams[P_AIN_W].off + 2 * INTER * INTER;
     q.bias_grad = G + kParams[P_AIN_B].off + 2 * INTER;
     q.M = INTER;
-    g.p[1] = q;
-    TRY(X.run(g));
-  }
-  // B18: input projections (weights only: inputs need no gradient)
-  {
-    GemmGroup g{};
-    g.nprob = 2;
-    g.p[0] = X.dw(L.davin, INTER, a->video, in_f32, VID, P_VID_W, P_VID_B, G, B);
-    g.p[1] = X.dw(L.davin + (size_t)B * INTER * es, INTER, a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, G, B);
-    TRY(X.run(g));
-  }
-  // B19: fold the per-block partials (LayerNorm gamma/beta, last head layer) into the flat gradient buffer
-  {
+    X.set_split(q, G);
+    g.p[2] = q;
+    g.p[3] = X.dw(L.davin, INTER, a->video, in_f32, VID, P_VID_W, P_VID_B, G, B);                                  // rows [0,B)
+    g.p[4] = X.dw(L.davin + (size_t)B * INTER * es, INTER, a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, G, B);        // rows [B,2B)
     ReduceTable t{};
     reduce_ln(t, L.part_ln_a2, P_AVF_G, INTER);
-    if (!split_reduce) {
-      reduce_ln(t, L.part_ln_o1, P_OP_G, FUS);
-      reduce_ln(t, L.part_ln_t3, P_TFF_G, FUS);
-      reduce_head(t);
-    }
-    TRY(launch_reduce_partials(t, s));
+    TRY(run_dw_bucket(g, t));
   }
   if (a->bucket_events[2]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[2], s));
   return 0;
@@ -558,9 +554,28 @@ int mmdeer_gemm(const mmdeer_gemm_args* a) {
   p.drop_site = a->drop_site; p.drop_shift = a->drop_shift; p.regen_site = a->regen_site;
   p.mask_scale = a->mask_scale;
   MMDEER_CHECK(a->A && a->W && a->C, "gemm: A / W / C must be non-NULL");
+  if (a->splitk > 1) {
+    MMDEER_CHECK(a->slab != nullptr, "gemm: split-K needs a slab buffer of splitk * (M*N + M) floats");
+    p.splitk = a->splitk;
+    p.slab_stride = ((long long)a->M * a->N + a->M + 3) / 4 * 4;
+    p.slab_c = a->slab;
+    p.slab_b = a->slab + (long long)a->M * a->N;
+  }
   g.drop = make_drop(a->dropout_p, a->seed, a->offset);
   GemmTile t = (a->tile >= 0 && a->tile <= 2) ? (GemmTile)a->tile : pick_tile(g);
-  return launch_gemm_group(g, a->compute_f32 ? 1 : 0, t, (hipStream_t)a->stream);
+  TRY(launch_gemm_group(g, a->compute_f32 ? 1 : 0, t, (hipStream_t)a->stream));
+  if (g.p[0].splitk > 1) {   // fold the K-slices into C (and bias_grad)
+    ReduceTable rt{};
+    rt.nseg = 1;
+    rt.src[0] = p.slab_c; rt.dst[0] = reinterpret_cast<float*>(p.C); rt.nparts[0] = g.p[0].splitk;
+    rt.n[0] = a->M * a->N; rt.stride[0] = p.slab_stride;
+    if (p.bias_grad) {
+      rt.nseg = 2;
+      rt.src[1] = p.slab_b; rt.dst[1] = p.bias_grad; rt.nparts[1] = g.p[0].splitk; rt.n[1] = a->M; rt.stride[1] = p.slab_stride;
+    }
+    TRY(launch_reduce_partials(rt, (hipStream_t)a->stream));
+  }
+  return 0;
 }
 
 int mmdeer_layernorm_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,

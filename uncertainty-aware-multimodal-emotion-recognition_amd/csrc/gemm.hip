@@ -11,11 +11,17 @@
 //    multiplied.  Register staging (rather than LDS-DMA) is what lets the loader (a) convert fp32 sources to
 //    bf16 on the fly, (b) zero-fill ragged M / K=84 tails and (c) transpose 4xEPC blocks for operands whose
 //    reduction index is the slow one (dX = dY*W, dW = dY^T*X), so no transposed copy ever exists in HBM.
+//  * Every global load is unconditional (out-of-range pieces read a safe address and are zeroed by a select):
+//    a load under a per-lane branch makes hipcc end the branch with s_waitcnt vmcnt(0), which serialised the
+//    4-8 loads of a K-step (~3500 cycles per step before the change).
 //  * Epilogue: accumulators -> fp32 LDS staging -> one thread per 4 consecutive columns applies
 //    bias / ReLU / counter-based dropout / (Y>0) mask and issues coalesced 8- or 16-byte stores.
 //  * dW problems also emit the bias gradient: the waves of column-block 0 sum the dY^T fragments they already
-//    hold, so db costs no extra pass over dY and is deterministic (no atomics).
+//    hold, so db costs no extra pass over dY and is deterministic (no atomics).  Long reductions with few
+//    output tiles are split over K into slabs (see gemm.h).
 #include "gemm.h"
+
+#include <cstdlib>
 
 namespace mmdeer {
 
@@ -23,7 +29,7 @@ namespace {
 
 constexpr int LDS_ROW = 144;  // bytes: 128 B of K + 16 B pad
 
-// Native clang vectors (not HIP's u32x4/float4 union structs): they stay SSA values, so the register tiles
+// Native clang vectors (not HIP's uint4/float4 union structs): they stay SSA values, so the register tiles
 // below are never materialised in scratch or promoted to LDS.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -31,44 +37,29 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x4 zero4() { return u32x4{0u, 0u, 0u, 0u}; }
 
 // Load one 16-byte compute chunk (EPC elements of CT) from a source of element type ST.
-// `valid` = number of in-range elements (0, 4 or 8; callers guarantee multiples of 4).
-template <typename CT, typename ST>
-__device__ __forceinline__ u32x4 load_chunk(const ST* p, int valid, bool vec16);
-
-template <>
-__device__ __forceinline__ u32x4 load_chunk<float, float>(const float* p, int valid, bool) {
-  if (valid >= 4) return *reinterpret_cast<const u32x4*>(p);
-  return zero4();
-}
-template <>
-__device__ __forceinline__ u32x4 load_chunk<bf16_t, bf16_t>(const bf16_t* p, int valid, bool vec16) {
-  u32x4 r = zero4();
-  if (valid >= 8) {
-    if (vec16) {
-      r = *reinterpret_cast<const u32x4*>(p);
-    } else {
-      u32x2 a = *reinterpret_cast<const u32x2*>(p);
-      u32x2 b = *reinterpret_cast<const u32x2*>(p + 4);
-      r = u32x4{a.x, a.y, b.x, b.y};
-    }
-  } else if (valid >= 4) {
-    u32x2 a = *reinterpret_cast<const u32x2*>(p);
-    r.x = a.x; r.y = a.y;
+// `valid` = number of in-range elements (0, 4 or 8; callers guarantee multiples of 4).  An out-of-range piece
+// reads `safe` (an in-bounds, 16-byte-aligned address of the same operand) instead: every load is unconditional
+// and NOTHING is computed on the loaded registers here, so the compiler can leave all loads of a K-tile in
+// flight across the MFMAs of the previous tile and wait only at the LDS store.  (A load under a per-lane branch,
+// or a select/AND on its result, made hipcc wait for each load right where it was issued: ~3500 cycles/K-step.)
+// Garbage read through `safe` is harmless for rows beyond M / N (those outputs are never stored); the K tail is
+// zeroed by tile_lstore.  Only the fp32 -> bf16 source path converts at load time.
+template <typename CT, typename ST, bool VEC16>
+__device__ __forceinline__ u32x4 load_chunk(const ST* p, const ST* safe, int valid) {
+  const bool ok0 = valid >= 4, ok1 = valid >= 8;
+  if constexpr (sizeof(CT) == 4) {   // fp32 compute, fp32 source: one 16-byte load
+    return *reinterpret_cast<const u32x4*>(ok0 ? p : safe);
+  } else if constexpr (sizeof(ST) == 4) {   // bf16 compute, fp32 source: two 16-byte loads, RNE convert
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ok0 ? p : safe);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(ok1 ? p + 4 : safe);
+    return u32x4{pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w)};
+  } else if constexpr (VEC16) {   // bf16 source, 16-byte aligned rows, extent % 8 == 0: valid is 0 or 8
+    return *reinterpret_cast<const u32x4*>(ok1 ? p : safe);
+  } else {   // bf16 source with 8-byte aligned rows (K = 84): two 8-byte loads
+    const u32x2 a = *reinterpret_cast<const u32x2*>(ok0 ? p : safe);
+    const u32x2 b = *reinterpret_cast<const u32x2*>(ok1 ? p + 4 : safe);
+    return u32x4{a.x, a.y, b.x, b.y};
   }
-  return r;
-}
-template <>
-__device__ __forceinline__ u32x4 load_chunk<bf16_t, float>(const float* p, int valid, bool) {
-  u32x4 r = zero4();
-  if (valid >= 4) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(p);
-    r.x = pack_bf2(a.x, a.y); r.y = pack_bf2(a.z, a.w);
-  }
-  if (valid >= 8) {
-    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
-    r.z = pack_bf2(b.x, b.y); r.w = pack_bf2(b.z, b.w);
-  }
-  return r;
 }
 
 // Register tile of one operand: four named 16-byte registers (named, not an indexed array: a loop-indexed
@@ -78,49 +69,82 @@ struct RTile { u32x4 r0, r1, r2, r3; };
 __device__ __forceinline__ unsigned word_of(const u32x4& v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
+__device__ __forceinline__ u32x4 and4(const u32x4& v, unsigned m) { return u32x4{v.x & m, v.y & m, v.z & m, v.w & m}; }
 
-// ---- global -> registers for one operand tile of ROWS rows x (128 B of K)
-template <typename CT, typename ST, int ROWS>
-__device__ __forceinline__ RTile tile_gload(const ST* base, long long ld, int rows_valid, int k0, int K,
-                                            bool trans, bool vec16, int tid) {
+// ---- global -> registers for one operand tile of ROWS rows x (128 B of K); straight-line, no branches
+template <typename CT, typename ST, int ROWS, bool TRANS, bool VEC16>
+__device__ __forceinline__ RTile tile_gload(const ST* base, const ST* safe, long long ld, int rows_valid, int k0, int K, int tid) {
   constexpr int EPC = Elem<CT>::EPC, KT = Elem<CT>::KT;
   RTile t;
   t.r0 = t.r1 = t.r2 = t.r3 = zero4();
-  if (!trans) {
+  if constexpr (!TRANS) {
     // operand stored [row][k]: 8 lanes cover one 128-byte row segment (full cache line per row)
     const int kc = tid & 7, ke = k0 + kc * EPC, rem = K - ke;
     const int kvalid = rem >= EPC ? EPC : (rem > 0 ? rem : 0);
     const int row = tid >> 3;
     const ST* p = base + (long long)row * ld + ke;
-    t.r0 = load_chunk<CT, ST>(p, row < rows_valid ? kvalid : 0, vec16);
-    if constexpr (ROWS >= 64) t.r1 = load_chunk<CT, ST>(p + 32 * ld, row + 32 < rows_valid ? kvalid : 0, vec16);
+    t.r0 = load_chunk<CT, ST, VEC16>(p, safe, row < rows_valid ? kvalid : 0);
+    if constexpr (ROWS >= 64) t.r1 = load_chunk<CT, ST, VEC16>(p + 32 * ld, safe, row + 32 < rows_valid ? kvalid : 0);
     if constexpr (ROWS >= 128) {
-      t.r2 = load_chunk<CT, ST>(p + 64 * ld, row + 64 < rows_valid ? kvalid : 0, vec16);
-      t.r3 = load_chunk<CT, ST>(p + 96 * ld, row + 96 < rows_valid ? kvalid : 0, vec16);
+      t.r2 = load_chunk<CT, ST, VEC16>(p + 64 * ld, safe, row + 64 < rows_valid ? kvalid : 0);
+      t.r3 = load_chunk<CT, ST, VEC16>(p + 96 * ld, safe, row + 96 < rows_valid ? kvalid : 0);
     }
   } else {
     // operand stored [k][row]: each thread takes 4 consecutive k x EPC consecutive rows
+    // (threads beyond UNITS still issue clamped loads: their registers are never stored to LDS)
     constexpr int QN = KT / 4, UNITS = QN * (ROWS / EPC);
-    if (tid < UNITS) {
-      const int q = tid % QN, c0 = (tid / QN) * EPC;
-      const int rem = rows_valid - c0;
-      const int cvalid = rem >= EPC ? EPC : (rem > 0 ? rem : 0);
-      const int k = k0 + 4 * q;
-      const ST* p = base + (long long)k * ld + c0;
-      t.r0 = load_chunk<CT, ST>(p, (k < K) ? cvalid : 0, vec16);
-      t.r1 = load_chunk<CT, ST>(p + ld, (k + 1 < K) ? cvalid : 0, vec16);
-      t.r2 = load_chunk<CT, ST>(p + 2 * ld, (k + 2 < K) ? cvalid : 0, vec16);
-      t.r3 = load_chunk<CT, ST>(p + 3 * ld, (k + 3 < K) ? cvalid : 0, vec16);
-    }
+    const int q = tid % QN, c0 = (tid / QN) * EPC;
+    const int rem = (tid < UNITS) ? rows_valid - c0 : 0;
+    const int cvalid = rem >= EPC ? EPC : (rem > 0 ? rem : 0);
+    const int k = k0 + 4 * q;
+    const ST* p = base + (long long)k * ld + c0;
+    t.r0 = load_chunk<CT, ST, VEC16>(p, safe, (k < K) ? cvalid : 0);
+    t.r1 = load_chunk<CT, ST, VEC16>(p + ld, safe, (k + 1 < K) ? cvalid : 0);
+    t.r2 = load_chunk<CT, ST, VEC16>(p + 2 * ld, safe, (k + 2 < K) ? cvalid : 0);
+    t.r3 = load_chunk<CT, ST, VEC16>(p + 3 * ld, safe, (k + 3 < K) ? cvalid : 0);
   }
   return t;
 }
 
-// ---- registers -> LDS tile ([row][k], LDS_ROW bytes per row)
-template <typename CT, int ROWS>
-__device__ __forceinline__ void tile_lstore(unsigned char* t, const RTile& v, bool trans, int tid) {
+// Zero the part of a register tile that lies beyond K (only called for a partial last K-tile).
+template <typename CT, bool TRANS>
+__device__ __forceinline__ RTile tile_ktail_mask(RTile t, int k0, int K, int tid) {
   constexpr int EPC = Elem<CT>::EPC, KT = Elem<CT>::KT;
-  if (!trans) {
+  if constexpr (!TRANS) {
+    const int rem = K - (k0 + (tid & 7) * EPC);   // in-range elements of this lane's chunk (same for r0..r3)
+    const unsigned mlo = rem >= EPC / 2 ? 0xFFFFFFFFu : 0u, mhi = rem >= EPC ? 0xFFFFFFFFu : 0u;
+    // fp32: the chunk is 4 elements, valid is 0 or 4 -> mlo == mhi would need rem >= 4; EPC/2 = 2 < 4 is still exact
+    // because rem is a multiple of 4.  bf16: low 8 bytes = elements 0-3, high 8 bytes = elements 4-7.
+    auto m = [&](const u32x4& v) { return u32x4{v.x & mlo, v.y & mlo, v.z & mhi, v.w & mhi}; };
+    t.r0 = m(t.r0); t.r1 = m(t.r1); t.r2 = m(t.r2); t.r3 = m(t.r3);
+  } else {
+    const int k = k0 + 4 * (tid % (KT / 4));
+    t.r0 = and4(t.r0, k < K ? 0xFFFFFFFFu : 0u);
+    t.r1 = and4(t.r1, k + 1 < K ? 0xFFFFFFFFu : 0u);
+    t.r2 = and4(t.r2, k + 2 < K ? 0xFFFFFFFFu : 0u);
+    t.r3 = and4(t.r3, k + 3 < K ? 0xFFFFFFFFu : 0u);
+  }
+  return t;
+}
+
+// operand tile load for a COMPILE-TIME source mode (the mode switch lives outside the K loop: a wave-uniform
+// switch inside the loop made hipcc open every arm with s_waitcnt vmcnt(0), serialising the A and B loads)
+template <typename CT, int ROWS, bool TRANS, int MODE>
+__device__ __forceinline__ RTile tile_gload_m(const void* opnd, long long off, long long ld, int rows_valid, int k0, int K, int tid) {
+  if constexpr (sizeof(CT) == 4 || MODE == SRC_F32) {
+    const float* b = reinterpret_cast<const float*>(opnd);
+    return tile_gload<CT, float, ROWS, TRANS, true>(b + off, b, ld, rows_valid, k0, K, tid);
+  } else {
+    const bf16_t* b = reinterpret_cast<const bf16_t*>(opnd);
+    return tile_gload<CT, bf16_t, ROWS, TRANS, MODE == SRC_BF16_V16>(b + off, b, ld, rows_valid, k0, K, tid);
+  }
+}
+
+// ---- registers -> LDS tile ([row][k], LDS_ROW bytes per row)
+template <typename CT, int ROWS, bool TRANS>
+__device__ __forceinline__ void tile_lstore(unsigned char* t, const RTile& v, int tid) {
+  constexpr int EPC = Elem<CT>::EPC, KT = Elem<CT>::KT;
+  if constexpr (!TRANS) {
     unsigned char* d = t + (tid >> 3) * LDS_ROW + (tid & 7) * 16;
     *reinterpret_cast<u32x4*>(d) = v.r0;
     if constexpr (ROWS >= 64) *reinterpret_cast<u32x4*>(d + 32 * LDS_ROW) = v.r1;
@@ -183,13 +207,79 @@ __device__ __forceinline__ float chunk_sum(const u32x4& a) {
   }
 }
 
+struct KArgs {
+  const void* A;
+  const void* B;
+  long long a_off, b_off, lda, ldb;
+  int a_rows, b_rows, K, kt0, kt1;
+  bool do_bsum;
+};
+
+// The K loop of one workgroup for compile-time source modes.  Per K-tile: issue the global loads of tile t+1
+// (8 independent 16-byte loads per thread at 128x128), multiply tile t out of LDS, then -- and only then --
+// wait for the loads and store them to the other LDS buffer; one barrier per K-tile.
+template <typename CT, int BM, int BN, bool TA, bool TB, int AM, int BMODE, int TM, int TN>
+__device__ __forceinline__ void k_loop(const KArgs& ka, unsigned char* lds, f32x4 (&acc)[TM][TN], float (&bsum)[TM]) {
+  constexpr int KT = Elem<CT>::KT;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int A_BYTES = BM * LDS_ROW, B_BYTES = BN * LDS_ROW, STAGE = A_BYTES + B_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const int K = ka.K;
+  RTile ra, rb;
+  auto gload = [&](int k0) __attribute__((always_inline)) {
+    ra = tile_gload_m<CT, BM, TA, AM>(ka.A, ka.a_off, ka.lda, ka.a_rows, k0, K, tid);
+    rb = tile_gload_m<CT, BN, TB, BMODE>(ka.B, ka.b_off, ka.ldb, ka.b_rows, k0, K, tid);
+  };
+  auto lstore = [&](int buf, int k0) __attribute__((always_inline)) {
+    if (k0 + KT > K) {   // partial last K-tile (K = 84, ragged batch as reduction dim): zero the tail
+      ra = tile_ktail_mask<CT, TA>(ra, k0, K, tid);
+      rb = tile_ktail_mask<CT, TB>(rb, k0, K, tid);
+    }
+    tile_lstore<CT, BM, TA>(lds + buf * STAGE, ra, tid);
+    tile_lstore<CT, BN, TB>(lds + buf * STAGE + A_BYTES, rb, tid);
+  };
+  const int kt0 = ka.kt0, kt1 = ka.kt1;
+  if (kt0 < kt1) {
+    gload(kt0 * KT);
+    lstore(0, kt0 * KT);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) gload((kt + 1) * KT);
+    const unsigned char* la = lds + cur * STAGE + (wm * WTM + li) * LDS_ROW + lg * 16;
+    const unsigned char* lb = lds + cur * STAGE + A_BYTES + (wn * WTN + li) * LDS_ROW + lg * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(la + i * 16 * LDS_ROW + s * 64);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(lb + j * 16 * LDS_ROW + s * 64);
+      if (ka.do_bsum) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) bsum[i] += chunk_sum<CT>(fa[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<CT>(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) lstore(cur ^ 1, (kt + 1) * KT);
+    __syncthreads();
+  }
+}
+
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // second launch-bound argument = waves per SIMD the register allocator must leave room for:
 // 64x64 tiles run 3 workgroups per CU (LDS 36 KiB each), the larger tiles 2.
-template <typename CT, int BM, int BN>
+template <typename CT, int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 3 : 2) void gemm_group_kernel(const GemmGroup g) {
-  constexpr int EPC = Elem<CT>::EPC, KT = Elem<CT>::KT;
+  constexpr int KT = Elem<CT>::KT;
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
   constexpr int A_BYTES = BM * LDS_ROW, B_BYTES = BN * LDS_ROW, STAGE = A_BYTES + B_BYTES;
   constexpr int SPAD = BN + 4;  // fp32 staging row stride (elements)
@@ -200,8 +290,14 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 3 : 2) void gemm_group_
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
 
-  // ---- which problem / tile is this workgroup
-  const int bid = blockIdx.x;
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group).  Renumber so each
+  // group owns a contiguous range of tiles: neighbouring tiles share an A row-panel, so the panel is fetched
+  // into ONE XCD's L2 instead of all eight (speed only -- any placement is correct).
+  int bid = blockIdx.x;
+  if (g.xcd_remap) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
@@ -214,37 +310,24 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 3 : 2) void gemm_group_
       *(const __attribute__((address_space(4))) GemmProblem*)(
           kbase + __builtin_offsetof(GemmGroup, p) + (size_t)pi * sizeof(GemmProblem));
   const int local = bid - g.tile_start[pi];
-  const int per_batch = p.tiles_m * p.tiles_n;
+  const int per_slice = p.tiles_m * p.tiles_n;
+  const int per_batch = per_slice * p.splitk;
   const int z = local / per_batch;
-  const int rem = local - z * per_batch;
+  const int rem_b = local - z * per_batch;
+  const int slice = rem_b / per_slice;
+  const int rem = rem_b - slice * per_slice;
   const int tmb = rem / p.tiles_n, tnb = rem - tmb * p.tiles_n;
   const int row0 = tmb * BM, col0 = tnb * BN;
   const int M = p.M, N = p.N, K = p.K;
-  const bool ta = p.trans_a, tb = p.trans_b;
-  const bool af32 = (sizeof(CT) == 4) || p.a_f32, bf32 = (sizeof(CT) == 4) || p.b_f32;
 
   // element offsets of this tile's first operand row (k = 0)
-  const long long a_off = (long long)z * p.sA + (ta ? (long long)row0 : (long long)row0 * p.lda);
-  const long long b_off = (long long)z * p.sB + (tb ? (long long)col0 : (long long)col0 * p.ldb);
+  const long long a_off = (long long)z * p.sA + (TA ? (long long)row0 : (long long)row0 * p.lda);
+  const long long b_off = (long long)z * p.sB + (TB ? (long long)col0 : (long long)col0 * p.ldb);
   const int a_rows = M - row0, b_rows = N - col0;
-
-  RTile ra, rb;
   const long long lda = p.lda, ldb = p.ldb;
-  const bool av16 = p.a_vec16, bv16 = p.b_vec16;
+  const int amode = p.a_mode, bmode = p.b_mode;
   const void* Ap = p.A;
   const void* Bp = p.B;
-  auto gload = [&](int k0) __attribute__((always_inline)) {
-    if (af32) ra = tile_gload<CT, float, BM>(reinterpret_cast<const float*>(Ap) + a_off, lda, a_rows, k0, K, ta, true, tid);
-    else if constexpr (sizeof(CT) == 2)
-      ra = tile_gload<CT, bf16_t, BM>(reinterpret_cast<const bf16_t*>(Ap) + a_off, lda, a_rows, k0, K, ta, av16, tid);
-    if (bf32) rb = tile_gload<CT, float, BN>(reinterpret_cast<const float*>(Bp) + b_off, ldb, b_rows, k0, K, tb, true, tid);
-    else if constexpr (sizeof(CT) == 2)
-      rb = tile_gload<CT, bf16_t, BN>(reinterpret_cast<const bf16_t*>(Bp) + b_off, ldb, b_rows, k0, K, tb, bv16, tid);
-  };
-  auto lstore = [&](int buf) __attribute__((always_inline)) {
-    tile_lstore<CT, BM>(lds + buf * STAGE, ra, ta, tid);
-    tile_lstore<CT, BN>(lds + buf * STAGE + A_BYTES, rb, tb, tid);
-  };
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -256,44 +339,41 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 3 : 2) void gemm_group_
   for (int i = 0; i < TM; ++i) bsum[i] = 0.f;
   const bool do_bsum = (p.bias_grad != nullptr) && (tnb == 0) && (wn == 0);
 
-  const int nk = (K + KT - 1) / KT;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * KT);
-    const unsigned char* la = lds + cur * STAGE + (wm * WTM + li) * LDS_ROW + lg * 16;
-    const unsigned char* lb = lds + cur * STAGE + A_BYTES + (wn * WTN + li) * LDS_ROW + lg * 16;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(la + i * 16 * LDS_ROW + s * 64);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(lb + j * 16 * LDS_ROW + s * 64);
-      if (do_bsum) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) bsum[i] += chunk_sum<CT>(fa[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<CT>(fa[i], fb[j], acc[i][j]);
+  // K-tile range of this slice
+  const int nk_all = (K + KT - 1) / KT;
+  const int nk_per = (nk_all + p.splitk - 1) / p.splitk;
+  const int kt0 = slice * nk_per;
+  const int kt1 = (kt0 + nk_per < nk_all) ? kt0 + nk_per : nk_all;
+
+  KArgs ka{Ap, Bp, a_off, b_off, lda, ldb, a_rows, b_rows, K, kt0, kt1, do_bsum};
+  if constexpr (sizeof(CT) == 4) {
+    k_loop<CT, BM, BN, TA, TB, SRC_F32, SRC_F32>(ka, lds, acc, bsum);
+  } else {
+    // nine loop instances, one per (A source, B source) pair; the pair is wave-uniform
+    switch (amode * 3 + bmode) {
+      case SRC_F32 * 3 + SRC_F32: k_loop<CT, BM, BN, TA, TB, SRC_F32, SRC_F32>(ka, lds, acc, bsum); break;
+      case SRC_F32 * 3 + SRC_BF16_V16: k_loop<CT, BM, BN, TA, TB, SRC_F32, SRC_BF16_V16>(ka, lds, acc, bsum); break;
+      case SRC_F32 * 3 + SRC_BF16_V8: k_loop<CT, BM, BN, TA, TB, SRC_F32, SRC_BF16_V8>(ka, lds, acc, bsum); break;
+      case SRC_BF16_V16 * 3 + SRC_F32: k_loop<CT, BM, BN, TA, TB, SRC_BF16_V16, SRC_F32>(ka, lds, acc, bsum); break;
+      case SRC_BF16_V16 * 3 + SRC_BF16_V16: k_loop<CT, BM, BN, TA, TB, SRC_BF16_V16, SRC_BF16_V16>(ka, lds, acc, bsum); break;
+      case SRC_BF16_V16 * 3 + SRC_BF16_V8: k_loop<CT, BM, BN, TA, TB, SRC_BF16_V16, SRC_BF16_V8>(ka, lds, acc, bsum); break;
+      case SRC_BF16_V8 * 3 + SRC_F32: k_loop<CT, BM, BN, TA, TB, SRC_BF16_V8, SRC_F32>(ka, lds, acc, bsum); break;
+      case SRC_BF16_V8 * 3 + SRC_BF16_V16: k_loop<CT, BM, BN, TA, TB, SRC_BF16_V8, SRC_BF16_V16>(ka, lds, acc, bsum); break;
+      default: k_loop<CT, BM, BN, TA, TB, SRC_BF16_V8, SRC_BF16_V8>(ka, lds, acc, bsum); break;
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
-    __syncthreads();
   }
 
-  // ---- bias gradient (dW problems): row sums of op(A) over the whole reduction
+  const bool sliced = p.splitk > 1;
+  // ---- bias gradient (dW problems): row sums of op(A) over this slice of the reduction
   if (do_bsum) {
+    float* bg = sliced ? p.slab_b + (long long)slice * p.slab_stride : p.bias_grad;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float v = bsum[i];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       int r = row0 + wm * WTM + i * 16 + li;
-      if (lg == 0 && r < M) p.bias_grad[(long long)z * p.sBiasGrad + r] = v;
+      if (lg == 0 && r < M) bg[(long long)z * p.sBiasGrad + r] = v;
     }
   }
 
@@ -311,6 +391,17 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 3 : 2) void gemm_group_
   // ---- phase 2: one thread per 4 consecutive columns
   const DropCtx dc = g.drop;
   const long long c_base = (long long)z * p.sC;
+  if (sliced) {
+    float* cs = p.slab_c + (long long)slice * p.slab_stride + c_base;
+#pragma unroll 2
+    for (int c = tid; c < BM * BN / 4; c += 256) {
+      const int row = c / (BN / 4), cc = c - row * (BN / 4);
+      const int gr = row0 + row, gc = col0 + cc * 4;
+      if (gr >= M || gc >= N) continue;
+      *reinterpret_cast<f32x4*>(cs + (long long)gr * p.ldc + gc) = *reinterpret_cast<const f32x4*>(S + row * SPAD + cc * 4);
+    }
+    return;
+  }
 #pragma unroll 2
   for (int c = tid; c < BM * BN / 4; c += 256) {
     const int row = c / (BN / 4), cc = c - row * (BN / 4);
@@ -368,10 +459,22 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 3 : 2) void gemm_group_
 }
 
 template <typename CT, int BM, int BN>
-int launch_t(const GemmGroup& g, int total, hipStream_t stream) {
-  hipLaunchKernelGGL((gemm_group_kernel<CT, BM, BN>), dim3(total), dim3(256), 0, stream, g);
+int launch_tt(const GemmGroup& g, int total, int ta, int tb, hipStream_t stream) {
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_group_kernel<CT, BM, BN, false, false>), dim3(total), dim3(256), 0, stream, g);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_group_kernel<CT, BM, BN, false, true>), dim3(total), dim3(256), 0, stream, g);
+  else if (ta && tb) hipLaunchKernelGGL((gemm_group_kernel<CT, BM, BN, true, true>), dim3(total), dim3(256), 0, stream, g);
+  else {
+    set_error("gemm: (trans_a=1, trans_b=0) is not instantiated");
+    return -1;
+  }
   MMDEER_HIP(hipGetLastError());
   return 0;
+}
+
+int env_xcd() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_XCD"); v = e ? atoi(e) : 1; }
+  return v;
 }
 
 }  // namespace
@@ -379,51 +482,71 @@ int launch_t(const GemmGroup& g, int total, hipStream_t stream) {
 void gemm_problem_defaults(GemmProblem& p) {
   p = GemmProblem{};
   p.batch = 1;
+  p.splitk = 1;
   p.drop_site = -1;
   p.regen_site = -1;
   p.mask_scale = 1.f;
-  p.a_vec16 = p.b_vec16 = 1;
 }
 
 int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t stream) {
   static const int bm_of[3] = {64, 128, 128}, bn_of[3] = {64, 64, 128};
   MMDEER_CHECK(g.nprob >= 1 && g.nprob <= GEMM_MAX_PROBLEMS, "gemm: bad problem count %d", g.nprob);
+  g.xcd_remap = env_xcd();
   const int BM = bm_of[tile], BN = bn_of[tile];
+  const int ta = g.p[0].trans_a ? 1 : 0, tb = g.p[0].trans_b ? 1 : 0;
   int total = 0;
   for (int i = 0; i < g.nprob; ++i) {
     GemmProblem& p = g.p[i];
+    MMDEER_CHECK((p.trans_a ? 1 : 0) == ta && (p.trans_b ? 1 : 0) == tb, "gemm[%d]: all problems of a launch must share trans flags", i);
     MMDEER_CHECK(p.M >= 0 && p.N > 0 && p.K > 0 && p.batch >= 1, "gemm[%d]: bad shape M=%d N=%d K=%d", i, p.M, p.N, p.K);
+    MMDEER_CHECK(p.A && p.B && p.C, "gemm[%d]: A / B / C must be non-NULL", i);
     MMDEER_CHECK(p.N % 4 == 0, "gemm[%d]: N=%d must be a multiple of 4", i, p.N);
     MMDEER_CHECK(p.trans_a || p.K % 4 == 0, "gemm[%d]: K=%d must be a multiple of 4 for a k-contiguous A", i, p.K);
     MMDEER_CHECK(p.trans_b || p.K % 4 == 0, "gemm[%d]: K=%d must be a multiple of 4 for a k-contiguous B", i, p.K);
     MMDEER_CHECK(!p.trans_a || p.M % 4 == 0, "gemm[%d]: M=%d must be a multiple of 4 for a transposed A", i, p.M);
     MMDEER_CHECK(p.lda % 4 == 0 && p.ldb % 4 == 0 && p.ldc % 4 == 0, "gemm[%d]: leading dims must be multiples of 4", i);
+    MMDEER_CHECK(((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.B % 16 == 0) && ((uintptr_t)p.C % 8 == 0),
+                 "gemm[%d]: A and B must be 16-byte aligned, C 8-byte aligned", i);
+    MMDEER_CHECK(p.M == 0 || ((long long)p.lda * (p.trans_a ? p.K : p.M) >= 8 && (long long)p.ldb * (p.trans_b ? p.K : p.N) >= 8),
+                 "gemm[%d]: operands must hold at least 8 elements", i);
     MMDEER_CHECK(!p.Y || p.ldy % 4 == 0, "gemm[%d]: ldy must be a multiple of 4", i);
     MMDEER_CHECK(!(p.accumulate && !p.c_f32), "gemm[%d]: accumulate needs an fp32 C", i);
-    if (!compute_f32) {
-      p.a_vec16 = (!p.a_f32 && p.lda % 8 == 0 && ((uintptr_t)p.A % 16 == 0) && (p.sA % 8 == 0)) ? 1 : 0;
-      p.b_vec16 = (!p.b_f32 && p.ldb % 8 == 0 && ((uintptr_t)p.B % 16 == 0) && (p.sB % 8 == 0)) ? 1 : 0;
-    } else {
+    if (p.splitk < 1) p.splitk = 1;
+    if (p.splitk > 1) {
+      MMDEER_CHECK(p.slab_c && p.c_f32 && !p.bias && !p.relu && !p.Y && !p.accumulate && p.drop_site < 0 && p.regen_site < 0,
+                   "gemm[%d]: split-K needs an fp32 slab and no epilogue", i);
+      MMDEER_CHECK(!p.bias_grad || p.slab_b, "gemm[%d]: split-K with bias_grad needs slab_b", i);
+      const int nk = gemm_ktiles(p.K, compute_f32);
+      if (p.splitk > nk) p.splitk = nk;
+    }
+    if (compute_f32) {
       MMDEER_CHECK(p.a_f32 && p.b_f32, "gemm[%d]: fp32 compute needs fp32 operands", i);
+      p.a_mode = p.b_mode = SRC_F32;
+    } else {
+      // 16-byte loads of a bf16 source need 16-byte aligned rows AND no half-valid chunk (extent multiple of 8)
+      const bool av16 = p.lda % 8 == 0 && p.sA % 8 == 0 && (p.trans_a ? p.M : p.K) % 8 == 0;
+      const bool bv16 = p.ldb % 8 == 0 && p.sB % 8 == 0 && (p.trans_b ? p.N : p.K) % 8 == 0;
+      p.a_mode = p.a_f32 ? SRC_F32 : (av16 ? SRC_BF16_V16 : SRC_BF16_V8);
+      p.b_mode = p.b_f32 ? SRC_F32 : (bv16 ? SRC_BF16_V16 : SRC_BF16_V8);
     }
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     g.tile_start[i] = total;
-    total += p.tiles_m * p.tiles_n * p.batch;
+    total += p.tiles_m * p.tiles_n * p.batch * p.splitk;
   }
   for (int i = g.nprob; i <= GEMM_MAX_PROBLEMS; ++i) g.tile_start[i] = total;
   if (total == 0) return 0;  // empty batch: nothing to do
   if (compute_f32) {
     switch (tile) {
-      case TILE_64x64: return launch_t<float, 64, 64>(g, total, stream);
-      case TILE_128x64: return launch_t<float, 128, 64>(g, total, stream);
-      default: return launch_t<float, 128, 128>(g, total, stream);
+      case TILE_64x64: return launch_tt<float, 64, 64>(g, total, ta, tb, stream);
+      case TILE_128x64: return launch_tt<float, 128, 64>(g, total, ta, tb, stream);
+      default: return launch_tt<float, 128, 128>(g, total, ta, tb, stream);
     }
   }
   switch (tile) {
-    case TILE_64x64: return launch_t<bf16_t, 64, 64>(g, total, stream);
-    case TILE_128x64: return launch_t<bf16_t, 128, 64>(g, total, stream);
-    default: return launch_t<bf16_t, 128, 128>(g, total, stream);
+    case TILE_64x64: return launch_tt<bf16_t, 64, 64>(g, total, ta, tb, stream);
+    case TILE_128x64: return launch_tt<bf16_t, 128, 64>(g, total, ta, tb, stream);
+    default: return launch_tt<bf16_t, 128, 128>(g, total, ta, tb, stream);
   }
 }
 

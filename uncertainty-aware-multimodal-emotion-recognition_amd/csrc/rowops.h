@@ -30,16 +30,18 @@ int ln_bwd_nparts(int M);
 int launch_ln_bwd(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
                   void* dz, float* partial, int M, int N, int act_f32, float mask_scale, hipStream_t s);
 
-constexpr int REDUCE_MAX_SEGMENTS = 8;
+constexpr int REDUCE_MAX_SEGMENTS = 16;
 struct ReduceTable {
   int nseg;
   const float* src[REDUCE_MAX_SEGMENTS];  // part p of element j at src[p * stride + j]
   float* dst[REDUCE_MAX_SEGMENTS];        // [n]
   int nparts[REDUCE_MAX_SEGMENTS];
-  int n[REDUCE_MAX_SEGMENTS];
-  int stride[REDUCE_MAX_SEGMENTS];
-  int start[REDUCE_MAX_SEGMENTS + 1];     // prefix of n
+  int n[REDUCE_MAX_SEGMENTS];             // multiple of 4
+  long long stride[REDUCE_MAX_SEGMENTS];
+  int bstart[REDUCE_MAX_SEGMENTS + 1];    // filled by the launcher: first block of each segment (256 elements per block)
 };
+// dst[j] = sum_p src[p*stride + j] in a fixed order (deterministic): folds LayerNorm / head partial slabs and
+// split-K weight-gradient slabs into the flat gradient buffer.
 int launch_reduce_partials(ReduceTable& t, hipStream_t s);
 
 // keep-mask dump for the test harness: out[r*cols + c] = keep(site, r, c) ? 1 : 0   (c already in site granularity)

@@ -167,19 +167,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dout, const voi
 }
 
 // ------------------------------------------------------------------ partial-sum reduction
+// One block = 256 consecutive output elements of one segment: 64 float4 columns x 4 part-lanes; each lane sums
+// parts pl, pl+4, ... (4 independent loads in flight), then the 4 lanes combine through LDS in a fixed order.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceTable t) {
+  __shared__ f32x4 red[4][64];
   const auto& T = karg<ReduceTable>();
-  const int total = T.start[T.nseg];
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    int sgm = 0;
+  const int b = blockIdx.x;
+  int sgm = 0;
 #pragma unroll
-    for (int i = 1; i < REDUCE_MAX_SEGMENTS; ++i)
-      if (i < T.nseg && e >= T.start[i]) sgm = i;
-    const int j = e - T.start[sgm], st = T.stride[sgm], np = T.nparts[sgm];
-    const float* src = (const float*)T.src[sgm];
-    float acc = 0.f;
-    for (int pidx = 0; pidx < np; ++pidx) acc += src[(long long)pidx * st + j];
-    ((float*)T.dst[sgm])[j] = acc;
+  for (int i = 1; i < REDUCE_MAX_SEGMENTS; ++i)
+    if (i < T.nseg && b >= T.bstart[i]) sgm = i;
+  const int n = T.n[sgm], np = T.nparts[sgm];
+  const long long st = T.stride[sgm];
+  const float* src = (const float*)T.src[sgm];
+  const int e = ((b - T.bstart[sgm]) * 64 + (threadIdx.x & 63)) * 4;
+  const int pl = threadIdx.x >> 6;
+  f32x4 acc{0.f, 0.f, 0.f, 0.f};
+  if (e < n) {
+    int p = pl;
+    for (; p + 12 < np; p += 16) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (long long)p * st + e);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (long long)(p + 4) * st + e);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (long long)(p + 8) * st + e);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(src + (long long)(p + 12) * st + e);
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; p < np; p += 4) acc += *reinterpret_cast<const f32x4*>(src + (long long)p * st + e);
+  }
+  red[pl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (pl == 0 && e < n) {
+    const int c = threadIdx.x;
+    *reinterpret_cast<f32x4*>((float*)T.dst[sgm] + e) = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
   }
 }
 
@@ -250,12 +269,16 @@ int launch_ln_bwd(const void* dout, const void* y, const float* mean, const floa
 }
 
 int launch_reduce_partials(ReduceTable& t, hipStream_t s) {
-  MMDEER_CHECK(t.nseg >= 1 && t.nseg <= REDUCE_MAX_SEGMENTS, "reduce: bad segment count %d", t.nseg);
-  int total = 0;
-  for (int i = 0; i < t.nseg; ++i) { t.start[i] = total; total += t.n[i]; }
-  for (int i = t.nseg; i <= REDUCE_MAX_SEGMENTS; ++i) t.start[i] = total;
-  if (total == 0) return 0;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(total)), dim3(256), 0, s, t);
+  MMDEER_CHECK(t.nseg >= 0 && t.nseg <= REDUCE_MAX_SEGMENTS, "reduce: bad segment count %d", t.nseg);
+  int blocks = 0;
+  for (int i = 0; i < t.nseg; ++i) {
+    MMDEER_CHECK(t.n[i] % 4 == 0 && t.nparts[i] >= 1 && t.stride[i] % 4 == 0, "reduce: segment %d: n and stride must be multiples of 4", i);
+    t.bstart[i] = blocks;
+    blocks += (t.n[i] + 255) / 256;
+  }
+  for (int i = t.nseg; i <= REDUCE_MAX_SEGMENTS; ++i) t.bstart[i] = blocks;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, t);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

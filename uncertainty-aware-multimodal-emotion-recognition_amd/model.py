@@ -212,6 +212,8 @@ class MultimodalDEER(nn.Module):
         self._st = _State()
         self._step = 0          # dropout counter offset: advanced once per training forward
         self._flat_grad: Optional[torch.Tensor] = None
+        self._step_flat: Optional[torch.Tensor] = None
+        self._step_views = None
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -299,7 +301,7 @@ class MultimodalDEER(nn.Module):
                 "trimodal_features": trif, "av_attention": avw, "trimodal_attention": triw}
 
     def _launch_backward(self, ctx_or_meta, targets, g_mu=None, g_nu=None, g_alpha=None, g_beta=None,
-                         loss_out=None, bin_counts=None, events=None):
+                         loss_out=None, bin_counts=None, events=None, flat=None):
         lib = _lib.load()
         if isinstance(ctx_or_meta, dict):
             meta = ctx_or_meta
@@ -310,7 +312,10 @@ class MultimodalDEER(nn.Module):
                                    "same model; call backward() before the next forward (one workspace per batch size)")
         B = meta["B"]
         dev = meta["ws"].device
-        flat = torch.empty(self._flat_elems, dtype=torch.float32, device=dev)
+        if flat is None:
+            # autograd path: a fresh buffer per backward so gradients handed to autograd never alias a later
+            # backward; zero-filled because the 64-element alignment gaps between tensors are never written
+            flat = torch.zeros(self._flat_elems, dtype=torch.float32, device=dev)
         a = _lib.BackwardArgs()
         a.batch, a.compute_f32, a.training, a.inputs_bf16 = B, self.compute_f32, meta["training"], meta["in_bf16"]
         a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), meta["offset"]
@@ -400,9 +405,18 @@ class MultimodalDEER(nn.Module):
         dev = meta["ws"].device
         loss_out = torch.empty(17, dtype=torch.float32, device=dev)
         bins = torch.empty(30, dtype=torch.int32, device=dev)
-        views = self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, events=events)
-        for p, g in zip(self._live, views):
-            p.grad = g
+        # the fused path owns ONE persistent flat gradient buffer per device (zeroed once: the alignment gaps stay 0);
+        # every step overwrites all live slices, and .grad of each live parameter is a view of it
+        if self._step_flat is None or self._step_flat.device != dev:
+            self._step_flat = torch.zeros(self._flat_elems, dtype=torch.float32, device=dev)
+            self._step_views = None
+        views = self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, events=events,
+                                      flat=self._step_flat)
+        if self._step_views is None:
+            self._step_views = views
+        for p, g in zip(self._live, self._step_views):
+            if p.grad is not g:
+                p.grad = g
         d = loss_dict_from(loss_out, meta["B"])
         d["ece_bin_counts"] = bins.view(3, 10)
         d["_outputs"] = o

@@ -43,10 +43,13 @@ def _splitmix64(x: np.ndarray) -> np.ndarray:
 
 
 def uniform01(stream: int, n: int, offset: int = 0) -> np.ndarray:
-    """n doubles in [0,1): element i of stream s = splitmix64(s * 2^40 + offset + i) >> 11."""
+    """n doubles in [0,1): element i of stream s = splitmix64(key(s) + offset + i) >> 11, where
+    key(s) = splitmix64(s * golden) is a full 64-bit mix of the (arbitrary non-negative) stream id."""
+    key = _splitmix64(np.array([(int(stream) * 0x9E3779B97F4A7C15 + 0x1234567) & 0xFFFFFFFFFFFFFFFF],
+                               dtype=np.uint64))[0]
     idx = np.arange(offset, offset + n, dtype=np.uint64)
-    base = np.uint64((int(stream) << 40) & 0xFFFFFFFFFFFFFFFF)
-    bits = _splitmix64(base + idx)
+    with np.errstate(over="ignore"):
+        bits = _splitmix64((idx + key) & _M64)
     return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
@@ -107,7 +110,7 @@ def closed_form_state(dims: Dims = DEFAULT_DIMS, variant: int = 0,
     sd: Dict[str, np.ndarray] = {}
     for name, shape, kind in table:
         n = int(np.prod(shape))
-        u = uniform01(_stream_of(name) + (variant << 30), n) * 2.0 - 1.0
+        u = uniform01(_stream_of(name) + (variant << 32), n) * 2.0 - 1.0
         if kind in (XAVIER, KAIMING):
             fan_in, fan_out = _fans(shape)
             w = u * math.sqrt(6.0 / (fan_in + fan_out))
@@ -134,7 +137,7 @@ def reference_init_state(dims: Dims = DEFAULT_DIMS, seed: int = 0,
     sd: Dict[str, np.ndarray] = {}
     for name, shape, kind in table:
         n = int(np.prod(shape))
-        u = uniform01(_stream_of(name) + ((seed + 7) << 30), n) * 2.0 - 1.0
+        u = uniform01(_stream_of(name) + ((seed + 7) << 32), n) * 2.0 - 1.0
         fan_in, fan_out = _fans(shape)
         if kind == XAVIER:
             w = u * math.sqrt(6.0 / (fan_in + fan_out))
