@@ -38,7 +38,7 @@ extern "C" {
 #define MMDEER_HIDDEN_DIM 256
 #define MMDEER_NUM_DIMS 3        /* valence, arousal, dominance */
 #define MMDEER_NUM_PARAMS_ABI 50 /* canonical parameter order: mmdeer_param_name(i) */
-#define MMDEER_LOSS_OUT 17       /* per dim {total,nll,reg,kl,ece} x3, cross_dim, total */
+#define MMDEER_LOSS_OUT 20       /* per dim {total,nll,reg,kl,ece} x3, cross_dim, total, mean nll / reg / kl */
 
 const char* mmdeer_version(void);
 int mmdeer_abi_version(void);
@@ -150,6 +150,7 @@ typedef struct mmdeer_gemm_args {
    * summed in a fixed order; needs an fp32 C and no epilogue. */
   int32_t splitk;
   float* slab;
+  void* debug;   /* diagnostic builds (-DMMDEER_STAMPS) only: uint64 buffer for in-kernel cycle stamps; NULL otherwise */
   void* stream;
 } mmdeer_gemm_args;
 int mmdeer_gemm(const mmdeer_gemm_args* a);

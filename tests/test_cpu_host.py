@@ -98,7 +98,7 @@ def test_unsupported_geometry_and_cpu_inputs_fail_loudly():
 
 
 def test_loss_dict_layout():
-    lo = torch.arange(17, dtype=torch.float32)
+    lo = torch.arange(20, dtype=torch.float32)
     d = loss_dict_from(lo, 5)
     assert float(d["total_loss"]) == 16 and float(d["cross_dim_loss"]) == 15
     assert float(d["arousal_kl_loss"]) == 8 and d["dominance_batch_size"] == 5

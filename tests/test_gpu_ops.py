@@ -269,7 +269,7 @@ def test_nig_loss_vs_oracle(golden_dir):
         B = yt.shape[0]
         stats = torch.empty(lib.mmdeer_nig_stats_elems(B), device=dev())
         grads = torch.zeros(4, B, 3, device=dev())
-        loss_out = torch.empty(17, device=dev())
+        loss_out = torch.empty(20, device=dev())
         bins = torch.empty(30, dtype=torch.int32, device=dev())
         from mmdeer.model import make_loss_cfg
         cfg = make_loss_cfg()

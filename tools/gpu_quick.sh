@@ -1,0 +1,11 @@
+#!/bin/bash
+# tests + bench + rocprof kernel stats (no microbenchmarks)
+set -u
+mkdir -p gpurun_out
+run() { local name=$1 to=$2; shift 2; echo "=== $name"; timeout -k 10 "$to" "$@" > "gpurun_out/$name.log" 2>&1; local rc=$?; echo "rc=$rc"; grep -v "amdgpu.ids\|UserWarning\|Consider using\|float(ld\|^$" "gpurun_out/$name.log" | tail -n 12; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi; }
+run pytest_gpu 900 python -m pytest tests -m gpu -q -p no:cacheprovider
+run smoke 300 python __graft_entry__.py smoke
+run bench 600 python bench.py --steps 30 --warmup 10 ${BENCH_ARGS:-}
+ROOT=$(pwd); export TMPDIR=/tmp
+( cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/gpurun_out/rocprof.log 2>&1; echo "rocprof rc=$?" )
+python tools/prof_summary.py

@@ -25,3 +25,5 @@ ROOT=$(pwd)
 export TMPDIR=/tmp
 ( cd /tmp && step_dir=$ROOT/gpurun_out && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?" | tee -a $ROOT/gpurun_out/round.log )
 find gpurun_out/prof -name "*stats*" | head; tail -n 5 gpurun_out/rocprof.log
+step stamps 300 python tools/gemm_stamps.py
+cat gpurun_out/stamps.log

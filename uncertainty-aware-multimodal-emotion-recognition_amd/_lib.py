@@ -63,7 +63,7 @@ class GemmArgs(C.Structure):
         ("relu", c_int), ("accumulate", c_int), ("compute_f32", c_int), ("tile", c_int),
         ("drop_site", c_int), ("drop_shift", c_int), ("regen_site", c_int),
         ("dropout_p", c_float), ("mask_scale", c_float), ("seed", c_u64), ("offset", c_u64),
-        ("splitk", c_int), ("slab", c_void_p), ("stream", c_void_p),
+        ("splitk", c_int), ("slab", c_void_p), ("debug", c_void_p), ("stream", c_void_p),
     ]
 
 

@@ -16,7 +16,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(PKG_DIR, "libmmdeer_hip.so")
-SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "nig.hip", "side.hip", "api.hip"]
+SOURCES = ["gemm_nt.hip", "gemm_nx.hip", "gemm_tt.hip", "gemm.hip", "rowops.hip", "attention.hip", "nig.hip", "side.hip", "api.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
@@ -38,6 +38,17 @@ def needs_build() -> bool:
     return not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < _newest_dep_mtime()
 
 
+def build_stamps() -> str:
+    """Diagnostic library with in-kernel s_memtime stamps (tools/gemm_stamps.py); never loaded by the product."""
+    hipcc = _hipcc()
+    out = os.path.join(PKG_DIR, "libmmdeer_stamps.so")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    r = subprocess.run([hipcc, *FLAGS, "-DMMDEER_STAMPS", "-shared", "-o", out, *srcs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
@@ -55,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(compile_one, srcs))
     tmp = LIB_PATH + ".tmp"
     r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs],

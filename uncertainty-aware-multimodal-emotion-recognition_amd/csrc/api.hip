@@ -130,7 +130,7 @@ int ksteps_target() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("MMDEER_KSTEPS");
-    v = e ? atoi(e) : 16;
+    v = e ? atoi(e) : 8;
     if (v < 1) v = 1;
   }
   return v;
@@ -158,6 +158,9 @@ GemmTile pick_tile(const GemmGroup& g) {
       tiles[t] += (long long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * p.batch;
     }
   }
+  // weight-gradient groups (both operands transposed): the strided loads and the packing LDS store cost the same per
+  // K-tile whatever the tile size, so the largest tile wins; split-K supplies the parallelism
+  if (g.p[0].trans_a) return TILE_128x128;
   if (tiles[2] >= 512) return TILE_128x128;
   if (tiles[1] >= 512) return TILE_128x64;
   return TILE_64x64;
@@ -562,6 +565,7 @@ int mmdeer_gemm(const mmdeer_gemm_args* a) {
     p.slab_b = a->slab + (long long)a->M * a->N;
   }
   g.drop = make_drop(a->dropout_p, a->seed, a->offset);
+  g.stamps = reinterpret_cast<unsigned long long*>(a->debug);
   GemmTile t = (a->tile >= 0 && a->tile <= 2) ? (GemmTile)a->tile : pick_tile(g);
   TRY(launch_gemm_group(g, a->compute_f32 ? 1 : 0, t, (hipStream_t)a->stream));
   if (g.p[0].splitk > 1) {   // fold the K-slices into C (and bias_grad)

@@ -45,6 +45,7 @@ enum SrcMode { SRC_F32 = 0, SRC_BF16_V16 = 1, SRC_BF16_V8 = 2 };
 constexpr int GEMM_MAX_PROBLEMS = 6;
 
 struct GemmGroup {
+  unsigned long long* stamps;   // diagnostic builds (-DMMDEER_STAMPS) only: s_memtime samples of workgroup 0; else null
   int nprob;
   int xcd_remap;   // 1: renumber workgroups so that each XCD (blockIdx % 8) owns a contiguous range of tiles
   int tile_start[GEMM_MAX_PROBLEMS + 1];

@@ -6,7 +6,7 @@
 namespace mmdeer {
 
 constexpr int NIG_NSTAT = 35;      // per (block, dim): 5 sums + 10 bins x {sum conf, sum err, count}
-constexpr int NIG_LOSS_OUT = 17;   // per dim {total, nll, reg, kl, ece} x 3, cross, total
+constexpr int NIG_LOSS_OUT = 20;   // per dim {total, nll, reg, kl, ece} x 3, cross, total, mean nll, mean reg, mean kl
 
 struct LossCfg {
   float reg_w, kl_w, ece_w, cross_w;   // losses.py:52-53, 239   (0.1, 0.01, 0.05, 0.05)

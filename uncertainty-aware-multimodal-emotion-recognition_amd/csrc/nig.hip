@@ -143,6 +143,10 @@ __device__ __forceinline__ void compute_finals(const float* stats, int nblk, int
     if (cfg.cross_w > 0.f) tot += cfg.cross_w * cross;
     F.out[15] = cross;
     F.out[16] = tot / 3.f;                                                          // losses.py:314
+    // dimension means of the components (the keys the reference trainer accumulates, training.py:187-190)
+    F.out[17] = (F.out[1] + F.out[6] + F.out[11]) / 3.f;
+    F.out[18] = (F.out[2] + F.out[7] + F.out[12]) / 3.f;
+    F.out[19] = (F.out[3] + F.out[8] + F.out[13]) / 3.f;
   }
   __syncthreads();
 }
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
   __shared__ float gs[3][NIG_NSTAT];
   __shared__ f32x4 sdE[256];
   __shared__ Finals F;
+  __shared__ float xt[256][65];   // this block's e2 rows (fp32, +1 pad): reused by the weight-gradient partial
   const int d = blockIdx.y, tid = threadIdx.x;
   const int nblk = gridDim.x;
   W[tid >> 6][tid & 63] = wload<F32>(w3, d * 256 + tid);
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
     load_row64<F32>(e2, (long long)b * 192 + d * 64, x);
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
+      xt[tid][j] = x[j];
       const float v = dE.x * W[0][j] + dE.y * W[1][j] + dE.z * W[2][j] + dE.w * W[3][j];
       x[j] = x[j] > 0.f ? v * mask_scale : 0.f;
     }
@@ -315,13 +321,9 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
     const int c = tid >> 6, j = tid & 63;
     const int rows = min(256, B - blockIdx.x * 256);
     float acc = 0.f;
-    for (int s = 0; s < rows; ++s) {
-      const f32x4 e = sdE[s];
-      const float ec = c == 0 ? e.x : (c == 1 ? e.y : (c == 2 ? e.z : e.w));
-      const long long idx = (long long)(blockIdx.x * 256 + s) * 192 + d * 64 + j;
-      const float xv = F32 ? reinterpret_cast<const float*>(e2)[idx] : bf2f(reinterpret_cast<const bf16_t*>(e2)[idx]);
-      acc = fmaf(ec, xv, acc);
-    }
+    const float* sde = reinterpret_cast<const float*>(sdE) + c;   // one wave = one c: broadcast reads
+#pragma unroll 8
+    for (int s = 0; s < rows; ++s) acc = fmaf(sde[4 * s], xt[s][j], acc);
     partial_w[((long long)blockIdx.x * 3 + d) * 256 + tid] = acc;
     if (tid < 4) {
       float bs = 0.f;

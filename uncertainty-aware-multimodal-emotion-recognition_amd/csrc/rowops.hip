@@ -37,19 +37,31 @@ __device__ __forceinline__ void store4(void* base, long long idx, f32x4 v) {
 // ------------------------------------------------------------------ parameter pack
 template <bool DST_F32>
 __global__ __launch_bounds__(256) void pack_params_kernel(const PackTable t, void* wdst, float* vdst) {
+  // one block = 1024 consecutive 4-element chunks (4 per thread); the segment of the block's first chunk is found
+  // once by binary search, each thread then only walks forward (a block rarely spans more than two tensors)
+  __shared__ int seg0;
   const auto& T = karg<PackTable>();
   const int total = T.total_chunks, nseg = T.nseg;
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < total; c += gridDim.x * 256) {
-    int lo = 0, hi = nseg - 1;  // last segment whose chunk_start <= c
+  const int first = blockIdx.x * 1024;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = nseg - 1;
     while (lo < hi) {
       int mid = (lo + hi + 1) >> 1;
-      if (T.chunk_start[mid] <= c) lo = mid; else hi = mid - 1;
+      if (T.chunk_start[mid] <= first) lo = mid; else hi = mid - 1;
     }
-    const int e = (c - T.chunk_start[lo]) * 4;
-    const float* src = (const float*)T.src[lo];
-    f32x4 v = *reinterpret_cast<const f32x4*>(src + e);
-    if (T.is_vec[lo]) store4<true>(vdst, T.dst_off[lo] + e, v);
-    else store4<DST_F32>(wdst, T.dst_off[lo] + e, v);
+    seg0 = lo;
+  }
+  __syncthreads();
+  int sg = seg0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = first + i * 256 + threadIdx.x;
+    if (c >= total) break;
+    while (sg + 1 < nseg && T.chunk_start[sg + 1] <= c) ++sg;
+    const int e = (c - T.chunk_start[sg]) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>((const float*)T.src[sg] + e);
+    if (T.is_vec[sg]) store4<true>(vdst, T.dst_off[sg] + e, v);
+    else store4<DST_F32>(wdst, T.dst_off[sg] + e, v);
   }
 }
 
@@ -234,7 +246,7 @@ int launch_pack_params(PackTable& t, void* wdst, int w_f32, float* vdst, hipStre
   }
   t.chunk_start[t.nseg] = chunks;
   t.total_chunks = chunks;
-  const int grid = grid_for(t.total_chunks);
+  const int grid = (chunks + 1023) / 1024;
   if (w_f32) hipLaunchKernelGGL(pack_params_kernel<true>, dim3(grid), dim3(256), 0, s, t, wdst, vdst);
   else hipLaunchKernelGGL(pack_params_kernel<false>, dim3(grid), dim3(256), 0, s, t, wdst, vdst);
   MMDEER_HIP(hipGetLastError());

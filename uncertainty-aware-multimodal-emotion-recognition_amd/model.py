@@ -138,7 +138,7 @@ class _LossFn(torch.autograd.Function):
         y = targets.contiguous().float()
         stats = torch.empty(lib.mmdeer_nig_stats_elems(B), dtype=torch.float32, device=dev)
         grads = torch.empty(4, B, 3, dtype=torch.float32, device=dev)
-        loss_out = torch.empty(17, dtype=torch.float32, device=dev)
+        loss_out = torch.empty(20, dtype=torch.float32, device=dev)
         bins = torch.empty(30, dtype=torch.int32, device=dev)
         _lib.check(lib.mmdeer_nig_loss(g.data_ptr(), n.data_ptr(), a.data_ptr(), b.data_ptr(), y.data_ptr(),
                                        stats.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
@@ -176,9 +176,7 @@ def loss_dict_from(loss_out: torch.Tensor, batch_size: int) -> Dict[str, torch.T
     d["total_loss"] = loss_out[16]
     # keys the reference trainer accumulates when present (training.py:187-190)
     d["deer_loss"] = loss_out[16]
-    d["nll_loss"] = (loss_out[1] + loss_out[6] + loss_out[11]) / 3
-    d["evidence_reg"] = (loss_out[2] + loss_out[7] + loss_out[12]) / 3
-    d["kl_reg"] = (loss_out[3] + loss_out[8] + loss_out[13]) / 3
+    d["nll_loss"], d["evidence_reg"], d["kl_reg"] = loss_out[17], loss_out[18], loss_out[19]   # computed in-kernel
     return d
 
 
@@ -403,7 +401,7 @@ class MultimodalDEER(nn.Module):
         o = self._launch_forward(audio, video, text, targets, prof_events)
         meta = o["_meta"]
         dev = meta["ws"].device
-        loss_out = torch.empty(17, dtype=torch.float32, device=dev)
+        loss_out = torch.empty(20, dtype=torch.float32, device=dev)
         bins = torch.empty(30, dtype=torch.int32, device=dev)
         # the fused path owns ONE persistent flat gradient buffer per device (zeroed once: the alignment gaps stay 0);
         # every step overwrites all live slices, and .grad of each live parameter is a view of it
