@@ -1,0 +1,83 @@
+"""BASELINE config 1 on the GPU: the launcher / trainer plumbing on synthetic data, B = 32."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mmdeer import synth  # noqa: E402
+from mmdeer.model import ModelConfig, MultimodalDEER  # noqa: E402
+from mmdeer.trainer import DEERTrainer, TrainingConfig, evaluate_deer_model, profile_training_speed  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def loaders(n, bs, seed, as_dict):
+    b = synth.make_batch(n, seed=seed)
+    if as_dict:   # multi_dataset_framework.py:88-98 batch format
+        data = [{"audio_features": torch.from_numpy(b["audio"][i:i + bs]), "video_features": torch.from_numpy(b["video"][i:i + bs]),
+                 "text_features": torch.from_numpy(b["text"][i:i + bs]), "targets": torch.from_numpy(b["targets"][i:i + bs])}
+                for i in range(0, n, bs)]
+        return {"iemocap": data}
+    ds = torch.utils.data.TensorDataset(*(torch.from_numpy(b[k]) for k in ("audio", "video", "text", "targets")))
+    return {"synthetic_train": torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=False)}
+
+
+@pytest.mark.parametrize("as_dict", [False, True])
+def test_trainer_reduces_loss_and_reports_metrics(tmp_path, as_dict):
+    model = MultimodalDEER(ModelConfig(compute_dtype="fp32", dropout=0.1, seed=3))
+    cfg = TrainingConfig(learning_rate=3e-4, batch_size=32, num_epochs=4, output_dir=str(tmp_path / "out"),
+                         log_dir=str(tmp_path / "log"), checkpoint_dir=str(tmp_path / "ckpt"))
+    tr = DEERTrainer(model, cfg, "cuda:0")
+    assert len(tr.optimizer.param_groups) >= 2                 # 'attention'-named group + default group
+    hist = tr.train(loaders(256, 32, 1, as_dict), loaders(96, 32, 2, as_dict))
+    json.dumps(hist)
+    assert len(hist["train_loss"]) == 4 and hist["train_loss"][-1] < hist["train_loss"][0]
+    assert all(np.isfinite(hist["grad_norm"]))
+    ev = tr.evaluate_model(loaders(96, 32, 5, as_dict))
+    for k in ("ccc_valence", "mae_arousal", "rmse_dominance", "ece", "ccc_overall", "test_loss"):
+        assert np.isfinite(ev[k]), k
+    ck = torch.load(tmp_path / "ckpt" / "best_model.pt", weights_only=False)
+    assert set(ck) == {"model_state_dict", "training_config", "training_history", "training_time"}
+    m2 = MultimodalDEER(ModelConfig()).to("cuda:0")
+    m2.load_state_dict(ck["model_state_dict"])
+    assert np.isfinite(evaluate_deer_model(m2, loaders(64, 32, 5, as_dict), "cuda:0")["ccc_overall"])
+
+
+def test_clip_matches_torch_clip_grad_norm():
+    model = MultimodalDEER(ModelConfig(dropout=0.0)).to("cuda:0").train()
+    b = {k: torch.from_numpy(v).to("cuda:0") for k, v in synth.make_batch(16, seed=4).items()}
+    tr = DEERTrainer(model, TrainingConfig(gradient_clip=0.05, output_dir="/tmp/mmdeer_t/o", log_dir="/tmp/mmdeer_t/l",
+                                           checkpoint_dir="/tmp/mmdeer_t/c"), "cuda:0")
+    model.train_step(b["audio"], b["video"], b["text"], b["targets"])
+    ref = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    total_ref = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 1e9)
+    total = tr.clip_gradients()
+    assert float(total) == pytest.approx(float(total_ref), rel=1e-5)
+    scale = min(1.0, 0.05 / (float(total_ref) + 1e-6))
+    for g0, p in zip(ref, [p for p in model.parameters() if p.grad is not None]):
+        assert torch.allclose(p.grad, g0 * scale, rtol=1e-5, atol=1e-9)
+
+
+def test_profile_training_speed_runs():
+    model = MultimodalDEER(ModelConfig(compute_dtype="bf16")).to("cuda:0")
+    r = profile_training_speed(model, batch_size=256, warmup=2, iters=5)
+    assert r["forward"]["samples_per_sec"] > 0 and r["forward_backward"]["samples_per_sec"] > 0
+
+
+def test_launcher_quick_run(tmp_path):
+    """`run_multimodal_deer.py --mode full --quick --batch_size 32` (BASELINE configs[0])."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "experiments", "run_multimodal_deer.py"), "--mode", "full", "--quick",
+                        "--batch_size", "32", "--epochs", "2", "--output_dir", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = [d for d in os.listdir(tmp_path) if d.startswith("experiment_")]
+    rep = json.load(open(tmp_path / exp[0] / "report.json"))
+    assert len(rep["history"]["train_loss"]) == 2
+    assert rep["sample_predictions"]["nig_keys"] == ["gamma", "nu", "alpha", "beta"]
+    assert np.array(rep["sample_predictions"]["predictions"]).shape == (4, 3)

@@ -1,0 +1,206 @@
+"""Thin trainer / evaluator reproducing the hook contract of the reference's DEERTrainer
+(src/training/training.py:75-507) on top of the fused HIP step.
+
+Kept: TrainingConfig field names (:38-72); AdamW eps 1e-8 with three parameter groups, 'encoder'-named
+parameters at 0.5 x lr (:121-150); cosine / plateau / exponential schedules (:152-174); global-norm clip 1.0
+(:219-222); dataset weighting of the loss (:211-212); both batch formats (dict with *_features/targets, and the
+4-tuple of the script's TensorDataset, run_multimodal_deer.py:342, 414-415); JSON-serialisable history.
+Not reproduced (out of scope): curriculum sampling, TensorBoard.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from dataclasses import asdict, dataclass, field
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+from .metrics import validation_metrics
+from .model import MultimodalDEER
+
+
+@dataclass
+class TrainingConfig:
+    learning_rate: float = 1e-4
+    weight_decay: float = 1e-5
+    gradient_clip: float = 1.0
+    batch_size: int = 32
+    num_epochs: int = 100
+    scheduler_type: str = "cosine"
+    warmup_epochs: int = 5
+    patience: int = 10
+    evidence_weight: float = 1.0
+    kl_weight: float = 0.1
+    attention_reg_weight: float = 0.1
+    dataset_weights: Dict[str, float] = field(default_factory=lambda: {"iemocap": 1.0, "ravdess": 0.8, "meld": 0.6})
+    curriculum_learning: bool = True
+    val_frequency: int = 5
+    save_frequency: int = 10
+    early_stopping: bool = True
+    output_dir: str = "./results"
+    log_dir: str = "./logs"
+    checkpoint_dir: str = "./checkpoints"
+
+
+def unpack_batch(batch, device):
+    """dict batches (training.py:201-204) or (audio, video, text, emotions) tuples (run_multimodal_deer.py:414-415)."""
+    if isinstance(batch, dict):
+        a, v, t, y = (batch[k] for k in ("audio_features", "video_features", "text_features", "targets"))
+    else:
+        a, v, t, y = batch
+    nb = device.type == "cuda"
+    return tuple(x.to(device, non_blocking=nb) for x in (a, v, t, y))
+
+
+class DEERTrainer:
+    def __init__(self, model: MultimodalDEER, config: Optional[TrainingConfig] = None, device=None, comm=None):
+        self.config = config or TrainingConfig()
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
+        self.model = model.to(self.device)
+        self.comm = comm                     # optional mmdeer.parallel.BucketedAllReduce (data parallel)
+        self.optimizer = self._create_optimizer()
+        self.scheduler = self._create_scheduler()
+        self.current_epoch = 0
+        self.history = {"train_loss": [], "val_loss": [], "train_ccc": [], "val_ccc": [], "learning_rate": [], "grad_norm": []}
+        for d in (self.config.output_dir, self.config.log_dir, self.config.checkpoint_dir):
+            os.makedirs(d, exist_ok=True)
+
+    # ---- optimiser semantics of training.py:121-174
+    def _create_optimizer(self):
+        enc, att, rest = [], [], []
+        for name, p in self.model.named_parameters():
+            (enc if "encoder" in name else att if "attention" in name else rest).append(p)
+        lr = self.config.learning_rate
+        groups = [g for g in ({"params": enc, "lr": lr * 0.5}, {"params": att, "lr": lr}, {"params": rest, "lr": lr}) if g["params"]]
+        return torch.optim.AdamW(groups, weight_decay=self.config.weight_decay, eps=1e-8)
+
+    def _create_scheduler(self):
+        c = self.config
+        if c.scheduler_type == "cosine":
+            return torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=c.num_epochs, eta_min=1e-6)
+        if c.scheduler_type == "plateau":
+            return torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", patience=max(1, c.patience // 2), factor=0.5)
+        return torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=0.95)
+
+    def clip_gradients(self) -> torch.Tensor:
+        """clip_grad_norm_(model.parameters(), gradient_clip) on the flat gradient buffer (its alignment gaps are
+        zeros, and unused parameters have no gradient, so its 2-norm IS the global norm).  No host sync."""
+        flat = self.model.flat_grad()
+        total = torch.linalg.vector_norm(flat)
+        flat.mul_(torch.clamp(self.config.gradient_clip / (total + 1e-6), max=1.0))
+        return total
+
+    # ---- one epoch (training.py:176-245)
+    def train_epoch(self, train_loaders: Dict[str, Iterable]) -> Dict[str, float]:
+        self.model.train()
+        keys = ("total_loss", "deer_loss", "nll_loss", "evidence_reg", "kl_reg")
+        sums = torch.zeros(len(keys), device=self.device, dtype=torch.float64)
+        total, norms = 0, []
+        events = self.comm.events if self.comm is not None else None
+        for name, loader in train_loaders.items():
+            w = float(self.config.dataset_weights.get(name, 1.0))
+            for batch in loader:
+                a, v, t, y = unpack_batch(batch, self.device)
+                # no zero_grad(): the fused step overwrites every live gradient slice of the flat buffer
+                ld = self.model.train_step(a, v, t, y, events=events)     # forward + loss + backward, fused
+                if w != 1.0:
+                    self.model.flat_grad().mul_(w)                         # weighted_loss = total_loss * weight (:211-212)
+                if self.comm is not None:
+                    self.comm.launch(self.model.flat_grad())
+                    self.comm.wait(self.model.flat_grad())
+                norms.append(self.clip_gradients())
+                self.optimizer.step()
+                bs = a.shape[0]
+                sums += torch.stack([ld[k].double() for k in keys]) * bs    # accumulated on device: no .item() per batch
+                total += bs
+        out = {k: float(s) / max(total, 1) for k, s in zip(keys, sums.cpu())}
+        out["attention_reg"] = 0.0
+        out["grad_norm"] = float(torch.stack(norms).mean()) if norms else 0.0
+        return out
+
+    @torch.no_grad()
+    def validate_epoch(self, val_loaders: Dict[str, Iterable]) -> Dict[str, float]:
+        self.model.eval()
+        preds, tgts, uncs, losses = [], [], [], []
+        for loader in val_loaders.values():
+            for batch in loader:
+                a, v, t, y = unpack_batch(batch, self.device)
+                out = self.model(a, v, t)
+                p, u = self.model.get_predictions_and_uncertainties(out)
+                losses.append(self.model.compute_loss(out, y)["total_loss"])
+                preds.append(p); tgts.append(y); uncs.append(u)
+        if not preds:
+            return {"val_loss": float("nan")}
+        m = validation_metrics(torch.cat(preds).cpu().numpy(), torch.cat(tgts).cpu().numpy(), torch.cat(uncs).cpu().numpy())
+        m["val_loss"] = float(torch.stack(losses).mean())
+        return m
+
+    def evaluate_model(self, test_loaders: Dict[str, Iterable]) -> Dict[str, float]:
+        m = self.validate_epoch(test_loaders)
+        m["test_loss"] = m.pop("val_loss")
+        return m
+
+    def train(self, train_loaders, val_loaders) -> Dict:
+        """Returns a JSON-serialisable history (run_multimodal_deer.py:503-509)."""
+        t0 = time.time()
+        best, bad = float("inf"), 0
+        for epoch in range(self.config.num_epochs):
+            self.current_epoch = epoch
+            tr = self.train_epoch(train_loaders)
+            va = self.validate_epoch(val_loaders) if val_loaders else {"val_loss": float("nan")}
+            if isinstance(self.scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau):
+                self.scheduler.step(va["val_loss"])
+            else:
+                self.scheduler.step()
+            self.history["train_loss"].append(tr["total_loss"])
+            self.history["val_loss"].append(va["val_loss"])
+            self.history["train_ccc"].append(float("nan"))
+            self.history["val_ccc"].append(va.get("ccc_overall", float("nan")))
+            self.history["learning_rate"].append(self.optimizer.param_groups[0]["lr"])
+            self.history["grad_norm"].append(tr["grad_norm"])
+            if va["val_loss"] < best - 1e-6:
+                best, bad = va["val_loss"], 0
+                self.save_checkpoint(os.path.join(self.config.checkpoint_dir, "best_model.pt"), time.time() - t0)
+            else:
+                bad += 1
+                if self.config.early_stopping and bad >= self.config.patience:
+                    break
+        self.history["training_time"] = time.time() - t0
+        with open(os.path.join(self.config.output_dir, "training_history.json"), "w") as f:
+            json.dump(self.history, f, indent=2)
+        return self.history
+
+    def save_checkpoint(self, path: str, training_time: float = 0.0) -> None:
+        """Checkpoint layout of run_multimodal_deer.py:512-517."""
+        torch.save({"model_state_dict": self.model.state_dict(), "training_config": asdict(self.config),
+                    "training_history": self.history, "training_time": training_time}, path)
+
+
+def evaluate_deer_model(model: MultimodalDEER, test_loaders, device=None) -> Dict[str, float]:
+    """evaluation.evaluate_deer_model (evaluation.py:785-808): metrics of the model on the test loaders."""
+    return DEERTrainer(model, TrainingConfig(), device).evaluate_model(test_loaders)
+
+
+def profile_training_speed(model: MultimodalDEER, batch_size: int = 32, warmup: int = 10, iters: int = 100):
+    """TrainingUtils.profile_training_speed (training.py:554-605): warm-up + timed forward and forward+backward."""
+    from . import synth
+    dev = next(model.parameters()).device
+    b = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_batch(batch_size).items()}
+    out = {}
+    for name, fn in (("forward", lambda: model(b["audio"], b["video"], b["text"])),
+                     ("forward_backward", lambda: model.train_step(b["audio"], b["video"], b["text"], b["targets"]))):
+        model.train(name != "forward")
+        with torch.set_grad_enabled(False):
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out[name] = {"ms_per_batch": dt * 1e3, "samples_per_sec": batch_size / dt}
+    return out
