@@ -83,7 +83,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_comm = os.environ.get("MMDEER_FORCE_COMM") == "1" and "RANK" in os.environ   # 1-rank rehearsal of the DP path
+    if world > 1 or force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -101,7 +102,7 @@ def main():
     a, v, t, y = (torch.from_numpy(data[k]).to(dev) for k in ("audio", "video", "text", "targets"))
     if args.dtype == "bf16":
         a, v, t = a.bfloat16(), v.bfloat16(), t.bfloat16()         # BASELINE configs 3-5: bf16 feature blocks
-    comm = BucketedAllReduce(device=dev) if world > 1 else None
+    comm = BucketedAllReduce(device=dev, force=force_comm) if (world > 1 or force_comm) else None
     K, W = args.steps, args.warmup
     prof = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     for e0, e1 in prof:
@@ -168,7 +169,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_comm:
         dist.destroy_process_group()
 
 

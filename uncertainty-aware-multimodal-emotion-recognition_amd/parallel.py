@@ -18,9 +18,11 @@ from . import _lib
 
 
 class BucketedAllReduce:
-    def __init__(self, group: Optional["dist.ProcessGroup"] = None, device: Optional[torch.device] = None):
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None, device: Optional[torch.device] = None,
+                 force: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()    # run the collectives even on a 1-rank group (rehearsal)
         lib = _lib.load()
         self.ranges = [(lib.mmdeer_bucket_begin(i), lib.mmdeer_bucket_end(i)) for i in range(3)]
         self.cuda = device is not None and device.type == "cuda"
@@ -35,7 +37,7 @@ class BucketedAllReduce:
 
     def launch(self, flat: torch.Tensor) -> None:
         """Enqueue the bucket all-reduces (call right after model.train_step(..., events=self.events))."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         self._work = []
         if self.cuda:
@@ -49,7 +51,7 @@ class BucketedAllReduce:
 
     def wait(self, flat: Optional[torch.Tensor] = None) -> None:
         """Make the reduced gradients visible to the current stream (or the host for gloo)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         for w in self._work:
             w.wait()
