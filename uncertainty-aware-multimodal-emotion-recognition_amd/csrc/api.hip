@@ -66,6 +66,7 @@ constexpr int SPLITK_MAX = 8;
 struct Layout {
   // packed parameters
   char* wpack;   // compute dtype, MMDEER_FLAT_ELEMS
+  char* wtpack;  // transposed weight matrices (W^T, compute dtype) at the same flat offsets: dX runs as an NT GEMM
   float* vpack;  // fp32 vectors, MMDEER_FLAT_ELEMS
   // saved activations (activation dtype unless noted)
   char *avin, *avv, *cat, *y_a2, *av, *xtok, *qkv, *obar, *pool, *y_t3, *tri, *y_o1, *fused, *h1, *h2, *e1, *e2;
@@ -88,6 +89,7 @@ Layout make_layout(void* base, int B, int f32) {
   auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += align_up(bytes); return p; };
   const size_t Bz = (size_t)(B > 0 ? B : 1);
   L.wpack = take((size_t)MMDEER_FLAT_ELEMS * es);
+  L.wtpack = take((size_t)MMDEER_FLAT_ELEMS * es);
   L.vpack = reinterpret_cast<float*>(take((size_t)MMDEER_FLAT_ELEMS * 4));
   auto act = [&](size_t rows, size_t cols) { return take(rows * cols * es); };
   auto f32buf = [&](size_t n) { return reinterpret_cast<float*>(take(n * 4)); };
@@ -192,12 +194,14 @@ struct Exec {
     p.drop_site = drop_on ? site : -1;
     return p;
   }
-  // dX = dY W, optionally masked by (Yprev > 0) * mask_scale
+  // dX = dY W, optionally masked by (Yprev > 0) * mask_scale.  Runs as an NT GEMM against the packed W^T
+  // ([K_layer][N_layer], reduction-contiguous), i.e. on the LDS-DMA kernel in bf16 mode.
+  const char* WT(int pid) const { return L->wtpack + (size_t)kParams[pid].off * es; }
   GemmProblem dx(const void* dY, int ldy_in, int pidW, void* dX, int ldx, int M, const void* Ymask, int ldmask) const {
     GemmProblem p;
     gemm_problem_defaults(p);
     p.A = dY; p.a_f32 = f32; p.lda = ldy_in;
-    p.B = W(pidW); p.b_f32 = f32; p.ldb = kParams[pidW].cols; p.trans_b = 1;
+    p.B = WT(pidW); p.b_f32 = f32; p.ldb = kParams[pidW].rows;
     p.C = dX; p.c_f32 = f32; p.ldc = ldx;
     p.M = M; p.N = kParams[pidW].cols; p.K = kParams[pidW].rows;
     p.Y = Ymask; p.y_f32 = f32; p.ldy = ldmask; p.mask_scale = mask_scale;
@@ -312,6 +316,23 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
       t.is_vec[i] = kParams[i].is_matrix ? 0 : 1;
     }
     TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
+    // W^T copies for the backward dX GEMMs (only when this call trains: inference never reads them)
+    if (a->training || a->targets) {
+      PackTTable tt{};
+      for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
+        if (!kParams[i].is_matrix || i == P_AUD_W || i == P_VID_W || i == P_TXT_W || i >= P_EV2_W) continue;  // no dX needed
+        const int k = tt.nmat++;
+        tt.src[k] = reinterpret_cast<const float*>(a->params[i]);
+        tt.dst_off[k] = kParams[i].off;
+        tt.rows[k] = kParams[i].rows; tt.cols[k] = kParams[i].cols;
+        if (i >= P_EV0_W && i < P_EV0_W + 3) {   // the three stacked first head layers: one [256][3*128] image
+          tt.dst_off[k] = kParams[P_EV0_W].off;
+          tt.ld_dst[k] = 3 * EV1;
+          tt.dst_col[k] = (i - P_EV0_W) * EV1;
+        }
+      }
+      TRY(launch_pack_transposed(tt, L.wtpack, f32, s));
+    }
   }
   if (B == 0) return 0;
   MMDEER_CHECK(a->audio && a->video && a->text, "audio / video / text must be non-NULL");
@@ -452,7 +473,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // evidence_net layer 0 (256 -> 3 x 128 stacked)
   {
     GemmProblem p = X.dx(L.de1, 3 * EV1, P_EV0_W, L.dh2, HID, B, L.h2, HID);
-    p.K = 3 * EV1;
+    p.K = 3 * EV1; p.ldb = 3 * EV1;   // W^T of the stacked heads: [256][384]
     TRY(X.run1(p));
   }
   // feature_processor
@@ -506,7 +527,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // by batching over the two column halves of the weight
   {
     GemmProblem p = X.dx(L.dz_a2, INTER, P_AVF_W, L.dcats, INTER, B, nullptr, 0);
-    p.N = INTER; p.batch = 2; p.sB = INTER; p.sC = (long long)B * INTER;
+    p.N = INTER; p.batch = 2; p.sB = (long long)INTER * INTER; p.sC = (long long)B * INTER;   // rows [256 z, 256 z + 256) of W^T [512][256]
     TRY(X.run1(p));
   }
   // AV out_proj; dX gets the regenerated attention-dropout factor of the forward value projection
@@ -518,7 +539,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // AV value projection (rows [2E,3E) of in_proj)
   {
     GemmProblem p = X.dx(L.davv, INTER, P_AIN_W, L.davin, INTER, 2 * B, nullptr, 0);
-    p.B = X.W(P_AIN_W) + (size_t)2 * INTER * INTER * es;
+    p.B = X.WT(P_AIN_W) + (size_t)2 * INTER * es;   // columns [2E, 3E) of W^T [256][768]
     p.K = INTER;
     TRY(X.run1(p));
   }

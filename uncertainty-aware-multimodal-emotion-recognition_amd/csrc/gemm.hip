@@ -9,11 +9,18 @@ namespace mmdeer {
 int gemm_dispatch_nt(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
 int gemm_dispatch_nx(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
 int gemm_dispatch_tt(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
+int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStream_t s);
 
 namespace {
 int env_xcd() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MMDEER_XCD"); v = e ? atoi(e) : 1; }
+  return v;
+}
+// MMDEER_GLDS=0 forces the register-staged kernel for NT problems (A/B comparison, debugging)
+int env_glds() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_GLDS"); v = e ? atoi(e) : 1; }
   return v;
 }
 }  // namespace
@@ -92,7 +99,14 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t 
     for (int j = sub.nprob; j <= GEMM_MAX_PROBLEMS; ++j) sub.tile_start[j] = total;
     if (total == 0) continue;  // empty batch: nothing to do
     int rc;
-    if (!ta && !tb) rc = gemm_dispatch_nt(sub, total, compute_f32, tile, am, bm, stream);
+    // LDS-DMA fast path: bf16 NT problems whose operands are 16-byte aligned, row-contiguous and K % 64 == 0
+    // (128x128 tiles keep the register-staged kernel: its 74 KiB of LDS allow two workgroups per CU, the ring would not)
+    bool glds = !ta && !tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 && env_glds() && !sub.stamps &&
+                tile != TILE_128x128;
+    for (int j = 0; j < sub.nprob && glds; ++j)
+      glds = sub.p[j].K % 64 == 0 && sub.p[j].splitk == 1 && !sub.p[j].bias_grad;
+    if (glds) rc = gemm_dispatch_nt_glds(sub, total, tile, stream);
+    else if (!ta && !tb) rc = gemm_dispatch_nt(sub, total, compute_f32, tile, am, bm, stream);
     else if (!ta && tb) rc = gemm_dispatch_nx(sub, total, compute_f32, tile, am, bm, stream);
     else if (ta && tb) rc = gemm_dispatch_tt(sub, total, compute_f32, tile, am, bm, stream);
     else { set_error("gemm: (trans_a=1, trans_b=0) is not instantiated"); rc = -1; }

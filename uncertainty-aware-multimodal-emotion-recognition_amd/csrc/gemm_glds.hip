@@ -1,0 +1,170 @@
+// NT GEMM with LDS-DMA staging (global_load_lds_dwordx4) for gfx950: the fast path of  Y = X W^T  and of
+// dX = dY (W^T)^T  when both operands are bf16, K-contiguous, 16-byte aligned and K is a multiple of 64.
+//
+// Versus the register-staged kernel (gemm_kernel.inc) there is no VGPR staging, no ds_write and no wait in front
+// of the MFMAs: every wave DMA-writes 1 KiB pieces (8 rows x 128 B) of the next tiles straight into an NST-deep
+// LDS ring and the K loop is  { counted vmcnt wait -> one s_barrier -> issue tile t+NST-1 -> MFMA tile t }.
+//
+// LDS image: unpadded 128-byte rows (the DMA destination is lane-linear: base + lane*16), XOR-swizzled through the
+// per-lane SOURCE address: the 16-byte chunk stored at slot p of row r is logical chunk p ^ (r & 7), and fragment
+// reads apply the same involution (rule "swizzle both sides or neither").  With the ds_read_b128 lane groups of
+// gfx950 ({0-3,12-15,20-27}, ...) the 16 rows x 2 chunks of a group land on 16 distinct 16-byte slots per bank
+// parity: conflict-free (checked on paper in DESIGN.md, and against SQ_LDS_BANK_CONFLICT).
+//
+// Synchronisation (MI355X_MICROARCH: an LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt plus a
+// barrier the reader has passed): iteration t first waits until its own pieces of tile t have landed
+// (vmcnt = pieces of the younger tiles still allowed in flight), then s_barrier -- which also proves every wave
+// finished reading tile t-1 -- and only then re-issues into the stage tile t-1 occupied.  Raw s_barrier, never
+// __syncthreads(): the latter would drain vmcnt to 0.
+#include "gemm_kernel.inc"
+
+namespace mmdeer {
+namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// pieces (1 KiB wave-instructions) each wave issues per K-tile
+template <int BM, int BN> struct Glds { static constexpr int PA = BM / 32, PB = BN / 32, LPT = PA + PB; };
+
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_glds_kernel(const GemmGroup g) {
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int SPAD = BN + 4;
+  constexpr int LDS_BYTES = cmax(NST * STAGE, BM * SPAD * 4);
+  constexpr int PA = Glds<BM, BN>::PA, PB = Glds<BM, BN>::PB, LPT = Glds<BM, BN>::LPT;
+  static_assert(NST >= 3 && NST <= 4, "ring depth");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMA's LDS base (M0) must be wave-uniform
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+
+  int bid = blockIdx.x;
+  if (g.xcd_remap) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+    if (i < g.nprob && bid >= g.tile_start[i]) pi = i;
+  typedef const __attribute__((address_space(4))) unsigned char* karg_ptr;
+  karg_ptr kbase = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  const __attribute__((address_space(4))) GemmProblem& p =
+      *(const __attribute__((address_space(4))) GemmProblem*)(
+          kbase + __builtin_offsetof(GemmGroup, p) + (size_t)pi * sizeof(GemmProblem));
+  const int local = bid - g.tile_start[pi];
+  const int per_batch = p.tiles_m * p.tiles_n;
+  const int z = local / per_batch;
+  const int rem = local - z * per_batch;
+  const int tmb = rem / p.tiles_n, tnb = rem - tmb * p.tiles_n;
+  const int row0 = tmb * BM, col0 = tnb * BN;
+  const int M = p.M, N = p.N, K = p.K;
+  const int nk = K >> 6;   // K % 64 == 0 (checked by the launcher)
+
+  // ---- per-lane DMA source pointers: piece j of a wave covers tile rows (4j + wave) * 8 + (lane >> 3);
+  //      lane (r8 = lane>>3, slot = lane&7) fetches logical chunk slot ^ r8.  Rows beyond the matrix read row 0 of
+  //      the operand (their products only reach outputs that are never stored).
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (long long)z * p.sA;
+  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B) + (long long)z * p.sB;
+  const int r8 = lane >> 3, kchunk = ((lane & 7) ^ r8) * 8;
+  const bf16_t* pa[PA];
+  const bf16_t* pb[PB];
+#pragma unroll
+  for (int j = 0; j < PA; ++j) {
+    const int row = row0 + (4 * j + wave) * 8 + r8;
+    pa[j] = (row < M ? Ab + (long long)row * p.lda : reinterpret_cast<const bf16_t*>(p.A)) + kchunk;
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int row = col0 + (4 * j + wave) * 8 + r8;
+    pb[j] = (row < N ? Bb + (long long)row * p.ldb : reinterpret_cast<const bf16_t*>(p.B)) + kchunk;
+  }
+  auto issue = [&](int stage) __attribute__((always_inline)) {   // DMA one K-tile into `stage`, advance the pointers
+    unsigned char* sa = lds + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[j],
+                                       (__attribute__((address_space(3))) void*)(sa + j * 4096), 16, 0, 0);
+      pa[j] += 64;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[j],
+                                       (__attribute__((address_space(3))) void*)(sa + A_BYTES + j * 4096), 16, 0, 0);
+      pb[j] += 64;
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: row = w*WT + i*16 + li (row & 7 == li & 7), logical chunk 4s + lg
+  const int sw0 = ((lg) ^ (li & 7)) * 16, sw1 = ((4 + lg) ^ (li & 7)) * 16;
+  const int a_row_off = (wm * WTM + li) * 128, b_row_off = A_BYTES + (wn * WTN + li) * 128;
+
+  // ---- prologue: fill NST-1 stages
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nk) issue(t);
+
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // pieces of tile kt have landed once at most `younger` whole tiles of this wave are still in flight
+    const int younger = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+    if (younger >= 2) wait_vmcnt<2 * LPT>();
+    else if (younger == 1) wait_vmcnt<LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < nk) issue(stage == 0 ? NST - 1 : stage - 1);   // the stage tile kt-1 used
+    const unsigned char* sb = lds + stage * STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int sw = s == 0 ? sw0 : sw1;
+      u32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sb + a_row_off + i * 2048 + sw);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sb + b_row_off + j * 2048 + sw);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<bf16_t>(fa[i], fb[j], acc[i][j]);
+    }
+    stage = stage + 1 == NST ? 0 : stage + 1;
+  }
+  // every wave must be done reading the ring before the epilogue reuses it as fp32 staging (no DMA is in flight:
+  // the last iteration waited vmcnt(0))
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  gemm_epilogue<BM, BN>(g, p, lds, acc, z, 0, row0, col0);
+}
+
+template <int BM, int BN, int NST>
+int launch_glds(const GemmGroup& g, int total, hipStream_t stream) {
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<BM, BN, NST>), dim3(total), dim3(256), 0, stream, g);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// caller guarantees: bf16 compute, both operands bf16 with ld % 8 == 0 and 16-byte aligned bases, K % 64 == 0,
+// no transposition, no split-K
+int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStream_t s) {
+  switch (tile) {
+    case TILE_64x64: return launch_glds<64, 64, 4>(g, total, s);
+    case TILE_128x64: return launch_glds<128, 64, 3>(g, total, s);   // 72 KiB ring: two workgroups per CU
+    default: return launch_glds<128, 128, 4>(g, total, s);
+  }
+}
+
+}  // namespace mmdeer

@@ -18,6 +18,20 @@ struct PackTable {
 // cast), vectors go to `vdst` in fp32.  Both buffers use the same flat element offsets.
 int launch_pack_params(PackTable& t, void* wdst, int w_f32, float* vdst, hipStream_t s);
 
+// Transposed weight pack: for every matrix segment (rows x cols, row-major fp32) write W^T (cols x rows) in the
+// compute dtype at the same flat offset of `wtdst`.  Lets dX = dY W run as an NT GEMM (dY [M][N_l] times
+// W^T stored [K_l][N_l], both reduction-contiguous) on the LDS-DMA kernel.
+constexpr int PACKT_MAX = 32;
+struct PackTTable {
+  int nmat;
+  const float* src[PACKT_MAX];
+  long long dst_off[PACKT_MAX];
+  int rows[PACKT_MAX], cols[PACKT_MAX];
+  int ld_dst[PACKT_MAX], dst_col[PACKT_MAX];   // W^T[c][r] is written at dst_off + c*ld_dst + dst_col + r (ld_dst 0 = rows)
+  int tstart[PACKT_MAX + 1];   // filled by the launcher: first 32x32 tile of each matrix
+};
+int launch_pack_transposed(PackTTable& t, void* wtdst, int w_f32, hipStream_t s);
+
 // out = LayerNorm(y) * gamma + beta over the last dim (eps 1e-5, biased variance); stats = {mean, rstd} per row.
 // y / out are activations of dtype `act_f32`; out32 (optional) receives an fp32 copy for user-visible features.
 int launch_ln_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,

@@ -65,6 +65,41 @@ __global__ __launch_bounds__(256) void pack_params_kernel(const PackTable t, voi
   }
 }
 
+// ------------------------------------------------------------------ transposed weight pack
+// one block = one 32x32 tile: coalesced fp32 reads along the source rows, LDS transpose, coalesced writes along
+// the destination rows (= source columns)
+template <bool DST_F32>
+__global__ __launch_bounds__(256) void pack_transposed_kernel(const PackTTable t, void* wtdst) {
+  __shared__ float tile[32][33];
+  const auto& T = karg<PackTTable>();
+  int m = 0;
+  for (int i = 1; i < PACKT_MAX; ++i)
+    if (i < T.nmat && (int)blockIdx.x >= T.tstart[i]) m = i;
+  const int rows = T.rows[m], cols = T.cols[m];
+  const int tiles_c = (cols + 31) / 32;
+  const int local = blockIdx.x - T.tstart[m];
+  const int r0 = (local / tiles_c) * 32, c0 = (local % tiles_c) * 32;
+  const float* src = (const float*)T.src[m];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;   // destination row = source column
+    if (c < cols && r < rows) {
+      const int ldd = T.ld_dst[m] ? T.ld_dst[m] : rows;
+      const long long o = T.dst_off[m] + (long long)c * ldd + T.dst_col[m] + r;
+      const float v = tile[tx][ty + 8 * i];
+      if constexpr (DST_F32) reinterpret_cast<float*>(wtdst)[o] = v;
+      else reinterpret_cast<bf16_t*>(wtdst)[o] = f2bf(v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm forward
 constexpr int LN_MAX_VEC = 4;  // N <= 4 * 256 = 1024
 
@@ -249,6 +284,20 @@ int launch_pack_params(PackTable& t, void* wdst, int w_f32, float* vdst, hipStre
   const int grid = (chunks + 1023) / 1024;
   if (w_f32) hipLaunchKernelGGL(pack_params_kernel<true>, dim3(grid), dim3(256), 0, s, t, wdst, vdst);
   else hipLaunchKernelGGL(pack_params_kernel<false>, dim3(grid), dim3(256), 0, s, t, wdst, vdst);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_pack_transposed(PackTTable& t, void* wtdst, int w_f32, hipStream_t s) {
+  MMDEER_CHECK(t.nmat >= 1 && t.nmat <= PACKT_MAX, "pack_transposed: bad matrix count %d", t.nmat);
+  int tiles = 0;
+  for (int i = 0; i < t.nmat; ++i) {
+    t.tstart[i] = tiles;
+    tiles += ((t.rows[i] + 31) / 32) * ((t.cols[i] + 31) / 32);
+  }
+  for (int i = t.nmat; i <= PACKT_MAX; ++i) t.tstart[i] = tiles;
+  if (w_f32) hipLaunchKernelGGL(pack_transposed_kernel<true>, dim3(tiles), dim3(256), 0, s, t, wtdst);
+  else hipLaunchKernelGGL(pack_transposed_kernel<false>, dim3(tiles), dim3(256), 0, s, t, wtdst);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
