@@ -18,6 +18,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # see mmdeer/_lib.py
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

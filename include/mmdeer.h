@@ -69,7 +69,7 @@ typedef struct mmdeer_loss_cfg {
 typedef struct mmdeer_forward_args {
   int32_t batch;
   int32_t compute_f32;      /* 1: exact-fp32 MFMA path (parity config); 0: bf16 MFMA, fp32 accumulate */
-  int32_t training;         /* 1: dropout active (counter-based Philox keyed by seed/offset) */
+  int32_t training;         /* 1: dropout active (counter-based hash keyed by seed/offset) */
   int32_t inputs_bf16;      /* 0: audio/video/text are fp32; 1: bf16 */
   int32_t repack;           /* 1: parameters changed since the last call with this workspace */
   float dropout_p;

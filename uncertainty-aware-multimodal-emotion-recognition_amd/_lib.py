@@ -14,7 +14,11 @@ from typing import Optional
 # torch must be imported BEFORE libmmdeer_hip.so is dlopen'ed: the PyTorch-ROCm wheel ships its own
 # libamdhip64.so, and the library has to bind to that already-loaded runtime (one HIP runtime per process,
 # shared streams and device pointers) rather than pull in a second copy from /opt/rocm/lib.
-import torch  # noqa: F401
+# kernel arguments in device memory: a kernarg fetch from host memory costs a PCIe round trip per dependent
+# scalar load (measured 8.7k vs 2.4k cycles of kernel setup, 0.69 vs 0.53 ms per train step).  Read at HIP init.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: F401,E402
 
 from . import build as _build
 

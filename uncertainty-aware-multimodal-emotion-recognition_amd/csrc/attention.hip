@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void tri_attn_fwd_kernel(const void* qkv, void
   if (j == 0) *reinterpret_cast<f32x4*>(probs + ((long long)b * 8 + h) * 4) = f32x4{p00, p01, p10, p11};
   float d00 = p00, d01 = p01, d10 = p10, d11 = p11;
   if (train) {
-    Philox4 r = drop_rand4(dc, SITE_TRI_ATTN, (unsigned)b, (unsigned)h);
+    Rand4 r = drop_rand4(dc, SITE_TRI_ATTN, (unsigned)b, (unsigned)h);
     d00 = r.x < dc.thresh ? p00 * dc.scale : 0.f;
     d01 = r.y < dc.thresh ? p01 * dc.scale : 0.f;
     d10 = r.z < dc.thresh ? p10 * dc.scale : 0.f;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void tri_attn_bwd_kernel(const void* qkv, cons
   const f32x4 p = *reinterpret_cast<const f32x4*>(probs + ((long long)b * 8 + h) * 4);
   float k00 = 1.f, k01 = 1.f, k10 = 1.f, k11 = 1.f;  // keep * 1/(1-p)
   if (train) {
-    Philox4 r = drop_rand4(dc, SITE_TRI_ATTN, (unsigned)b, (unsigned)h);
+    Rand4 r = drop_rand4(dc, SITE_TRI_ATTN, (unsigned)b, (unsigned)h);
     k00 = r.x < dc.thresh ? dc.scale : 0.f; k01 = r.y < dc.thresh ? dc.scale : 0.f;
     k10 = r.z < dc.thresh ? dc.scale : 0.f; k11 = r.w < dc.thresh ? dc.scale : 0.f;
   }

@@ -29,28 +29,18 @@ template <> struct Elem<bf16_t> {
   static constexpr int KT = 64;
 };
 
-// ---------------------------------------------------------------- Philox4x32-10
-// Counter-based dropout: the keep decision of element (site, row, col) is a pure
-// function of (seed, offset, site, row, col) so the backward pass and the test
-// harness regenerate masks instead of storing them.
-typedef unsigned Philox4 __attribute__((ext_vector_type(4)));
+// ---------------------------------------------------------------- counter-based dropout RNG
+// The keep decision of element (site, row, col) is a pure function of (seed, offset, site, row, col), so the
+// backward pass and the test harness regenerate masks instead of storing them.  One 32-bit avalanche hash
+// (the "lowbias32" finaliser, 2 multiplies) per element over a per-(seed, offset, site) key: ~9 VALU ops per
+// element.  (A Philox4x32-10 block per 4 elements cost ~100 ops and doubled the GEMM epilogue.)
+typedef unsigned Rand4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ __forceinline__ unsigned mulhi32(unsigned a, unsigned b) {
-  return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32);
-}
-
-__host__ __device__ __forceinline__ Philox4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
-                                                          unsigned k0, unsigned k1) {
-  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    unsigned h0 = mulhi32(M0, c0), l0 = M0 * c0;
-    unsigned h1 = mulhi32(M1, c2), l1 = M1 * c2;
-    unsigned n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-    k0 += W0; k1 += W1;
-  }
-  return Philox4{c0, c1, c2, c3};
+__host__ __device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
 }
 
 struct DropCtx {
@@ -60,17 +50,25 @@ struct DropCtx {
   float scale;                // 1 / (1 - p)
 };
 
-// 4 keep-randoms for columns [4*cq, 4*cq+3] of `row` at dropout site `site`.
-__host__ __device__ __forceinline__ Philox4 drop_rand4(const DropCtx& d, int site, unsigned row, unsigned cq) {
-  return philox4x32_10(row, cq, (unsigned)site ^ (unsigned)(d.offset << 8), (unsigned)(d.offset >> 24),
-                       (unsigned)d.seed, (unsigned)(d.seed >> 32));
+__host__ __device__ __forceinline__ unsigned drop_key(const DropCtx& d, int site) {
+  unsigned k = mix32((unsigned)d.seed ^ 0x9E3779B9u);
+  k = mix32(k ^ (unsigned)(d.seed >> 32));
+  k = mix32(k ^ (unsigned)d.offset);
+  k = mix32(k ^ (unsigned)(d.offset >> 32) ^ ((unsigned)site * 0x85EBCA6Bu));
+  return k;
+}
+__host__ __device__ __forceinline__ unsigned drop_rand1(unsigned key, unsigned row, unsigned c) {
+  return mix32((row * 0x9E3779B1u) ^ (c * 0x85EBCA77u) ^ key);
+}
+// 4 keep-randoms for columns [4*cq, 4*cq+3] of `row` at dropout site `site`
+__host__ __device__ __forceinline__ Rand4 drop_rand4(const DropCtx& d, int site, unsigned row, unsigned cq) {
+  const unsigned key = drop_key(d, site), r = row * 0x9E3779B1u;
+  return Rand4{mix32(r ^ ((4 * cq) * 0x85EBCA77u) ^ key), mix32(r ^ ((4 * cq + 1) * 0x85EBCA77u) ^ key),
+               mix32(r ^ ((4 * cq + 2) * 0x85EBCA77u) ^ key), mix32(r ^ ((4 * cq + 3) * 0x85EBCA77u) ^ key)};
 }
 // keep decision of one element; `c` is the column index already shifted by the site's granularity
 __host__ __device__ __forceinline__ bool drop_keep(const DropCtx& d, int site, unsigned row, unsigned c) {
-  Philox4 r = drop_rand4(d, site, row, c >> 2);
-  const unsigned e = c & 3;
-  const unsigned x = e == 0 ? r.x : (e == 1 ? r.y : (e == 2 ? r.z : r.w));
-  return x < d.thresh;
+  return drop_rand1(drop_key(d, site), row, c) < d.thresh;
 }
 
 // dropout sites (one id per nn.Dropout / attention-dropout call site of the path)

@@ -10,11 +10,17 @@ int gemm_dispatch_nt(const GemmGroup& g, int total, int compute_f32, GemmTile ti
 int gemm_dispatch_nx(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
 int gemm_dispatch_tt(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
 int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStream_t s);
+int gemm_dispatch_tt_glds(const GemmGroup& g, int total, int ring, hipStream_t s);
 
 namespace {
 int env_xcd() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MMDEER_XCD"); v = e ? atoi(e) : 1; }
+  return v;
+}
+int env_ttring() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_TTRING"); v = e ? atoi(e) : 2; }
   return v;
 }
 // MMDEER_GLDS=0 forces the register-staged kernel for NT problems (A/B comparison, debugging)
@@ -101,11 +107,16 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t 
     int rc;
     // LDS-DMA fast path: bf16 NT problems whose operands are 16-byte aligned, row-contiguous and K % 64 == 0
     // (128x128 tiles keep the register-staged kernel: its 74 KiB of LDS allow two workgroups per CU, the ring would not)
-    bool glds = !ta && !tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 && env_glds() && !sub.stamps &&
+    bool glds = !ta && !tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 && env_glds() &&
                 tile != TILE_128x128;
     for (int j = 0; j < sub.nprob && glds; ++j)
       glds = sub.p[j].K % 64 == 0 && sub.p[j].splitk == 1 && !sub.p[j].bias_grad;
-    if (glds) rc = gemm_dispatch_nt_glds(sub, total, tile, stream);
+    // LDS-DMA + transposed-read path for weight gradients (both operands stored [K][cols])
+    bool ttg = ta && tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 && env_glds() && !sub.stamps &&
+               tile == TILE_128x128;
+    for (int j = 0; j < sub.nprob && ttg; ++j) ttg = sub.p[j].K % 64 == 0;
+    if (ttg) rc = gemm_dispatch_tt_glds(sub, total, env_ttring(), stream);
+    else if (glds) rc = gemm_dispatch_nt_glds(sub, total, tile, stream);
     else if (!ta && !tb) rc = gemm_dispatch_nt(sub, total, compute_f32, tile, am, bm, stream);
     else if (!ta && tb) rc = gemm_dispatch_nx(sub, total, compute_f32, tile, am, bm, stream);
     else if (ta && tb) rc = gemm_dispatch_tt(sub, total, compute_f32, tile, am, bm, stream);
