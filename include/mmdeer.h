@@ -141,7 +141,7 @@ typedef struct mmdeer_gemm_args {
   const void* A; const void* W; void* C; const float* bias; float* bias_grad; const void* Y;
   int32_t M, N, K, lda, ldw, ldc, ldy;
   int32_t a_f32, w_f32, c_f32, y_f32, trans_a, trans_w, relu, accumulate;
-  int32_t compute_f32, tile;            /* tile: 0 = 64x64, 1 = 128x64, 2 = 128x128, -1 = auto */
+  int32_t compute_f32, tile;            /* tile: 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 256x256 (bf16 dW), -1 = auto */
   int32_t drop_site, drop_shift, regen_site;
   float dropout_p, mask_scale;
   uint64_t seed, offset;

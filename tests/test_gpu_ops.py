@@ -115,8 +115,9 @@ def test_gemm_dx(compute_f32, tile, M, N, K):
 
 @pytest.mark.parametrize("compute_f32", [1, 0])
 @pytest.mark.parametrize("splitk", [1, 3, 8])
-@pytest.mark.parametrize("tile", [0, 1, 2])
-@pytest.mark.parametrize("Bt,Nl,Kl", [(64, 128, 64), (100, 256, 84), (7, 64, 256), (513, 384, 256), (1100, 64, 128)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("Bt,Nl,Kl", [(64, 128, 64), (100, 256, 84), (7, 64, 256), (513, 384, 256), (1100, 64, 128),
+                                      (1024, 512, 768), (2048, 384, 256), (96, 64, 128), (4096, 520, 264)])
 def test_gemm_dw_and_bias_grad(compute_f32, splitk, tile, Bt, Nl, Kl):
     """dW[Nl,Kl] = dY[Bt,Nl]^T X[Bt,Kl] and db = column sums of dY (both operands transposed by the loader)."""
     dY, X = rnd(Bt, Nl, seed=10), rnd(Bt, Kl, seed=11)

@@ -5,10 +5,15 @@ import glob
 import os
 import sys
 
-files = sorted(glob.glob("gpurun_out/prof/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
+# usage: prof_summary.py [steps | profile_dir] [steps]
+root = "gpurun_out/prof"
+args = sys.argv[1:]
+if args and not args[0].isdigit():
+    root = args.pop(0)
+files = sorted(glob.glob(root + "/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
 if not files:
     sys.exit("no kernel_stats.csv")
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+steps = int(args[0]) if args else 25
 rows = list(csv.DictReader(open(files[-1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"{files[-1]}: GPU kernel time per step = {tot / steps / 1e3:.1f} us ({steps} steps)")

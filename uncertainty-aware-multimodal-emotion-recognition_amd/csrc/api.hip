@@ -128,14 +128,16 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset) {
 }
 
 // target number of K-tiles per split-K slice of a weight-gradient problem (MMDEER_KSTEPS overrides)
-int ksteps_target() {
+// in units of 64 batch rows.  Defaults: bf16 (256x256 LDS-DMA kernel) 16 = 1024 rows per slice -- the slab
+// traffic, 4 B per parameter per slice written and read back, is what limits the slice count; fp32 8.
+int ksteps_target(int f32) {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("MMDEER_KSTEPS");
-    v = e ? atoi(e) : 8;
-    if (v < 1) v = 1;
+    v = e ? atoi(e) : 0;
+    if (v < 0) v = 0;
   }
-  return v;
+  return v > 0 ? v : (f32 ? 8 : 16);
 }
 
 int forced_tile() {
@@ -150,7 +152,7 @@ int forced_tile() {
 // smallest tile that still gives the chip >= ~2 workgroups per CU; otherwise the largest tile count wins
 GemmTile pick_tile(const GemmGroup& g) {
   const int ft = forced_tile();
-  if (ft >= 0 && ft <= 2) return (GemmTile)ft;
+  if (ft >= 0 && ft <= 3) return (GemmTile)ft;
   static const int bm[3] = {64, 128, 128}, bn[3] = {64, 64, 128};
   long long tiles[3];
   for (int t = 0; t < 3; ++t) {
@@ -162,7 +164,7 @@ GemmTile pick_tile(const GemmGroup& g) {
   }
   // weight-gradient groups (both operands transposed): the strided loads and the packing LDS store cost the same per
   // K-tile whatever the tile size, so the largest tile wins; split-K supplies the parallelism
-  if (g.p[0].trans_a) return TILE_128x128;
+  if (g.p[0].trans_a) return TILE_256x256;   // (falls back to 128x128 per sub-group where the kernel does not apply)
   if (tiles[2] >= 512) return TILE_128x128;
   if (tiles[1] >= 512) return TILE_128x64;
   return TILE_64x64;
@@ -223,7 +225,8 @@ struct Exec {
   // (re)derive the split-K fields from p.K and the final destinations p.C / p.bias_grad
   void set_split(GemmProblem& p, float* grads) const {
     const int nk = gemm_ktiles(p.K, f32);
-    int sk = (nk + ksteps_target() - 1) / ksteps_target();
+    const int kst = ksteps_target(f32);
+    int sk = (nk + kst - 1) / kst;
     if (sk > SPLITK_MAX) sk = SPLITK_MAX;
     if (sk < 1) sk = 1;
     p.splitk = sk;
@@ -437,10 +440,9 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   MMDEER_HIP(hipMemsetAsync(G + kParams[P_AIN_W].off, 0, sizeof(float) * 2 * INTER * INTER, s));
   MMDEER_HIP(hipMemsetAsync(G + kParams[P_AIN_B].off, 0, sizeof(float) * 2 * INTER, s));
 
-  // Backward = a chain of dX GEMMs (each M = batch rows, plenty of tiles) and, per gradient bucket, ONE grouped
-  // launch of all the bucket's weight-gradient problems (few output tiles each, reduction over the batch, split
-  // over K into slabs) followed by one deterministic slab reduction.  A bucket's event is recorded right after
-  // its reduction so the data-parallel all-reduce of that bucket overlaps the rest of the chain.
+  // Backward = a chain of dX GEMMs (each M = batch rows, plenty of tiles) and ONE grouped launch of all
+  // weight-gradient problems (few output tiles each, reduction over the batch, split over K into slabs) followed by
+  // one deterministic slab reduction.
   auto reduce_head = [&](ReduceTable& t) {
     int k = t.nseg;
     t.src[k] = L.part_w3; t.dst[k] = G + kParams[P_EV2_W].off; t.nparts[k] = nblk; t.n[k] = 768; t.stride[k] = 768; ++k;
@@ -454,11 +456,12 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     t.src[k] = part; t.dst[k] = G + kParams[pidG].off; t.nparts[k] = npl; t.n[k] = 2 * N; t.stride[k] = 2 * N; ++k;
     t.nseg = k;
   };
-  auto run_dw_bucket = [&](GemmGroup& g, ReduceTable& t) -> int {
-    if (X.run(g) != 0) return -1;
-    for (int i = 0; i < g.nprob; ++i) Exec::add_slab_segments(t, g.p[i], L.slab, G);
-    return launch_reduce_partials(t, s);
-  };
+  // All weight-gradient problems are collected and run as ONE launch after the chain: a bucket on its own has
+  // only 30-180 workgroups of 16-32 sequential K-steps, i.e. each of three launches took one workgroup's latency
+  // (~35-40 us) on a mostly idle chip; together they fill it once.
+  GemmGroup dwg{};
+  ReduceTable rt{};
+  auto add_dw = [&](const GemmProblem& q) { dwg.p[dwg.nprob++] = q; };
 
   // ================= bucket 0: DEER head =================
   // B1: last head layer + NIG activations (+ loss gradient)
@@ -480,21 +483,16 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   TRY(X.run1(X.dx(L.dh2, HID, P_FP1_W, L.dh1, HID, B, L.h1, HID)));
   TRY(X.run1(X.dx(L.dh1, HID, P_FP0_W, L.dfused, FUS, B, nullptr, 0)));
   {
-    GemmGroup g{};
-    g.nprob = 4;
     GemmProblem q = X.dw(L.dz2, 3 * EV2, L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, G, B);
     q.batch = 3; q.sA = EV2; q.sB = EV1; q.sC = (long long)EV2 * EV1; q.sBiasGrad = EV2;
-    g.p[0] = q;
+    add_dw(q);
     GemmProblem r = X.dw(L.de1, 3 * EV1, L.h2, f32, HID, P_EV0_W, P_EV0_B, G, B);
     r.M = 3 * EV1;
-    g.p[1] = r;
-    g.p[2] = X.dw(L.dh2, HID, L.h1, f32, HID, P_FP1_W, P_FP1_B, G, B);
-    g.p[3] = X.dw(L.dh1, HID, L.fused, f32, FUS, P_FP0_W, P_FP0_B, G, B);
-    ReduceTable t{};
-    reduce_head(t);
-    TRY(run_dw_bucket(g, t));
+    add_dw(r);
+    add_dw(X.dw(L.dh2, HID, L.h1, f32, HID, P_FP1_W, P_FP1_B, G, B));
+    add_dw(X.dw(L.dh1, HID, L.fused, f32, FUS, P_FP0_W, P_FP0_B, G, B));
+    reduce_head(rt);
   }
-  if (a->bucket_events[0]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[0], s));
 
   // ================= bucket 1: output_projection + trimodal fusion =================
   TRY(launch_ln_bwd(L.dfused, L.y_o1, L.mean_o1, L.rstd_o1, X.V(P_OP_G), L.dz_o1, L.part_ln_o1, B, FUS, f32, X.mask_scale, s));
@@ -506,20 +504,15 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   TRY(X.run1(X.dx(L.dqkv, 3 * FUS, P_TIN_W, L.dxtok, FUS, 2 * B, nullptr, 0)));  // in_proj
   TRY(X.run1(X.dx(L.dxtok, 2 * FUS, P_AVP_W, L.dav, INTER, B, nullptr, 0)));     // token 0 -> audiovisual features
   {
-    GemmGroup g{};
-    g.nprob = 6;
-    g.p[0] = X.dw(L.dz_o1, FUS, L.tri, f32, FUS, P_OP_W, P_OP_B, G, B);
-    g.p[1] = X.dw(L.dz_t3, FUS, L.pool, f32, FUS, P_TFF_W, P_TFF_B, G, B);
-    g.p[2] = X.dw(L.dpool, FUS, L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, G, B);
-    g.p[3] = X.dw(L.dqkv, 3 * FUS, L.xtok, f32, FUS, P_TIN_W, P_TIN_B, G, 2 * B);
-    g.p[4] = X.dw(L.dxtok, 2 * FUS, L.av, f32, INTER, P_AVP_W, P_AVP_B, G, B);                          // token 0
-    g.p[5] = X.dw(L.dxtok + (size_t)FUS * es, 2 * FUS, a->text, in_f32, TXT, P_TXT_W, P_TXT_B, G, B);   // token 1
-    ReduceTable t{};
-    reduce_ln(t, L.part_ln_o1, P_OP_G, FUS);
-    reduce_ln(t, L.part_ln_t3, P_TFF_G, FUS);
-    TRY(run_dw_bucket(g, t));
+    add_dw(X.dw(L.dz_o1, FUS, L.tri, f32, FUS, P_OP_W, P_OP_B, G, B));
+    add_dw(X.dw(L.dz_t3, FUS, L.pool, f32, FUS, P_TFF_W, P_TFF_B, G, B));
+    add_dw(X.dw(L.dpool, FUS, L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, G, B));
+    add_dw(X.dw(L.dqkv, 3 * FUS, L.xtok, f32, FUS, P_TIN_W, P_TIN_B, G, 2 * B));
+    add_dw(X.dw(L.dxtok, 2 * FUS, L.av, f32, INTER, P_AVP_W, P_AVP_B, G, B));                          // token 0
+    add_dw(X.dw(L.dxtok + (size_t)FUS * es, 2 * FUS, a->text, in_f32, TXT, P_TXT_W, P_TXT_B, G, B));   // token 1
+    reduce_ln(rt, L.part_ln_o1, P_OP_G, FUS);
+    reduce_ln(rt, L.part_ln_t3, P_TFF_G, FUS);
   }
-  if (a->bucket_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[1], s));
 
   // ================= bucket 2: audio-visual fusion =================
   TRY(launch_ln_bwd(L.dav, L.y_a2, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), L.dz_a2, L.part_ln_a2, B, INTER, f32, X.mask_scale, s));
@@ -544,23 +537,24 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     TRY(X.run1(p));
   }
   {
-    GemmGroup g{};
-    g.nprob = 5;
-    g.p[0] = X.dw(L.dz_a2, INTER, L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, G, B);
-    g.p[1] = X.dw(L.dcats, INTER, L.avv, f32, INTER, P_AOUT_W, P_AOUT_B, G, 2 * B);
+    add_dw(X.dw(L.dz_a2, INTER, L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, G, B));
+    add_dw(X.dw(L.dcats, INTER, L.avv, f32, INTER, P_AOUT_W, P_AOUT_B, G, 2 * B));
     GemmProblem q = X.dw(L.davv, INTER, L.avin, f32, INTER, P_AIN_W, P_AIN_B, G, 2 * B);
     q.C = G + kParams[P_AIN_W].off + 2 * INTER * INTER;
     q.bias_grad = G + kParams[P_AIN_B].off + 2 * INTER;
     q.M = INTER;
     X.set_split(q, G);
-    g.p[2] = q;
-    g.p[3] = X.dw(L.davin, INTER, a->video, in_f32, VID, P_VID_W, P_VID_B, G, B);                                  // rows [0,B)
-    g.p[4] = X.dw(L.davin + (size_t)B * INTER * es, INTER, a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, G, B);        // rows [B,2B)
-    ReduceTable t{};
-    reduce_ln(t, L.part_ln_a2, P_AVF_G, INTER);
-    TRY(run_dw_bucket(g, t));
+    add_dw(q);
+    add_dw(X.dw(L.davin, INTER, a->video, in_f32, VID, P_VID_W, P_VID_B, G, B));                                  // rows [0,B)
+    add_dw(X.dw(L.davin + (size_t)B * INTER * es, INTER, a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, G, B));        // rows [B,2B)
+    reduce_ln(rt, L.part_ln_a2, P_AVF_G, INTER);
   }
-  if (a->bucket_events[2]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[2], s));
+  // ---- all weight gradients: one grouped split-K launch + one deterministic fold of every partial slab
+  TRY(X.run(dwg));
+  for (int i = 0; i < dwg.nprob; ++i) Exec::add_slab_segments(rt, dwg.p[i], L.slab, G);
+  TRY(launch_reduce_partials(rt, s));
+  for (int b = 0; b < 3; ++b)
+    if (a->bucket_events[b]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[b], s));
   return 0;
 }
 
@@ -587,7 +581,7 @@ int mmdeer_gemm(const mmdeer_gemm_args* a) {
   }
   g.drop = make_drop(a->dropout_p, a->seed, a->offset);
   g.stamps = reinterpret_cast<unsigned long long*>(a->debug);
-  GemmTile t = (a->tile >= 0 && a->tile <= 2) ? (GemmTile)a->tile : pick_tile(g);
+  GemmTile t = (a->tile >= 0 && a->tile <= 3) ? (GemmTile)a->tile : pick_tile(g);
   TRY(launch_gemm_group(g, a->compute_f32 ? 1 : 0, t, (hipStream_t)a->stream));
   if (g.p[0].splitk > 1) {   // fold the K-slices into C (and bias_grad)
     ReduceTable rt{};

@@ -42,7 +42,7 @@ struct GemmProblem {
 
 enum SrcMode { SRC_F32 = 0, SRC_BF16_V16 = 1, SRC_BF16_V8 = 2 };
 
-constexpr int GEMM_MAX_PROBLEMS = 6;
+constexpr int GEMM_MAX_PROBLEMS = 16;   // all weight-gradient problems of a backward pass fit one launch
 
 struct GemmGroup {
   unsigned long long* stamps;   // diagnostic builds (-DMMDEER_STAMPS) only: s_memtime samples of workgroup 0; else null
@@ -53,7 +53,7 @@ struct GemmGroup {
   GemmProblem p[GEMM_MAX_PROBLEMS];
 };
 
-enum GemmTile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2 };
+enum GemmTile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3 };   // 256x256: bf16 weight gradients only
 
 // compute_f32 = 1: fp32 operands in LDS, v_mfma_f32_16x16x4_f32 (exact fp32); 0: bf16 operands, v_mfma_f32_16x16x32_bf16.
 // Enqueues on `stream`, never synchronises.  Returns 0 / -1 (message via mmdeer_last_error()).

@@ -11,6 +11,7 @@ int gemm_dispatch_nx(const GemmGroup& g, int total, int compute_f32, GemmTile ti
 int gemm_dispatch_tt(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
 int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStream_t s);
 int gemm_dispatch_tt_glds(const GemmGroup& g, int total, int ring, hipStream_t s);
+int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s);
 
 namespace {
 int env_xcd() {
@@ -40,11 +41,11 @@ void gemm_problem_defaults(GemmProblem& p) {
   p.mask_scale = 1.f;
 }
 
-int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t stream) {
-  static const int bm_of[3] = {64, 128, 128}, bn_of[3] = {64, 64, 128};
+int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStream_t stream) {
+  static const int bm_of[4] = {64, 128, 128, 256}, bn_of[4] = {64, 64, 128, 256};
   MMDEER_CHECK(g.nprob >= 1 && g.nprob <= GEMM_MAX_PROBLEMS, "gemm: bad problem count %d", g.nprob);
+  MMDEER_CHECK((int)tile_req >= 0 && (int)tile_req <= 3, "gemm: bad tile id %d", (int)tile_req);
   g.xcd_remap = env_xcd();
-  const int BM = bm_of[tile], BN = bn_of[tile];
   const int ta = g.p[0].trans_a ? 1 : 0, tb = g.p[0].trans_b ? 1 : 0;
   for (int i = 0; i < g.nprob; ++i) {
     GemmProblem& p = g.p[i];
@@ -80,12 +81,10 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t 
       p.a_mode = p.a_f32 ? SRC_F32 : (av16 ? SRC_BF16_V16 : SRC_BF16_V8);
       p.b_mode = p.b_f32 ? SRC_F32 : (bv16 ? SRC_BF16_V16 : SRC_BF16_V8);
     }
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
   }
   // One launch per distinct (A mode, B mode) pair: the kernels are specialised on the pair so that their K loop
   // has no data-dependent control flow.  Most groups are homogeneous (one launch).
-  bool done[GEMM_MAX_PROBLEMS] = {false, false, false, false, false, false};
+  bool done[GEMM_MAX_PROBLEMS] = {};
   for (int i = 0; i < g.nprob; ++i) {
     if (done[i]) continue;
     GemmGroup sub{};
@@ -93,14 +92,28 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t 
     sub.xcd_remap = g.xcd_remap;
     sub.drop = g.drop;
     const int am = g.p[i].a_mode, bm = g.p[i].b_mode;
-    int total = 0;
     for (int j = i; j < g.nprob; ++j) {
       if (done[j] || g.p[j].a_mode != am || g.p[j].b_mode != bm) continue;
       done[j] = true;
-      sub.p[sub.nprob] = g.p[j];
-      sub.tile_start[sub.nprob] = total;
-      total += g.p[j].tiles_m * g.p[j].tiles_n * g.p[j].batch * g.p[j].splitk;
-      ++sub.nprob;
+      sub.p[sub.nprob++] = g.p[j];
+    }
+    // 256x256 tiles exist only as the LDS-DMA weight-gradient kernel; anything else of such a group runs 128x128
+    bool tt256 = tile_req == TILE_256x256 && ta && tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 &&
+                 env_glds();
+    for (int j = 0; j < sub.nprob && tt256; ++j) {
+      const GemmProblem& q = sub.p[j];
+      tt256 = q.K % 32 == 0 && q.c_f32 && !q.bias && !q.relu && !q.Y && q.drop_site < 0 && q.regen_site < 0 &&
+              (uintptr_t)q.C % 16 == 0 && q.sC % 4 == 0 && (q.splitk == 1 || ((uintptr_t)q.slab_c % 16 == 0 && q.slab_stride % 4 == 0));
+    }
+    const GemmTile tile = tt256 ? TILE_256x256 : (tile_req == TILE_256x256 ? TILE_128x128 : tile_req);
+    const int BM = bm_of[tile], BN = bn_of[tile];
+    int total = 0;
+    for (int j = 0; j < sub.nprob; ++j) {
+      GemmProblem& q = sub.p[j];
+      q.tiles_m = (q.M + BM - 1) / BM;
+      q.tiles_n = (q.N + BN - 1) / BN;
+      sub.tile_start[j] = total;
+      total += q.tiles_m * q.tiles_n * q.batch * q.splitk;
     }
     for (int j = sub.nprob; j <= GEMM_MAX_PROBLEMS; ++j) sub.tile_start[j] = total;
     if (total == 0) continue;  // empty batch: nothing to do
@@ -115,7 +128,8 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t 
     bool ttg = ta && tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 && env_glds() && !sub.stamps &&
                tile == TILE_128x128;
     for (int j = 0; j < sub.nprob && ttg; ++j) ttg = sub.p[j].K % 64 == 0;
-    if (ttg) rc = gemm_dispatch_tt_glds(sub, total, env_ttring(), stream);
+    if (tt256) rc = gemm_dispatch_tt256(sub, total, stream);
+    else if (ttg) rc = gemm_dispatch_tt_glds(sub, total, env_ttring(), stream);
     else if (glds) rc = gemm_dispatch_nt_glds(sub, total, tile, stream);
     else if (!ta && !tb) rc = gemm_dispatch_nt(sub, total, compute_f32, tile, am, bm, stream);
     else if (!ta && tb) rc = gemm_dispatch_nx(sub, total, compute_f32, tile, am, bm, stream);

@@ -1,0 +1,259 @@
+// Weight-gradient GEMM with 256x256 tiles:  C[M,N] = sum_k A[k][m] * B[k][n]  (A = dY stored [K][M], B = X stored
+// [K][N], K = batch rows), bf16 operands, fp32 result / split-K slabs.
+//
+// Why this tile: the operands of a weight gradient are activations (tens of MB per layer), served from the Infinity
+// Cache / L2 at 14-30 B/clk per CU.  A 128x128 tile moves 32 B of operand per 1 Ki MAC and the 128x128 kernel ran at
+// the cache's byte rate (9.6 TB/s chip-wide, ~4000 cycles per 64-deep K-tile); 256x256 halves the bytes per MAC.
+//
+// One workgroup = 8 waves (4 along M x 2 along N), each a 64x128 sub-tile = 4x8 MFMA 16x16x32 accumulators
+// (128 VGPRs).  K advances in 32-row stages (one MFMA k-step): a stage is two images of 32 rows x 512 B, copied AS
+// STORED by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB = 2 rows per instruction, 4 instructions per wave per
+// stage) into a 4-stage ring (128 KiB), two to three stages in flight.  The two waves of a SIMD work in opposite
+// phases (one issues MFMAs while the other reads fragments / issues DMA), see the loop.  Fragments are read with ds_read_b64_tr_b16 (the
+// hardware transposes a 4-row x 16-column block), two reads per fragment.  Swizzle: the 16-byte chunk at slot p of
+// image row r holds logical chunk p ^ f(r), f(r) = (((r >> 3) & 1) << 3) | ((r & 3) << 1), applied to the DMA source
+// address and to the read address alike: the 8 rows a half-wave reads in one LDS cycle land on 8 distinct 32-byte
+// bank groups.  Counted vmcnt + raw s_barrier as in gemm_glds.hip.
+#include "gemm_kernel.inc"
+
+namespace mmdeer {
+namespace {
+
+#ifdef MMDEER_STAMPS
+// diagnostic build: s_memtime stamps of wave 0 of workgroup 0 (placed only where lgkmcnt is already 0)
+#define TSTAMP(slot)                                                                       \
+  do {                                                                                     \
+    if (g.stamps && blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 128) {                 \
+      unsigned long long t_;                                                               \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+      g.stamps[slot] = t_;                                                                 \
+    }                                                                                      \
+  } while (0)
+#else
+#define TSTAMP(slot) do {} while (0)
+#endif
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Transposed LDS read as inline asm.  Through the builtin the compiler cannot tell the read from the LDS-DMA writes
+// in flight and drains vmcnt to 0 after every DMA issue (no prefetch left); asm reads are invisible to that pass, the
+// waits (vmcnt for the DMA, lgkmcnt for these reads) are placed by hand.
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_tr_read(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// s_waitcnt lgkmcnt(N) that the uses of the listed registers cannot be scheduled above
+template <int N>
+__device__ __forceinline__ void wait_lgkm(u32x2& a, u32x2& b, u32x2& c, u32x2& d, u32x2& e, u32x2& f, u32x2& g, u32x2& h) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
+  constexpr int BM = 256, BN = 256, KT = 32, NST = 4;
+  constexpr int TM = 4, TN = 8;                 // 16x16 accumulators per wave: 64 x 128
+  constexpr int ROWB = 512;                     // bytes per image row
+  constexpr int OPER = KT * ROWB, STAGE = 2 * OPER;
+  constexpr int LPT = 4;                        // DMA instructions per wave per stage
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+
+  int bid = blockIdx.x;
+  if (g.xcd_remap) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+    if (i < g.nprob && bid >= g.tile_start[i]) pi = i;
+  typedef const __attribute__((address_space(4))) unsigned char* karg_ptr;
+  karg_ptr kbase = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  const __attribute__((address_space(4))) GemmProblem& p =
+      *(const __attribute__((address_space(4))) GemmProblem*)(
+          kbase + __builtin_offsetof(GemmGroup, p) + (size_t)pi * sizeof(GemmProblem));
+  const int local = bid - g.tile_start[pi];
+  const int per_slice = p.tiles_m * p.tiles_n;
+  const int per_batch = per_slice * p.splitk;
+  const int z = local / per_batch;
+  const int rem_b = local - z * per_batch;
+  const int slice = rem_b / per_slice;
+  const int rem = rem_b - slice * per_slice;
+  const int tmb = rem / p.tiles_n, tnb = rem - tmb * p.tiles_n;
+  const int row0 = tmb * BM, col0 = tnb * BN;
+  const int M = p.M, N = p.N;
+  const int nk_all = p.K >> 5;   // K % 32 == 0 (checked by the launcher)
+  const int nk_per = (nk_all + p.splitk - 1) / p.splitk;
+  const int kt0 = slice * nk_per;
+  const int kt1 = (kt0 + nk_per < nk_all) ? kt0 + nk_per : nk_all;
+  const int nk = kt1 > kt0 ? kt1 - kt0 : 0;
+
+  // ---- DMA source pointers.  Piece 8j + wave of an operand image = rows 2(8j + wave) + (lane >> 5); lane l writes
+  //      slot (l & 31), so it fetches logical chunk (l & 31) ^ f(row).  f does not depend on j.  A chunk beyond the
+  //      operand's width reads column 0 instead (it only feeds outputs that are never stored).
+  const int rsub = lane >> 5;
+  const int fsw = (((wave >> 2) & 1) << 3) | ((((wave & 1) << 1) | rsub) << 1);
+  const int chunk = (lane & 31) ^ fsw;
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (long long)z * p.sA;
+  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B) + (long long)z * p.sB;
+  const long long lda = p.lda, ldb = p.ldb;
+  const long long krow = (long long)kt0 * KT + 2 * wave + rsub;
+  const int ca = row0 + chunk * 8, cb = col0 + chunk * 8;
+  const bf16_t* pa = Ab + krow * lda + (ca < M ? ca : 0);
+  const bf16_t* pb = Bb + krow * ldb + (cb < N ? cb : 0);
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    unsigned char* sa = lds + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + 16 * j * lda),
+                                       (__attribute__((address_space(3))) void*)(sa + j * 8192), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + 16 * j * ldb),
+                                       (__attribute__((address_space(3))) void*)(sa + OPER + j * 8192), 16, 0, 0);
+    pa += KT * lda;
+    pb += KT * ldb;
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dY over k: one extra MFMA per dY fragment against an all-ones fragment (every
+  // row of the product holds the sums), instead of ~70 VALU instructions per K-step on the critical MFMA phase
+  f32x4 bsum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // 8 x bf16(1.0)
+  const bool do_bsum = (p.bias_grad != nullptr) && (tnb == 0) && (wn == 0);
+
+  // ---- transposed-read addressing.  Within a 16-lane group lane 4q + pp supplies the address of block row q,
+  //      columns 4pp .. 4pp+3; the block of the k-step is rows 8 lg + {0..3} (first read) / + {4..7} (second).
+  //      Both rows share f, so one offset per fragment: logical chunk 2 c16 + (pp >> 1) -> slot 2 (c16 ^ h) + (pp >> 1).
+  const int q = (lane & 15) >> 2, pp = lane & 3;
+  const int h = ((lg & 1) << 2) | q;   // f(row) >> 1
+  const int lane_off = (8 * lg + q) * ROWB + (pp >> 1) * 16 + (pp & 1) * 8;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  unsigned offa[TM], offb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) offa[i] = lds_base + lane_off + (((wm * 4 + i) ^ h) * 32);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) offb[j] = lds_base + lane_off + (((wn * 8 + j) ^ h) * 32) + OPER;
+
+  // ---- ring + ping-pong.  A wave alternates a LOAD phase L(t) (DMA issue of tile t+3, fragment reads of tile t)
+  //      and an MFMA phase M(t), with a workgroup barrier after every phase.  Waves 4-7 run one phase behind waves
+  //      0-3, so while one half of the workgroup (one wave per SIMD) issues MFMAs the other half uses the LDS and
+  //      the DMA path.  Data validity: every wave ends L(t-1) by waiting for ITS pieces of tile t, so after the
+  //      barriers that separate it from any L(t) all pieces of tile t have landed; slot reuse: L(t) overwrites the
+  //      slot of tile t-1, which both halves finished reading at least one barrier earlier.
+  const bool second = wave >= 4;
+  TSTAMP(0);
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nk) issue(t);
+  if (nk > 2) wait_vm<LPT>();   // tiles 0 and 1 landed (tile 2 may be in flight)
+  else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  TSTAMP(1);
+  if (second) __builtin_amdgcn_s_barrier();
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    TSTAMP(8 + kt * 5);
+    // ---- L(kt): fragment reads of tile kt first (they only need the LDS), then the DMA of tile kt+3 into the slot
+    //      of tile kt-1 while the reads return
+    const unsigned so = stage * STAGE;
+    u32x2 al[TM], ah[TM], bl[TN], bh[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { al[i] = lds_tr_read<0>(offa[i] + so); ah[i] = lds_tr_read<4 * ROWB>(offa[i] + so); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { bl[j] = lds_tr_read<0>(offb[j] + so); bh[j] = lds_tr_read<4 * ROWB>(offb[j] + so); }
+    TSTAMP(8 + kt * 5 + 1);
+    if (kt + NST - 1 < nk) issue((stage + NST - 1) & (NST - 1));
+    wait_lgkm<0>(al[0], ah[0], al[1], ah[1], al[2], ah[2], al[3], ah[3]);
+    wait_lgkm<0>(bl[0], bh[0], bl[1], bh[1], bl[2], bh[2], bl[3], bh[3]);
+    wait_lgkm<0>(bl[4], bh[4], bl[5], bh[5], bl[6], bh[6], bl[7], bh[7]);
+    // own pieces of tile kt+1 landed; the tiles issued after it (kt+2, kt+3, where they exist) may be in flight
+    {
+      const int younger = nk - 2 - kt;   // tiles after kt+1
+      if (younger >= 2) wait_vm<2 * LPT>();
+      else if (younger == 1) wait_vm<LPT>();
+      else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    TSTAMP(8 + kt * 5 + 2);
+    // ---- M(kt): D[n][m] += X-fragment (rows n) x dY-fragment (cols m): a lane ends up with 4 consecutive n of one m
+    u32x4 fa[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = u32x4{al[i].x, al[i].y, ah[i].x, ah[i].y};
+    if (do_bsum) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) bsum[i] = mma_chunk<bf16_t>(ones, fa[i], bsum[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const u32x4 fb{bl[j].x, bl[j].y, bh[j].x, bh[j].y};
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i][j] = mma_chunk<bf16_t>(fb, fa[i], acc[i][j]);
+    }
+    TSTAMP(8 + kt * 5 + 3);
+    if (kt + 1 < nk) __builtin_amdgcn_s_barrier();
+    TSTAMP(8 + kt * 5 + 4);
+    stage = (stage + 1) & (NST - 1);
+  }
+  if (!second) __builtin_amdgcn_s_barrier();   // pairs with the extra barrier of waves 4-7
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  TSTAMP(2);
+
+  // ---- epilogue: accumulators straight to the fp32 destination.  acc[i][j] holds C[m][n..n+3] with m = the i-th
+  //      16-row block + li, n = the j-th 16-column block + 4 lg: one 16-byte store per accumulator.
+  const bool sliced = p.splitk > 1;
+  if (do_bsum) {
+    float* bg = sliced ? p.slab_b + (long long)slice * p.slab_stride : p.bias_grad;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = row0 + wm * 64 + i * 16 + li;
+      if (lg == 0 && r < M) bg[(long long)z * p.sBiasGrad + r] = bsum[i].x;
+    }
+  }
+  float* dst = (sliced ? p.slab_c + (long long)slice * p.slab_stride : reinterpret_cast<float*>(p.C)) + (long long)z * p.sC;
+  const long long ldc = p.ldc;
+  const bool accumulate = !sliced && p.accumulate;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = row0 + wm * 64 + i * 16 + li;
+    if (m >= M) continue;
+    float* rowp = dst + (long long)m * ldc + col0 + wn * 128 + 4 * lg;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (col0 + wn * 128 + j * 16 + 4 * lg >= N) continue;   // N % 4 == 0: a 4-column group is all in or all out
+      f32x4 v = acc[i][j];
+      f32x4* cp = reinterpret_cast<f32x4*>(rowp + j * 16);
+      if (accumulate) v += *cp;
+      *cp = v;
+    }
+  }
+  TSTAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSTAMP(4);
+}
+
+}  // namespace
+
+// caller guarantees: bf16 compute, trans_a = trans_b = 1, both operands bf16 with ld % 8 == 0 and 16-byte aligned,
+// K (the reduction = batch rows) % 32 == 0, fp32 C, no bias / ReLU / dropout / mask epilogue, tiles counted 256x256
+int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s) {
+  hipLaunchKernelGGL(gemm_tt256_kernel, dim3(total), dim3(512), 0, s, g);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mmdeer

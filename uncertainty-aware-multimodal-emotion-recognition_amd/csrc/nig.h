@@ -13,7 +13,8 @@ struct LossCfg {
   float task_w[3];                     // losses.py:256-259      (1, 1, 1)
 };
 
-inline int nig_nblocks(int B) { return B > 0 ? (B + 255) / 256 : 1; }
+constexpr int NIG_ROWS = 64;       // samples per workgroup of the head kernels (4 lanes per sample)
+inline int nig_nblocks(int B) { return B > 0 ? (B + NIG_ROWS - 1) / NIG_ROWS : 1; }
 
 // e2: [B,192] activations (post ReLU/dropout of the 128->64 layers, 3 heads side by side)
 // w3: packed weights [3][4][64] (activation dtype), b3: fp32, head stride `b3_stride` elements

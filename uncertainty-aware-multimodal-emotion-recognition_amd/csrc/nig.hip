@@ -1,7 +1,7 @@
 // NIG evidential head + MultiTaskDEERLoss kernels for gfx950.
 //
-// grid = (ceil(B/256), 3): blockIdx.y is the emotion dimension (valence / arousal / dominance), one thread
-// per sample.  All batch reductions are wave shuffles -> 4-wave LDS combine -> one partial slab per block; the
+// grid = (ceil(B/64), 3): blockIdx.y is the emotion dimension (valence / arousal / dominance), 4 lanes per
+// sample (one thread per sample, 256 per block, in the standalone loss kernels).  All batch reductions are wave shuffles -> 4-wave LDS combine -> one partial slab per block; the
 // consumer kernel sums the slabs in a fixed order, so loss values and gradients are run-to-run deterministic
 // and the ECE bin COUNTS are exact integers (bit-exact vs the reference's boolean masks for equal inputs).
 #include "nig.h"
@@ -107,6 +107,7 @@ __device__ __forceinline__ void compute_finals(const float* stats, int nblk, int
   for (int i = threadIdx.x; i < 3 * NIG_NSTAT; i += blockDim.x) {
     const int d = i / NIG_NSTAT, k = i - d * NIG_NSTAT;
     float acc = 0.f;
+#pragma unroll 8
     for (int p = 0; p < nblk; ++p) acc += stats[((long long)p * 3 + d) * NIG_NSTAT + k];
     gs[d][k] = acc;
   }
@@ -187,20 +188,24 @@ __device__ __forceinline__ f32x4 loss_grad(const Nig& n, const Terms& t, int d, 
   return g;
 }
 
+// ---- 4 lanes per (sample, dim): lane q of a quad owns columns [16q, 16q+16) of the 64-wide head input ----------
+// thread tid of block (bx, d): sample bx*64 + (tid >> 2), chunk q = tid & 3.  A quad reads 128 contiguous bytes
+// (bf16) of the activation row, so a wave's loads are whole 128-byte lines; the 4x16 weights of the chunk sit in
+// registers (the block's dimension d is uniform).
 template <bool F32>
-__device__ __forceinline__ void load_row64(const void* e2, long long idx, float (&x)[64]) {
+__device__ __forceinline__ void load_chunk16(const void* base, long long idx, float (&x)[16]) {
   if constexpr (F32) {
-    const float* p = reinterpret_cast<const float*>(e2) + idx;
+    const float* p = reinterpret_cast<const float*>(base) + idx;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * i);
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * i);
       x[4 * i] = a.x; x[4 * i + 1] = a.y; x[4 * i + 2] = a.z; x[4 * i + 3] = a.w;
     }
   } else {
-    const bf16_t* p = reinterpret_cast<const bf16_t*>(e2) + idx;
+    const bf16_t* p = reinterpret_cast<const bf16_t*>(base) + idx;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      u32x4 a = *reinterpret_cast<const u32x4*>(p + 8 * i);
+    for (int i = 0; i < 2; ++i) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(p + 8 * i);
       x[8 * i + 0] = __uint_as_float(a.x << 16); x[8 * i + 1] = __uint_as_float(a.x & 0xFFFF0000u);
       x[8 * i + 2] = __uint_as_float(a.y << 16); x[8 * i + 3] = __uint_as_float(a.y & 0xFFFF0000u);
       x[8 * i + 4] = __uint_as_float(a.z << 16); x[8 * i + 5] = __uint_as_float(a.z & 0xFFFF0000u);
@@ -210,35 +215,52 @@ __device__ __forceinline__ void load_row64(const void* e2, long long idx, float 
 }
 
 template <bool F32>
-__device__ __forceinline__ float wload(const void* w, int idx) {
-  if constexpr (F32) return reinterpret_cast<const float*>(w)[idx];
-  else return bf2f(reinterpret_cast<const bf16_t*>(w)[idx]);
+__device__ __forceinline__ void store_chunk16(void* base, long long idx, const float (&x)[16]) {
+  if constexpr (F32) {
+    float* p = reinterpret_cast<float*>(base) + idx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(p + 4 * i) = f32x4{x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
+  } else {
+    bf16_t* p = reinterpret_cast<bf16_t*>(base) + idx;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<u32x4*>(p + 8 * i) = u32x4{pack_bf2(x[8 * i], x[8 * i + 1]), pack_bf2(x[8 * i + 2], x[8 * i + 3]),
+                                                   pack_bf2(x[8 * i + 4], x[8 * i + 5]), pack_bf2(x[8 * i + 6], x[8 * i + 7])};
+  }
+}
+
+__device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lanes of a quad, result in every lane
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  return v;
 }
 
 // ------------------------------------------------------------------ forward (+ loss statistics)
 template <bool F32>
 __global__ __launch_bounds__(256) void nig_fwd_kernel(const void* e2, const void* w3, const float* b3, int b3_stride,
                                                       float* evid, float* nig_out, const float* targets, float* stats, int B) {
-  __shared__ float W[4][64];
-  const int d = blockIdx.y, tid = threadIdx.x;
-  W[tid >> 6][tid & 63] = wload<F32>(w3, d * 256 + tid);
-  __syncthreads();
-  const int b = blockIdx.x * 256 + tid;
+  const int d = blockIdx.y, tid = threadIdx.x, q = tid & 3;
+  const int b = blockIdx.x * NIG_ROWS + (tid >> 2);
   const bool active = b < B;
-  Nig n{0.f, 1.f, 2.f, 1.f};
-  if (active) {
-    float x[64];
-    load_row64<F32>(e2, (long long)b * 192 + d * 64, x);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int bc = active ? b : B - 1;   // inactive quads read a valid row, their results are discarded
+  float w[4][16];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      a0 = fmaf(x[j], W[0][j], a0); a1 = fmaf(x[j], W[1][j], a1);
-      a2 = fmaf(x[j], W[2][j], a2); a3 = fmaf(x[j], W[3][j], a3);
-    }
-    const float* bb = b3 + d * b3_stride;
-    const f32x4 ev{a0 + bb[0], a1 + bb[1], a2 + bb[2], a3 + bb[3]};
+  for (int c = 0; c < 4; ++c) load_chunk16<F32>(w3, d * 256 + c * 64 + q * 16, w[c]);
+  float x[16];
+  load_chunk16<F32>(e2, (long long)bc * 192 + d * 64 + q * 16, x);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    a0 = fmaf(x[j], w[0][j], a0); a1 = fmaf(x[j], w[1][j], a1);
+    a2 = fmaf(x[j], w[2][j], a2); a3 = fmaf(x[j], w[3][j], a3);
+  }
+  a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
+  const float* bb = b3 + d * b3_stride;
+  const f32x4 ev{a0 + bb[0], a1 + bb[1], a2 + bb[2], a3 + bb[3]};
+  const Nig n = nig_act(ev);
+  const bool writer = active && q == 0;
+  if (writer) {
     *reinterpret_cast<f32x4*>(evid + ((long long)b * 3 + d) * 4) = ev;
-    n = nig_act(ev);
     const float alea = n.beta / (n.alpha - 1.f);             // deer.py:96-98
     const float epis = n.beta / (n.nu * (n.alpha - 1.f));
     const long long o = (long long)b * 3 + d, plane = (long long)B * 3;
@@ -246,9 +268,9 @@ __global__ __launch_bounds__(256) void nig_fwd_kernel(const void* e2, const void
     nig_out[4 * plane + o] = alea; nig_out[5 * plane + o] = epis; nig_out[6 * plane + o] = alea + epis;
   }
   if (targets) {   // uniform across the grid
-    const float y = active ? targets[(long long)b * 3 + d] : 0.f;
+    const float y = targets[(long long)bc * 3 + d];
     const Terms t = loss_terms(n, y);
-    block_stats(t, active, stats + ((long long)blockIdx.x * 3 + d) * NIG_NSTAT);
+    block_stats(t, writer, stats + ((long long)blockIdx.x * 3 + d) * NIG_NSTAT);
   }
 }
 
@@ -259,79 +281,67 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
                                                       const float* galpha, const float* gbeta, float* devid, void* dz2,
                                                       float* partial_w, float* partial_b, float* loss_out,
                                                       int* bin_counts, int B, float mask_scale, LossCfg cfg) {
-  __shared__ float W[4][64];
   __shared__ float gs[3][NIG_NSTAT];
-  __shared__ f32x4 sdE[256];
+  __shared__ f32x4 sdE[NIG_ROWS];
   __shared__ Finals F;
-  __shared__ float xt[256][65];   // this block's e2 rows (fp32, +1 pad): reused by the weight-gradient partial
-  const int d = blockIdx.y, tid = threadIdx.x;
+  __shared__ float xt[NIG_ROWS][65];   // this block's e2 rows (fp32, +1 pad): reused by the weight-gradient partial
+  const int d = blockIdx.y, tid = threadIdx.x, q = tid & 3, s = tid >> 2;
   const int nblk = gridDim.x;
-  W[tid >> 6][tid & 63] = wload<F32>(w3, d * 256 + tid);
+  const int b = blockIdx.x * NIG_ROWS + s;
+  const bool active = b < B;
+  const int bc = active ? b : B - 1;
+  const long long o = (long long)bc * 3 + d;
+  // loads that do not depend on the loss finals go first
+  float w[4][16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) load_chunk16<F32>(w3, d * 256 + c * 64 + q * 16, w[c]);
+  float x[16];
+  load_chunk16<F32>(e2, (long long)bc * 192 + d * 64 + q * 16, x);
+  const f32x4 ev = *reinterpret_cast<const f32x4*>(evid + o * 4);
   const bool loss_mode = targets != nullptr;
+  f32x4 g{0.f, 0.f, 0.f, 0.f};
   if (loss_mode) {
+    const float y = targets[o];
     compute_finals(stats, nblk, B, cfg, F, gs);
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) write_loss(F, loss_out, bin_counts);
+    const Nig n = nig_act(ev);
+    const Terms t = loss_terms(n, y);
+    g = loss_grad(n, t, d, B, cfg, F);
+  } else {
+    if (gmu) g.x = gmu[o];
+    if (gnu) g.y = gnu[o];
+    if (galpha) g.z = galpha[o];
+    if (gbeta) g.w = gbeta[o];
   }
-  __syncthreads();
-  const int b = blockIdx.x * 256 + tid;
-  const bool active = b < B;
-  f32x4 dE{0.f, 0.f, 0.f, 0.f};
-  if (active) {
-    const long long o = (long long)b * 3 + d;
-    const f32x4 ev = *reinterpret_cast<const f32x4*>(evid + o * 4);
-    f32x4 g{0.f, 0.f, 0.f, 0.f};
-    if (loss_mode) {
-      const Nig n = nig_act(ev);
-      const Terms t = loss_terms(n, targets[o]);
-      g = loss_grad(n, t, d, B, cfg, F);
-    } else {
-      if (gmu) g.x = gmu[o];
-      if (gnu) g.y = gnu[o];
-      if (galpha) g.z = galpha[o];
-      if (gbeta) g.w = gbeta[o];
-    }
-    dE = f32x4{g.x, g.y * softplus_grad(ev.y), g.z * softplus_grad(ev.z), g.w * softplus_grad(ev.w)};
-    if (devid) *reinterpret_cast<f32x4*>(devid + o * 4) = dE;
-    // d e2 = dE . W3, masked by the ReLU/dropout of e2
-    float x[64];
-    load_row64<F32>(e2, (long long)b * 192 + d * 64, x);
+  f32x4 dE{g.x, g.y * softplus_grad(ev.y), g.z * softplus_grad(ev.z), g.w * softplus_grad(ev.w)};
+  if (!active) dE = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (active && q == 0 && devid) *reinterpret_cast<f32x4*>(devid + o * 4) = dE;
+  // d e2 = dE . W3, masked by the ReLU/dropout of e2
+  float dz[16];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      xt[tid][j] = x[j];
-      const float v = dE.x * W[0][j] + dE.y * W[1][j] + dE.z * W[2][j] + dE.w * W[3][j];
-      x[j] = x[j] > 0.f ? v * mask_scale : 0.f;
-    }
-    const long long zo = (long long)b * 192 + d * 64;
-    if constexpr (F32) {
-      float* p = reinterpret_cast<float*>(dz2) + zo;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(p + 4 * i) = f32x4{x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
-    } else {
-      bf16_t* p = reinterpret_cast<bf16_t*>(dz2) + zo;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<u32x4*>(p + 8 * i) = u32x4{pack_bf2(x[8 * i], x[8 * i + 1]), pack_bf2(x[8 * i + 2], x[8 * i + 3]),
-                                                     pack_bf2(x[8 * i + 4], x[8 * i + 5]), pack_bf2(x[8 * i + 6], x[8 * i + 7])};
-    }
+  for (int j = 0; j < 16; ++j) {
+    xt[s][q * 16 + j] = active ? x[j] : 0.f;
+    const float v = dE.x * w[0][j] + dE.y * w[1][j] + dE.z * w[2][j] + dE.w * w[3][j];
+    dz[j] = x[j] > 0.f ? v * mask_scale : 0.f;
   }
-  sdE[tid] = dE;
+  if (active) store_chunk16<F32>(dz2, (long long)b * 192 + d * 64 + q * 16, dz);
+  if (q == 0) sdE[s] = dE;
   __syncthreads();
   // weight-gradient partial of this block: dW3[d][c][j] = sum_s dE[s][c] * e2[s][d*64 + j]
   {
     const int c = tid >> 6, j = tid & 63;
-    const int rows = min(256, B - blockIdx.x * 256);
-    float acc = 0.f;
+    float acc0 = 0.f, acc1 = 0.f;
     const float* sde = reinterpret_cast<const float*>(sdE) + c;   // one wave = one c: broadcast reads
 #pragma unroll 8
-    for (int s = 0; s < rows; ++s) acc = fmaf(sde[4 * s], xt[s][j], acc);
-    partial_w[((long long)blockIdx.x * 3 + d) * 256 + tid] = acc;
-    if (tid < 4) {
+    for (int r = 0; r < NIG_ROWS; r += 2) {
+      acc0 = fmaf(sde[4 * r], xt[r][j], acc0);
+      acc1 = fmaf(sde[4 * r + 4], xt[r + 1][j], acc1);
+    }
+    partial_w[((long long)blockIdx.x * 3 + d) * 256 + tid] = acc0 + acc1;
+    if (j < 1) {   // lane 0 of wave c: bias-gradient partial
       float bs = 0.f;
-      for (int s = 0; s < rows; ++s) {
-        const f32x4 e = sdE[s];
-        bs += tid == 0 ? e.x : (tid == 1 ? e.y : (tid == 2 ? e.z : e.w));
-      }
-      partial_b[((long long)blockIdx.x * 3 + d) * 4 + tid] = bs;
+      for (int r = 0; r < NIG_ROWS; ++r) bs += sde[4 * r];
+      partial_b[((long long)blockIdx.x * 3 + d) * 4 + c] = bs;
     }
   }
 }
@@ -400,7 +410,7 @@ int launch_nig_bwd(const void* e2, const void* w3, const float* evid, const floa
 int launch_nig_loss_stats(const float* gamma, const float* nu, const float* alpha, const float* beta,
                           const float* targets, float* stats, int B, hipStream_t s) {
   MMDEER_CHECK(B > 0, "nig loss needs a non-empty batch");
-  hipLaunchKernelGGL(nig_loss_stats_kernel, dim3(nig_nblocks(B), 3), dim3(256), 0, s, gamma, nu, alpha, beta, targets, stats, B);
+  hipLaunchKernelGGL(nig_loss_stats_kernel, dim3((B + 255) / 256, 3), dim3(256), 0, s, gamma, nu, alpha, beta, targets, stats, B);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
@@ -409,7 +419,7 @@ int launch_nig_loss_grad(const float* gamma, const float* nu, const float* alpha
                          const float* targets, const float* stats, float* dgamma, float* dnu, float* dalpha,
                          float* dbeta, float* loss_out, int* bin_counts, int B, const LossCfg& cfg, hipStream_t s) {
   MMDEER_CHECK(B > 0, "nig loss needs a non-empty batch");
-  hipLaunchKernelGGL(nig_loss_grad_kernel, dim3(nig_nblocks(B), 3), dim3(256), 0, s, gamma, nu, alpha, beta, targets, stats,
+  hipLaunchKernelGGL(nig_loss_grad_kernel, dim3((B + 255) / 256, 3), dim3(256), 0, s, gamma, nu, alpha, beta, targets, stats,
                      dgamma, dnu, dalpha, dbeta, loss_out, bin_counts, B, cfg);
   MMDEER_HIP(hipGetLastError());
   return 0;

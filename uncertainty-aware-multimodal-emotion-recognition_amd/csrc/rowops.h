@@ -44,7 +44,7 @@ int ln_bwd_nparts(int M);
 int launch_ln_bwd(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
                   void* dz, float* partial, int M, int N, int act_f32, float mask_scale, hipStream_t s);
 
-constexpr int REDUCE_MAX_SEGMENTS = 16;
+constexpr int REDUCE_MAX_SEGMENTS = 48;
 struct ReduceTable {
   int nseg;
   const float* src[REDUCE_MAX_SEGMENTS];  // part p of element j at src[p * stride + j]
