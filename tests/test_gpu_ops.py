@@ -135,6 +135,23 @@ def test_gemm_dw_and_bias_grad(compute_f32, splitk, tile, Bt, Nl, Kl):
     assert (dbias.double() - dY.double().sum(0)).abs().max().item() < tol * max(1.0, math.sqrt(Bt) / 4)
 
 
+@pytest.mark.parametrize("tile", [2, 3])
+@pytest.mark.parametrize("splitk", [1, 4])
+def test_gemm_dw_padded_rows(tile, splitk):
+    """dW against an activation block whose 84 valid columns sit in 128-element rows (the padded audio block):
+    the columns beyond 84 must not reach the result."""
+    Bt, Nl, Kl, ld = 1024, 256, 84, 128
+    dY = bf(rnd(Bt, Nl, seed=20))
+    X = bf(rnd(Bt, ld, seed=21))          # columns 84..127 hold garbage on purpose
+    dbias = torch.zeros(Nl, device=dev())
+    out = run_gemm(dY, X, Nl, Kl, Bt, trans_a=1, trans_w=1, compute_f32=0, tile=tile, bias_grad=dbias,
+                   c_dtype=torch.float32, lda=Nl, ldw=ld, splitk=splitk)
+    ref = dY.double().t() @ X[:, :Kl].double()
+    assert out.shape == (Nl, Kl)
+    assert (out.double() - ref).abs().max().item() < 2e-2 * math.sqrt(Bt) / 4
+    assert (dbias.double() - dY.double().sum(0)).abs().max().item() < 2e-2 * math.sqrt(Bt) / 4
+
+
 def test_gemm_dropout_matches_mask_dump():
     lib = _lib.load()
     M, N, K, p, seed, off, site = 96, 256, 64, 0.3, 1234, 5, 4

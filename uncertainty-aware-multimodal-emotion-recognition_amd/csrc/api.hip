@@ -61,12 +61,15 @@ constexpr int P_EV2_W = MMDEER_P_HEAD0_EV6_WEIGHT, P_EV2_B = MMDEER_P_HEAD0_EV6_
 constexpr int AUD = MMDEER_AUDIO_DIM, VID = MMDEER_VIDEO_DIM, TXT = MMDEER_TEXT_DIM, INTER = MMDEER_INTER_DIM;
 constexpr int FUS = MMDEER_FUSION_DIM, HID = MMDEER_HIDDEN_DIM, EV1 = 128, EV2 = 64;
 constexpr int SPLITK_MAX = 8;
+constexpr int AUD_PAD = 128;   // the 84 audio features padded to a K-tile multiple for the LDS-DMA kernels
 
 // ------------------------------------------------------------------ workspace layout
 struct Layout {
   // packed parameters
   char* wpack;   // compute dtype, MMDEER_FLAT_ELEMS
   char* wtpack;  // transposed weight matrices (W^T, compute dtype) at the same flat offsets: dX runs as an NT GEMM
+  char* wa_pad;  // bf16 mode: audio_projection.weight as [256][AUD_PAD] (zero-padded rows, 16-byte aligned)
+  char* audio_pad;  // bf16 mode: the audio feature block as [B][AUD_PAD]
   float* vpack;  // fp32 vectors, MMDEER_FLAT_ELEMS
   // saved activations (activation dtype unless noted)
   char *avin, *avv, *cat, *y_a2, *av, *xtok, *qkv, *obar, *pool, *y_t3, *tri, *y_o1, *fused, *h1, *h2, *e1, *e2;
@@ -91,6 +94,8 @@ Layout make_layout(void* base, int B, int f32) {
   L.wpack = take((size_t)MMDEER_FLAT_ELEMS * es);
   L.wtpack = take((size_t)MMDEER_FLAT_ELEMS * es);
   L.vpack = reinterpret_cast<float*>(take((size_t)MMDEER_FLAT_ELEMS * 4));
+  L.wa_pad = take((size_t)INTER * AUD_PAD * 2);
+  L.audio_pad = take(Bz * AUD_PAD * 2);
   auto act = [&](size_t rows, size_t cols) { return take(rows * cols * es); };
   auto f32buf = [&](size_t n) { return reinterpret_cast<float*>(take(n * 4)); };
   L.avin = act(2 * Bz, INTER); L.avv = act(2 * Bz, INTER); L.cat = act(Bz, 2 * INTER); L.y_a2 = act(Bz, INTER);
@@ -337,7 +342,16 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
       TRY(launch_pack_transposed(tt, L.wtpack, f32, s));
     }
   }
-  if (B == 0) return 0;
+  const bool wa_pending = a->repack && !f32;   // the padded bf16 copy of audio_projection.weight follows the parameters
+  if (B == 0) {
+    if (wa_pending) {
+      PadTable pt{};
+      pt.src[0] = a->params[P_AUD_W]; pt.dst[0] = L.wa_pad; pt.src_f32[0] = 1; pt.rows[0] = INTER; pt.cols[0] = AUD; pt.ld_dst[0] = AUD_PAD;
+      pt.nseg = 1;
+      TRY(launch_pad_cols(pt, s));
+    }
+    return 0;
+  }
   MMDEER_CHECK(a->audio && a->video && a->text, "audio / video / text must be non-NULL");
   MMDEER_CHECK(a->nig_out != nullptr, "nig_out is NULL");
 
@@ -349,12 +363,28 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   const int in_f32 = a->inputs_bf16 ? 0 : 1;
   const size_t es = X.es;
 
+  // F0 (bf16 mode): 84-wide rows are not 16-byte aligned -- zero-pad the audio block (and, when the parameters
+  //     changed, the audio projection weight) to 128 columns so both run on the LDS-DMA kernels
+  if (!f32) {
+    PadTable pt{};
+    pt.src[0] = a->audio; pt.dst[0] = L.audio_pad; pt.src_f32[0] = in_f32; pt.rows[0] = B; pt.cols[0] = AUD; pt.ld_dst[0] = AUD_PAD;
+    pt.nseg = 1;
+    if (wa_pending) {
+      pt.src[1] = a->params[P_AUD_W]; pt.dst[1] = L.wa_pad; pt.src_f32[1] = 1; pt.rows[1] = INTER; pt.cols[1] = AUD; pt.ld_dst[1] = AUD_PAD;
+      pt.nseg = 2;
+    }
+    TRY(launch_pad_cols(pt, s));
+  }
   // F1: the three input projections (fusion.py:236-237, 322) in one launch
   {
     GemmGroup g{};
     g.nprob = 3;
     g.p[0] = X.fwd(a->video, in_f32, VID, P_VID_W, P_VID_B, L.avin, INTER, B, 0, -1);                       // rows [0,B)
     g.p[1] = X.fwd(a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, L.avin + (size_t)B * INTER * es, INTER, B, 0, -1); // rows [B,2B)
+    if (!f32) {
+      g.p[1].A = L.audio_pad; g.p[1].a_f32 = 0; g.p[1].lda = AUD_PAD;
+      g.p[1].B = L.wa_pad; g.p[1].ldb = AUD_PAD; g.p[1].K = AUD_PAD;
+    }
     g.p[2] = X.fwd(a->text, in_f32, TXT, P_TXT_W, P_TXT_B, L.xtok + (size_t)FUS * es, 2 * FUS, B, 0, -1);     // token 1
     TRY(X.run(g));
   }
@@ -546,7 +576,8 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     X.set_split(q, G);
     add_dw(q);
     add_dw(X.dw(L.davin, INTER, a->video, in_f32, VID, P_VID_W, P_VID_B, G, B));                                  // rows [0,B)
-    add_dw(X.dw(L.davin + (size_t)B * INTER * es, INTER, a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, G, B));        // rows [B,2B)
+    if (f32) add_dw(X.dw(L.davin + (size_t)B * INTER * es, INTER, a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, G, B));   // rows [B,2B)
+    else add_dw(X.dw(L.davin + (size_t)B * INTER * es, INTER, L.audio_pad, 0, AUD_PAD, P_AUD_W, P_AUD_B, G, B));    // padded copy of F0
     reduce_ln(rt, L.part_ln_a2, P_AVF_G, INTER);
   }
   // ---- all weight gradients: one grouped split-K launch + one deterministic fold of every partial slab

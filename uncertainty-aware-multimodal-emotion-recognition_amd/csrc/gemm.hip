@@ -76,8 +76,12 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
       p.a_mode = p.b_mode = SRC_F32;
     } else {
       // 16-byte loads of a bf16 source need 16-byte aligned rows AND no half-valid chunk (extent multiple of 8)
-      const bool av16 = p.lda % 8 == 0 && p.sA % 8 == 0 && (p.trans_a ? p.M : p.K) % 8 == 0;
-      const bool bv16 = p.ldb % 8 == 0 && p.sB % 8 == 0 && (p.trans_b ? p.N : p.K) % 8 == 0;
+      // (a transposed operand may end in a half-valid chunk when its rows are padded: the extra columns are read
+      //  from inside the row and only feed outputs that are never stored)
+      const bool av16 = p.lda % 8 == 0 && p.sA % 8 == 0 &&
+                        (p.trans_a ? (p.M % 8 == 0 || (p.batch == 1 && p.lda >= (p.M + 7) / 8 * 8)) : p.K % 8 == 0);
+      const bool bv16 = p.ldb % 8 == 0 && p.sB % 8 == 0 &&
+                        (p.trans_b ? (p.N % 8 == 0 || (p.batch == 1 && p.ldb >= (p.N + 7) / 8 * 8)) : p.K % 8 == 0);
       p.a_mode = p.a_f32 ? SRC_F32 : (av16 ? SRC_BF16_V16 : SRC_BF16_V8);
       p.b_mode = p.b_f32 ? SRC_F32 : (bv16 ? SRC_BF16_V16 : SRC_BF16_V8);
     }

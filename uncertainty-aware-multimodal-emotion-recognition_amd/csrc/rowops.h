@@ -58,6 +58,18 @@ struct ReduceTable {
 // split-K weight-gradient slabs into the flat gradient buffer.
 int launch_reduce_partials(ReduceTable& t, hipStream_t s);
 
+// dst[r][0..ld_dst) (bf16) = src[r][0..cols) converted, zero-padded to ld_dst (a multiple of 8): gives the 84-wide
+// audio feature block / audio projection weight 16-byte aligned 128-element rows for the LDS-DMA GEMM kernels.
+constexpr int PAD_MAX_SEGMENTS = 2;
+struct PadTable {
+  int nseg;
+  const void* src[PAD_MAX_SEGMENTS];
+  void* dst[PAD_MAX_SEGMENTS];
+  int src_f32[PAD_MAX_SEGMENTS], rows[PAD_MAX_SEGMENTS], cols[PAD_MAX_SEGMENTS], ld_dst[PAD_MAX_SEGMENTS];
+  int bstart[PAD_MAX_SEGMENTS + 1];   // filled by the launcher (256 destination chunks of 8 elements per block)
+};
+int launch_pad_cols(PadTable& t, hipStream_t s);
+
 // keep-mask dump for the test harness: out[r*cols + c] = keep(site, r, c) ? 1 : 0   (c already in site granularity)
 int launch_dropout_mask(const DropCtx& d, int site, int rows, int cols, unsigned char* out, hipStream_t s);
 

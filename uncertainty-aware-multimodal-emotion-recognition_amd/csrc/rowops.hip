@@ -7,6 +7,7 @@ namespace mmdeer {
 namespace {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // kernel arguments live in the constant address space; indexing them through this pointer (instead of the
 // by-value parameter) keeps descriptor tables out of scratch when the index is a runtime value.
@@ -249,6 +250,27 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceTable 
   }
 }
 
+__global__ __launch_bounds__(256) void pad_cols_kernel(const PadTable t) {
+  const auto& T = karg<PadTable>();
+  const int sg = (T.nseg > 1 && (int)blockIdx.x >= T.bstart[1]) ? 1 : 0;
+  const int cols = T.cols[sg], ld = T.ld_dst[sg], cpr = ld >> 3;
+  const long long c = (long long)(blockIdx.x - T.bstart[sg]) * 256 + threadIdx.x;
+  if (c >= (long long)T.rows[sg] * cpr) return;
+  const int r = (int)(c / cpr), c0 = (int)(c - (long long)r * cpr) * 8;
+  float v[8];
+  if (T.src_f32[sg]) {
+    const float* src = reinterpret_cast<const float*>(T.src[sg]) + (long long)r * cols;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = c0 + j < cols ? src[c0 + j] : 0.f;
+  } else {
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(T.src[sg]) + (long long)r * cols;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = c0 + j < cols ? bf2f(src[c0 + j]) : 0.f;
+  }
+  u32x4 o{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+  *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(T.dst[sg]) + (long long)r * ld + c0) = o;
+}
+
 __global__ __launch_bounds__(256) void dropout_mask_kernel(DropCtx d, int site, int rows, int cols, unsigned char* out) {
   const long long total = (long long)rows * cols;
   for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
@@ -340,6 +362,21 @@ int launch_reduce_partials(ReduceTable& t, hipStream_t s) {
   for (int i = t.nseg; i <= REDUCE_MAX_SEGMENTS; ++i) t.bstart[i] = blocks;
   if (blocks == 0) return 0;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, t);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_pad_cols(PadTable& t, hipStream_t s) {
+  MMDEER_CHECK(t.nseg >= 0 && t.nseg <= PAD_MAX_SEGMENTS, "pad: bad segment count %d", t.nseg);
+  int blocks = 0;
+  for (int i = 0; i < t.nseg; ++i) {
+    MMDEER_CHECK(t.ld_dst[i] % 8 == 0 && t.ld_dst[i] >= t.cols[i] && ((uintptr_t)t.dst[i] % 16) == 0, "pad[%d]: bad destination", i);
+    t.bstart[i] = blocks;
+    blocks += (int)(((long long)t.rows[i] * (t.ld_dst[i] / 8) + 255) / 256);
+  }
+  for (int i = t.nseg; i <= PAD_MAX_SEGMENTS; ++i) t.bstart[i] = blocks;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(pad_cols_kernel, dim3(blocks), dim3(256), 0, s, t);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
