@@ -180,6 +180,24 @@ int mmdeer_nig_loss(const float* gamma, const float* nu, const float* alpha, con
 int mmdeer_dropout_mask(int site, int rows, int cols, float dropout_p, uint64_t seed, uint64_t offset,
                         unsigned char* out, void* stream);
 
+/* ---- side rows (a8, a9, a14), forward only --------------------------------------------------------
+ * Their Linear(+ReLU) layers run on mmdeer_gemm and the LayerNorm on mmdeer_layernorm_fwd; the two entry points
+ * below are the parts that are neither.
+ *
+ * deer.CrossModalAttention.forward core (reference src/models/deer.py:399-423), feature_dim 256, 8 heads:
+ * q = query_proj(text), k_x / v_x = key_proj / value_proj(audio | video), each [B][256] with row stride ld;
+ * scores (q.k)/sqrt(32) per head, softmax over the HEAD axis, head-collapsing weighted sum -> [B][32], times the
+ * softmax of gate_logits [B][2] (the output of uncertainty_gate's last Linear).  Outputs fp32 [B][32]. */
+int mmdeer_cross_modal_attn_fwd(const void* q, const void* k_audio, const void* v_audio, const void* k_video,
+                                const void* v_video, int ld, const float* gate_logits, float* out_audio, float* out_video,
+                                int B, int act_f32, void* stream);
+
+/* nn.LSTM cell at T = 1 with zero initial state (reference src/models/encoders.py:82-89, 380; torch gate order
+ * i, f, g, o): gates [B][ndir*4*hidden] = W_ih x + b_ih + b_hh per direction ->
+ * out[b][dir*hidden + j] = sigmoid(o) * tanh(sigmoid(i) * tanh(g)). */
+int mmdeer_lstm_cell_t1(const void* gates, int ld_gates, void* out, int ld_out, int B, int hidden, int ndir, int act_f32,
+                        void* stream);
+
 /* fp32 <-> bf16 conversion of a contiguous device buffer (n % 4 == 0) */
 int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream);
 

@@ -1,0 +1,134 @@
+"""Side rows (a8 CrossModalAttention, a9 encoders, a14 audio-encoder feature branch) on the GPU through
+the C-ABI, against the golden vectors captured from the reference and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mmdeer import side, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _golden():
+    return np.load(os.path.join(GOLDEN, "side_kernels.npz"))
+
+
+def _fill(module, tag):
+    """The closed-form parameter fill of tests/golden/make_golden.py, keyed by state_dict name."""
+    sd = {}
+    for name, t in module.state_dict().items():
+        shape = tuple(t.shape)
+        n = int(np.prod(shape))
+        u = synth.uniform01(synth._stream_of(tag + "." + name), n) * 2.0 - 1.0
+        if len(shape) >= 2:
+            w = u * np.sqrt(6.0 / (shape[0] + shape[1]))
+        elif name.endswith("weight"):
+            w = 1.0 + 0.1 * u
+        else:
+            w = 0.05 * u
+        sd[name] = torch.from_numpy(w.reshape(shape).astype(np.float32))
+    module.load_state_dict(sd)
+    return {k: v.clone() for k, v in sd.items()}
+
+
+def _oracle():
+    from oracle import deer_oracle as O   # test infrastructure only
+    return O
+
+
+def cuda(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_cross_modal_attention_matches_golden(compute):
+    g = _golden()
+    m = side.CrossModalAttention(256, 8, compute_dtype=compute)
+    _fill(m, "cma")
+    m = m.to("cuda:0")
+    wa, wv = m(cuda(g["cma.in.audio"]), cuda(g["cma.in.video"]), cuda(g["cma.in.text"]))
+    assert wa.shape == (9, 32) and wv.shape == (9, 32)
+    tol = dict(rtol=1e-4, atol=2e-6) if compute == "fp32" else dict(rtol=5e-2, atol=5e-3)
+    np.testing.assert_allclose(wa.cpu().numpy(), g["cma.audio"], **tol)
+    np.testing.assert_allclose(wv.cpu().numpy(), g["cma.video"], **tol)
+
+
+def test_cross_modal_attention_matches_oracle_large_batch():
+    O = _oracle()
+    m = side.CrossModalAttention(256, 8)
+    P = _fill(m, "cma2")
+    m = m.to("cuda:0")
+    B = 1027   # ragged against the 4-samples-per-block launch
+    xs = [torch.from_numpy(synth.normal(synth._stream_of(f"cma2.in{i}"), B * 256).reshape(B, 256).astype(np.float32)) for i in range(3)]
+    wa, wv = m(*(x.to("cuda:0") for x in xs))
+    ra, rv = O.cross_modal_attention(P, *xs)
+    np.testing.assert_allclose(wa.cpu().numpy(), ra.numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(wv.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=2e-6)
+    # empty batch
+    ea, ev = m(*(x[:0].to("cuda:0") for x in xs))
+    assert ea.shape == (0, 32) and ev.shape == (0, 32)
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_modality_encoders_match_golden(compute):
+    g = _golden()
+    m = side.ModalityEncoders(compute_dtype=compute)
+    _fill(m, "hdf")
+    m = m.to("cuda:0")
+    b = synth.make_batch(9, seed=77)
+    ea, ev, et = m(cuda(b["audio"]), cuda(b["video"]), cuda(b["text"]))
+    tol = dict(rtol=1e-4, atol=2e-6) if compute == "fp32" else dict(rtol=5e-2, atol=2e-2)
+    np.testing.assert_allclose(ea.float().cpu().numpy(), g["hdf.audio_encoded"], **tol)
+    np.testing.assert_allclose(ev.float().cpu().numpy(), g["hdf.video_encoded"], **tol)
+    np.testing.assert_allclose(et.float().cpu().numpy(), g["hdf.text_encoded"], **tol)
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_audio_encoder_feature_branch_matches_golden(compute):
+    g = _golden()
+    m = side.EnhancedAudioEncoder(compute_dtype=compute)
+    _fill(m, "aenc")
+    m = m.to("cuda:0").eval()
+    b = synth.make_batch(9, seed=77)
+    out = m(cuda(b["audio"]))
+    assert out.shape == (9, 512) and out.dtype == torch.float32
+    tol = dict(rtol=1e-3, atol=2e-5) if compute == "fp32" else dict(rtol=1e-1, atol=8e-2)
+    np.testing.assert_allclose(out.cpu().numpy(), g["aenc.out"], **tol)
+    # (B, 1, 84) is the same path
+    out3 = m(cuda(b["audio"]).unsqueeze(1))
+    assert torch.equal(out3, out)
+
+
+def test_audio_encoder_matches_oracle_and_state_dict_names():
+    O = _oracle()
+    m = side.EnhancedAudioEncoder()
+    P = _fill(m, "aenc3")
+    names = set(P)
+    for l in (0, 1):
+        for sfx in ("", "_reverse"):
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                assert f"lstm.{n}_l{l}{sfx}" in names
+    assert {"attention.0.weight", "attention.2.weight", "output_projection.0.weight", "output_projection.3.weight",
+            "output_projection.4.weight"} <= names
+    m = m.to("cuda:0").eval()
+    B = 300
+    x = torch.from_numpy(synth.normal(synth._stream_of("aenc3.x"), B * 84).reshape(B, 84).astype(np.float32))
+    out = m(x.to("cuda:0"))
+    ref = O.audio_encoder_features(P, x)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=2e-5)
+
+
+def test_side_rows_reject_what_they_do_not_cover():
+    m = side.EnhancedAudioEncoder().to("cuda:0").eval()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 5, 84, device="cuda:0"))       # T > 1
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 16000, device="cuda:0"))       # raw waveform
+    with pytest.raises(NotImplementedError):
+        side.CrossModalAttention(128, 4)
+    with pytest.raises(RuntimeError):
+        side.ModalityEncoders()(torch.zeros(2, 84), torch.zeros(2, 256), torch.zeros(2, 768))   # CPU tensors: no fallback

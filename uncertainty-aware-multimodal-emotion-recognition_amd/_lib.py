@@ -96,6 +96,8 @@ SYMBOLS = [
     ("mmdeer_nig_stats_elems", c_ll, [c_int]),
     ("mmdeer_nig_loss", c_int, [c_void_p] * 12 + [c_int, C.POINTER(LossCfg), c_void_p]),
     ("mmdeer_dropout_mask", c_int, [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p]),
+    ("mmdeer_cross_modal_attn_fwd", c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
+    ("mmdeer_lstm_cell_t1", c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_convert", c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p]),
 ]
 
@@ -117,10 +119,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             try:
                 _build.build()
             except Exception as e:  # noqa: BLE001
-                if not os.path.exists(path):
-                    raise RuntimeError(
-                        "libmmdeer_hip.so is missing and could not be built (hipcc --offload-arch=gfx950). "
-                        f"There is no CPU fallback for the mmdeer hot path. Build error: {e}") from e
+                raise RuntimeError(
+                    "libmmdeer_hip.so is missing or older than its sources and could not be (re)built with "
+                    "hipcc --offload-arch=gfx950.  There is no CPU fallback for the mmdeer hot path and a stale "
+                    f"library is never loaded.  Build error: {e}") from e
         if not os.path.exists(path):
             raise RuntimeError(f"libmmdeer_hip.so not found at {path}; run `python -m mmdeer.build`. "
                                "There is no CPU fallback for the mmdeer hot path.")

@@ -1,0 +1,137 @@
+// Side rows of the hot-path table (a8, a9, a14) -- the pieces of them that are not a plain
+// Linear(+ReLU) (those run on mmdeer_gemm) or LayerNorm (mmdeer_layernorm_fwd):
+//   * deer.CrossModalAttention core (deer.py:379-425): per-head scores, softmax over the HEAD axis, head-collapsing
+//     weighted sum, 2-way gate softmax and scaling;
+//   * the T = 1, zero-state bidirectional LSTM cell of EnhancedAudioEncoder's feature branch (encoders.py:82-89,
+//     380): h = sigmoid(o) * tanh(sigmoid(i) * tanh(g)) per direction on the W_ih x + b_ih + b_hh gate rows.
+// Forward (inference) only, fp32 or bf16 storage, fp32 arithmetic.
+#include "common.h"
+
+namespace mmdeer {
+namespace {
+
+template <bool F32>
+__device__ __forceinline__ f32x4 ld4(const void* base, long long idx) {
+  if constexpr (F32) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+  } else {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t a = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const bf16_t*>(base) + idx);
+    return f32x4{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xFFFF0000u), __uint_as_float(a.y << 16),
+                 __uint_as_float(a.y & 0xFFFF0000u)};
+  }
+}
+
+template <bool F32>
+__device__ __forceinline__ float ld1(const void* base, long long idx) {
+  if constexpr (F32) return reinterpret_cast<const float*>(base)[idx];
+  else return bf2f(reinterpret_cast<const bf16_t*>(base)[idx]);
+}
+
+__device__ __forceinline__ float xor_sum(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float xor_max(float v, int mask) { return fmaxf(v, __shfl_xor(v, mask, 64)); }
+
+// One wave per sample; lane l owns head h = l >> 3 and dims 4 (l & 7) .. + 3 of that head (8 heads x 32 dims).
+// q, k_*, v_* : [B][256] projections (row stride ld);  gate_logits: [B][2] fp32;  out_*: [B][32] fp32.
+template <bool F32>
+__global__ __launch_bounds__(256) void cross_modal_attn_kernel(const void* q, const void* ka, const void* va, const void* kv,
+                                                               const void* vv, int ld, const float* gate_logits,
+                                                               float* out_a, float* out_v, int B) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const long long o = (long long)b * ld + lane * 4;   // element (h, 4j..4j+3) sits at h*32 + 4j = 4*lane
+  const f32x4 qv = ld4<F32>(q, o);
+  // gate: softmax over the two logits (deer.py:418-421)
+  const float g0 = gate_logits[2 * b], g1 = gate_logits[2 * b + 1];
+  const float gm = fmaxf(g0, g1), e0 = expf(g0 - gm), e1 = expf(g1 - gm);
+  const float gate[2] = {e0 / (e0 + e1), e1 / (e0 + e1)};
+  const void* ks[2] = {ka, kv};
+  const void* vs[2] = {va, vv};
+  float* outs[2] = {out_a, out_v};
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const f32x4 kk = ld4<F32>(ks[m], o), vw = ld4<F32>(vs[m], o);
+    float s = qv.x * kk.x + qv.y * kk.y + qv.z * kk.z + qv.w * kk.w;
+    s = xor_sum(xor_sum(xor_sum(s, 1), 2), 4) * 0.17677669529663687f;   // / sqrt(32)   (deer.py:403)
+    // softmax over the 8 heads (dim=1, deer.py:406): lanes with equal (l & 7) hold the 8 scores
+    const float mx = xor_max(xor_max(xor_max(s, 8), 16), 32);
+    const float e = expf(s - mx);
+    const float den = xor_sum(xor_sum(xor_sum(e, 8), 16), 32);
+    const float p = e / den;
+    f32x4 c{p * vw.x, p * vw.y, p * vw.z, p * vw.w};   // sum over heads -> (32,)   (deer.py:410-415)
+#pragma unroll
+    for (int sh = 8; sh < 64; sh <<= 1) {
+      c.x = xor_sum(c.x, sh); c.y = xor_sum(c.y, sh); c.z = xor_sum(c.z, sh); c.w = xor_sum(c.w, sh);
+    }
+    if (lane < 8) {
+      const float gm_ = gate[m];
+      *reinterpret_cast<f32x4*>(outs[m] + (long long)b * 32 + lane * 4) = f32x4{c.x * gm_, c.y * gm_, c.z * gm_, c.w * gm_};
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// gates: [B][ndir * 4H] rows (gate order i, f, g, o per direction; bias already added); out[b][dir*H + j]
+template <bool F32>
+__global__ __launch_bounds__(256) void lstm_cell_t1_kernel(const void* gates, int ld_g, void* out, int ld_o, int B, int H,
+                                                           int ndir) {
+  const long long total = (long long)B * ndir * H;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int b = (int)(e / (ndir * H)), r = (int)(e - (long long)b * ndir * H);
+    const int d = r / H, j = r - d * H;
+    const long long g0 = (long long)b * ld_g + (long long)d * 4 * H + j;
+    const float gi = ld1<F32>(gates, g0), gg = ld1<F32>(gates, g0 + 2 * H), go = ld1<F32>(gates, g0 + 3 * H);
+    const float c = sigmoidf_(gi) * tanhf(gg);          // f * c0 vanishes: c0 = 0
+    const float h = sigmoidf_(go) * tanhf(c);
+    if constexpr (F32) reinterpret_cast<float*>(out)[(long long)b * ld_o + r] = h;
+    else reinterpret_cast<bf16_t*>(out)[(long long)b * ld_o + r] = f2bf(h);
+  }
+}
+
+}  // namespace
+}  // namespace mmdeer
+
+using namespace mmdeer;
+
+extern "C" {
+
+int mmdeer_cross_modal_attn_fwd(const void* q, const void* k_audio, const void* v_audio, const void* k_video,
+                                const void* v_video, int ld, const float* gate_logits, float* out_audio, float* out_video,
+                                int B, int act_f32, void* stream) {
+  MMDEER_CHECK(B >= 0, "cross_modal_attn: batch must be >= 0 (got %d)", B);
+  if (B == 0) return 0;
+  MMDEER_CHECK(q && k_audio && v_audio && k_video && v_video && gate_logits && out_audio && out_video,
+               "cross_modal_attn: NULL pointer");
+  MMDEER_CHECK(ld >= 256 && ld % 4 == 0, "cross_modal_attn: ld=%d must be >= 256 and a multiple of 4", ld);
+  const dim3 grid((B + 3) / 4);
+  if (act_f32)
+    hipLaunchKernelGGL(cross_modal_attn_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q, k_audio, v_audio, k_video,
+                       v_video, ld, gate_logits, out_audio, out_video, B);
+  else
+    hipLaunchKernelGGL(cross_modal_attn_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q, k_audio, v_audio, k_video,
+                       v_video, ld, gate_logits, out_audio, out_video, B);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int mmdeer_lstm_cell_t1(const void* gates, int ld_gates, void* out, int ld_out, int B, int hidden, int ndir, int act_f32,
+                        void* stream) {
+  MMDEER_CHECK(B >= 0 && hidden > 0 && (ndir == 1 || ndir == 2), "lstm_cell_t1: bad shape B=%d hidden=%d ndir=%d", B, hidden, ndir);
+  if (B == 0) return 0;
+  MMDEER_CHECK(gates && out, "lstm_cell_t1: NULL pointer");
+  MMDEER_CHECK(ld_gates >= ndir * 4 * hidden && ld_out >= ndir * hidden, "lstm_cell_t1: leading dimensions too small");
+  const long long total = (long long)B * ndir * hidden;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (act_f32)
+    hipLaunchKernelGGL(lstm_cell_t1_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gates, ld_gates, out,
+                       ld_out, B, hidden, ndir);
+  else
+    hipLaunchKernelGGL(lstm_cell_t1_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gates, ld_gates, out,
+                       ld_out, B, hidden, ndir);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
