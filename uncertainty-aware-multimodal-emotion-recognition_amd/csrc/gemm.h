@@ -40,6 +40,8 @@ struct GemmProblem {
   unsigned char pad_[2];
 };
 
+static_assert(sizeof(GemmProblem) == 192, "gemm_glds.hip touches the descriptor's cache lines by byte offset");
+
 enum SrcMode { SRC_F32 = 0, SRC_BF16_V16 = 1, SRC_BF16_V8 = 2 };
 
 constexpr int GEMM_MAX_PROBLEMS = 16;   // all weight-gradient problems of a backward pass fit one launch

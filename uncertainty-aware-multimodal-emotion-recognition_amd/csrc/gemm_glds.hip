@@ -39,15 +39,109 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Epilogue straight from the accumulators.  The kernels below issue their MFMAs with the operands swapped
+// (D[n][m] += W-fragment x A-fragment), so a lane holds FOUR CONSECUTIVE COLUMNS n of one output row m:
+// acc[i][j] = C[m = row0 + wm*WTM + 16 i + li][n = col0 + wn*WTN + 16 j + 4 lg + {0..3}].  Bias, ReLU, dropout, the
+// (Y > 0) mask and the store are lane-local: no LDS staging, no barrier, one 8-byte (bf16) / 16-byte (fp32) store
+// per accumulator.  bias4[j] was loaded before the K loop.
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void epilogue_direct(const GemmGroup& g, const __attribute__((address_space(4))) GemmProblem& p,
+                                                f32x4 (&acc)[TM][TN], const f32x4 (&bias4)[TN], int z, int row0, int col0,
+                                                int wm, int wn, int li, int lg) {
+  const int M = p.M, N = p.N;
+  const DropCtx dc = g.drop;
+  const int relu = p.relu, accumulate = p.accumulate, c_f32 = p.c_f32, y_f32 = p.y_f32, shift = p.drop_shift;
+  const int site = p.drop_site >= 0 ? p.drop_site : p.regen_site;
+  const unsigned dkey = site >= 0 ? drop_key(dc, site) : 0u;
+  const void* Yp = p.Y;
+  void* Cp = p.C;
+  const long long ldc = p.ldc, ldy = p.ldy, c_base = (long long)z * p.sC, y_base = (long long)z * p.sY;
+  const float ms = p.mask_scale;
+  const int nb = col0 + wn * WTN + 4 * lg, mb = row0 + wm * WTM + li;
+  // mask source first: all loads in flight together
+  f32x4 yv[TM][TN];
+  if (Yp) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int m = mb + 16 * i, n = nb + 16 * j;
+        yv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < M && n < N) {
+          const long long yo = y_base + (long long)m * ldy + n;
+          if (y_f32) {
+            yv[i][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Yp) + yo);
+          } else {
+            const u32x2 y = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(Yp) + yo);
+            yv[i][j] = f32x4{__uint_as_float(y.x << 16), __uint_as_float(y.x & 0xFFFF0000u), __uint_as_float(y.y << 16),
+                             __uint_as_float(y.y & 0xFFFF0000u)};
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mb + 16 * i;
+    if (m >= M) continue;
+    const unsigned rk = ((unsigned)m * 0x9E3779B1u) ^ dkey;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nb + 16 * j;
+      if (n >= N) continue;   // N % 4 == 0: a 4-column group is all in or all out
+      f32x4 v = acc[i][j] + bias4[j];
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (site >= 0) {
+        const unsigned dcol = (unsigned)(n + z * N);   // batched problems: the column index continues across the batch
+        if (shift == 0) {
+          v.x = mix32(rk ^ (dcol * 0x85EBCA77u)) < dc.thresh ? v.x * dc.scale : 0.f;
+          v.y = mix32(rk ^ ((dcol + 1) * 0x85EBCA77u)) < dc.thresh ? v.y * dc.scale : 0.f;
+          v.z = mix32(rk ^ ((dcol + 2) * 0x85EBCA77u)) < dc.thresh ? v.z * dc.scale : 0.f;
+          v.w = mix32(rk ^ ((dcol + 3) * 0x85EBCA77u)) < dc.thresh ? v.w * dc.scale : 0.f;
+        } else {
+          const float f = mix32(rk ^ ((dcol >> shift) * 0x85EBCA77u)) < dc.thresh ? dc.scale : 0.f;
+          v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        }
+      }
+      if (Yp) {
+        const f32x4 y = yv[i][j];
+        v.x = y.x > 0.f ? v.x * ms : 0.f; v.y = y.y > 0.f ? v.y * ms : 0.f;
+        v.z = y.z > 0.f ? v.z * ms : 0.f; v.w = y.w > 0.f ? v.w * ms : 0.f;
+      }
+      const long long co = c_base + (long long)m * ldc + n;
+      if (c_f32) {
+        float* cp = reinterpret_cast<float*>(Cp) + co;
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(cp);
+        *reinterpret_cast<f32x4*>(cp) = v;
+      } else {
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(Cp) + co) = u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+      }
+    }
+  }
+}
+
 // pieces (1 KiB wave-instructions) each wave issues per K-tile
 template <int BM, int BN> struct Glds { static constexpr int PA = BM / 32, PB = BN / 32, LPT = PA + PB; };
 
+// Problem 0 of the launch as plain scalar kernel arguments: they lead the kernarg segment and are preloaded into
+// SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count), so a workgroup of problem 0 -- all of
+// them in most launches -- computes its DMA addresses without waiting for a single kernarg fetch (measured before:
+// ~3000 cycles from wave start to the first DMA, two dependent cold scalar loads).  Workgroups of the other
+// problems of a group (bid >= nt0) read their descriptor from `g` as before.  nt0 = 0 disables the fast path
+// (batched problem 0).
+struct NtKernargs {   // mirror of the kernel's parameter list (for the offset of `g` in the kernarg segment)
+  const bf16_t* A;
+  const bf16_t* B;
+  int M, N, nk, lda, ldb, tiles_n, nt0, nwg;
+  GemmGroup g;
+};
+
 template <int BM, int BN, int NST>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_glds_kernel(const GemmGroup g) {
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_glds_kernel(
+    const bf16_t* A0, const bf16_t* B0, int M0, int N0, int nk0, int lda0, int ldb0, int tiles_n0, int nt0, int nwg,
+    const GemmGroup g) {
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-  constexpr int SPAD = BN + 4;
-  constexpr int LDS_BYTES = cmax(NST * STAGE, BM * SPAD * 4);
+  constexpr int LDS_BYTES = NST * STAGE;
   constexpr int PA = Glds<BM, BN>::PA, PB = Glds<BM, BN>::PB, LPT = Glds<BM, BN>::LPT;
   static_assert(NST >= 3 && NST <= 4, "ring depth");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
@@ -59,45 +153,51 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_gl
   KSTAMP(0);
 
   int bid = blockIdx.x;
-  if (g.xcd_remap) {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
+  if (nwg > 0) {   // XCD-contiguous renumbering (nwg = grid size; 0 switches it off)
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
   }
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
-    if (i < g.nprob && bid >= g.tile_start[i]) pi = i;
   typedef const __attribute__((address_space(4))) unsigned char* karg_ptr;
-  karg_ptr kbase = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-  const __attribute__((address_space(4))) GemmProblem& p =
-      *(const __attribute__((address_space(4))) GemmProblem*)(
-          kbase + __builtin_offsetof(GemmGroup, p) + (size_t)pi * sizeof(GemmProblem));
-  const int local = bid - g.tile_start[pi];
-  const int per_batch = p.tiles_m * p.tiles_n;
-  const int z = local / per_batch;
-  const int rem = local - z * per_batch;
-  const int tmb = rem / p.tiles_n, tnb = rem - tmb * p.tiles_n;
+  typedef const __attribute__((address_space(4))) GemmProblem* desc_ptr;
+  karg_ptr kbase = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(NtKernargs, g);
+  desc_ptr pp = (desc_ptr)(kbase + __builtin_offsetof(GemmGroup, p));
+  const bf16_t *Ab = A0, *Bb = B0;
+  int M = M0, N = N0, nk = nk0, lda = lda0, ldb = ldb0, z = 0;
+  int tmb = bid / tiles_n0, tnb = bid - tmb * tiles_n0;
+  if (bid >= nt0) {   // not problem 0 (or problem 0 is batched): descriptor from the kernarg segment
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+      if (i < g.nprob && bid >= g.tile_start[i]) pi = i;
+    pp += pi;
+    const int local = bid - g.tile_start[pi];
+    const int tn = pp->tiles_n, per_batch = pp->tiles_m * tn;
+    z = local / per_batch;
+    const int rem = local - z * per_batch;
+    tmb = rem / tn; tnb = rem - tmb * tn;
+    Ab = reinterpret_cast<const bf16_t*>(pp->A) + (long long)z * pp->sA;
+    Bb = reinterpret_cast<const bf16_t*>(pp->B) + (long long)z * pp->sB;
+    M = pp->M; N = pp->N; nk = pp->K >> 6; lda = pp->lda; ldb = pp->ldb;   // K % 64 == 0 (checked by the launcher)
+  }
+  const __attribute__((address_space(4))) GemmProblem& p = *pp;
   const int row0 = tmb * BM, col0 = tnb * BN;
-  const int M = p.M, N = p.N, K = p.K;
-  const int nk = K >> 6;   // K % 64 == 0 (checked by the launcher)
+  const float* bias_ptr = p.bias;   // requested here, consumed after the DMA prologue has been issued
 
   // ---- per-lane DMA source pointers: piece j of a wave covers tile rows (4j + wave) * 8 + (lane >> 3);
   //      lane (r8 = lane>>3, slot = lane&7) fetches logical chunk slot ^ r8.  Rows beyond the matrix read row 0 of
   //      the operand (their products only reach outputs that are never stored).
-  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (long long)z * p.sA;
-  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B) + (long long)z * p.sB;
   const int r8 = lane >> 3, kchunk = ((lane & 7) ^ r8) * 8;
   const bf16_t* pa[PA];
   const bf16_t* pb[PB];
 #pragma unroll
   for (int j = 0; j < PA; ++j) {
     const int row = row0 + (4 * j + wave) * 8 + r8;
-    pa[j] = (row < M ? Ab + (long long)row * p.lda : reinterpret_cast<const bf16_t*>(p.A)) + kchunk;
+    pa[j] = Ab + (long long)(row < M ? row : 0) * lda + kchunk;
   }
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
     const int row = col0 + (4 * j + wave) * 8 + r8;
-    pb[j] = (row < N ? Bb + (long long)row * p.ldb : reinterpret_cast<const bf16_t*>(p.B)) + kchunk;
+    pb[j] = Bb + (long long)(row < N ? row : 0) * ldb + kchunk;
   }
   auto issue = [&](int stage) __attribute__((always_inline)) {   // DMA one K-tile into `stage`, advance the pointers
     unsigned char* sa = lds + stage * STAGE + wave * 1024;
@@ -131,6 +231,21 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_gl
   for (int t = 0; t < NST - 1; ++t)
     if (t < nk) issue(t);
   KSTAMP(2);
+  // Warm the scalar cache with this problem's descriptor lines: the epilogue reads ~20 fields of it, which would
+  // otherwise miss (cold, ~1000 cycles) at the very end of the kernel.  Asm loads so that they are issued HERE; the
+  // results are dead, the registers stay reserved until the matching wait after the K loop.
+  unsigned warm0, warm1, warm2, warm3;
+  asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xbc"
+               : "=&s"(warm0), "=&s"(warm1), "=&s"(warm2), "=&s"(warm3) : "s"(pp) : "memory");
+  // bias chunks of this lane's output columns, consumed after the K loop.  These loads are younger than the prologue
+  // DMAs, so the first counted waits below are merely stricter than needed (never too weak).
+  f32x4 bias4[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = col0 + wn * WTN + 16 * j + 4 * lg;
+    bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias_ptr && n < N) bias4[j] = *reinterpret_cast<const f32x4*>(bias_ptr + (long long)z * p.sBias + n);
+  }
 
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -156,23 +271,26 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_gl
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<bf16_t>(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<bf16_t>(fb[j], fa[i], acc[i][j]);   // D[n][m]: see epilogue_direct
     }
     stage = stage + 1 == NST ? 0 : stage + 1;
   }
-  // every wave must be done reading the ring before the epilogue reuses it as fp32 staging (no DMA is in flight:
-  // the last iteration waited vmcnt(0))
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(warm0), "s"(warm1), "s"(warm2), "s"(warm3) : "memory");
   KSTAMP(4);
-  gemm_epilogue<BM, BN>(g, p, lds, acc, z, 0, row0, col0);
+  epilogue_direct<TM, TN, WTM, WTN>(g, p, acc, bias4, z, row0, col0, wm, wn, li, lg);
+#ifdef MMDEER_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   KSTAMP(5);
 }
 
 template <int BM, int BN, int NST>
 int launch_glds(const GemmGroup& g, int total, hipStream_t stream) {
-  hipLaunchKernelGGL((gemm_nt_glds_kernel<BM, BN, NST>), dim3(total), dim3(256), 0, stream, g);
+  const GemmProblem& q = g.p[0];
+  const int nt0 = q.batch == 1 ? g.tile_start[1] : 0;   // tile_start[nprob..] = total
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<BM, BN, NST>), dim3(total), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(q.A), reinterpret_cast<const bf16_t*>(q.B), q.M, q.N, q.K >> 6, q.lda,
+                     q.ldb, q.tiles_n, nt0, g.xcd_remap ? total : 0, g);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
