@@ -86,8 +86,9 @@ def test_gemm_fp32_asymmetric_identity(tile):
     assert torch.equal(out, W.t().contiguous())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (130, 256, 84), (33, 512, 768), (300, 1536, 512)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (130, 256, 84), (33, 512, 768), (300, 1536, 512), (1000, 520, 96),
+                                   (2048, 768, 32)])
 def test_gemm_bf16_nt(tile, M, N, K):
     A, W, b = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.1), rnd(N, seed=6)
     # fp32 activations converted on the fly by the loader, bf16 weights
@@ -150,6 +151,21 @@ def test_gemm_dw_padded_rows(tile, splitk):
     assert out.shape == (Nl, Kl)
     assert (out.double() - ref).abs().max().item() < 2e-2 * math.sqrt(Bt) / 4
     assert (dbias.double() - dY.double().sum(0)).abs().max().item() < 2e-2 * math.sqrt(Bt) / 4
+
+
+def test_gemm_256_tile_epilogue_matches_64_tile():
+    """The 256x256 forward kernel (bias + ReLU + dropout, bf16 in/out) against the 64x64 kernel on the same
+    inputs: the same products summed in a different order, the same dropout decisions."""
+    M, N, K = 777, 1024, 512
+    A, W, b = bf(rnd(M, K, seed=30)), bf(rnd(N, K, seed=31, scale=0.1)), rnd(N, seed=32)
+    kw = dict(bias=b, relu=1, compute_f32=0, drop_site=4, p=0.3, seed=99, offset=7)
+    o3 = run_gemm(A, W, M, N, K, tile=3, **kw).float()
+    o0 = run_gemm(A, W, M, N, K, tile=0, **kw).float()
+    assert ((o3 == 0) == (o0 == 0)).float().mean().item() > 0.999   # identical keep decisions (up to relu ties)
+    assert (o3 - o0).abs().max().item() < 5e-2
+    ref = torch.relu(A.double() @ W.double().t() + b.double())
+    kept = o3 != 0
+    assert ((o3.double() - ref / 0.7).abs() * kept).max().item() < 8e-2
 
 
 def test_gemm_dropout_matches_mask_dump():

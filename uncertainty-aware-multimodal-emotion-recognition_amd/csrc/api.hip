@@ -170,7 +170,20 @@ GemmTile pick_tile(const GemmGroup& g) {
   // weight-gradient groups (both operands transposed): the strided loads and the packing LDS store cost the same per
   // K-tile whatever the tile size, so the largest tile wins; split-K supplies the parallelism
   if (g.p[0].trans_a) return TILE_256x256;   // (falls back to 128x128 per sub-group where the kernel does not apply)
-  if (tiles[2] >= 512) return TILE_128x128;
+  // bf16: 128x64 and 64x64 run on the LDS-DMA kernel, 128x128 only on the register-staged one (measured on the
+  // trimodal in_proj, 768 tiles of 128x128: 28.5 us against 17 us as 1536 tiles of 128x64)
+  const bool f32 = g.p[0].a_f32 && g.p[0].b_f32;
+  if (f32 && tiles[2] >= 512) return TILE_128x128;
+  if (!f32) {   // big forward problems: 256x256 tiles when they fill most of the chip in one round (in_proj: 192)
+    long long t256 = 0;
+    bool plain = true;
+    for (int i = 0; i < g.nprob; ++i) {
+      const GemmProblem& p = g.p[i];
+      t256 += (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.batch;
+      plain = plain && !p.Y && !p.trans_b;
+    }
+    if (plain && t256 >= 160 && t256 <= 256) return TILE_256x256;
+  }
   if (tiles[1] >= 512) return TILE_128x64;
   return TILE_64x64;
 }

@@ -12,6 +12,7 @@ int gemm_dispatch_tt(const GemmGroup& g, int total, int compute_f32, GemmTile ti
 int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStream_t s);
 int gemm_dispatch_tt_glds(const GemmGroup& g, int total, int ring, hipStream_t s);
 int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s);
+int gemm_dispatch_nt256(const GemmGroup& g, int total, hipStream_t s);
 
 namespace {
 int env_xcd() {
@@ -109,7 +110,16 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
       tt256 = q.K % 32 == 0 && q.c_f32 && !q.bias && !q.relu && !q.Y && q.drop_site < 0 && q.regen_site < 0 &&
               (uintptr_t)q.C % 16 == 0 && q.sC % 4 == 0 && (q.splitk == 1 || ((uintptr_t)q.slab_c % 16 == 0 && q.slab_stride % 4 == 0));
     }
-    const GemmTile tile = tt256 ? TILE_256x256 : (tile_req == TILE_256x256 ? TILE_128x128 : tile_req);
+    // ... and as the LDS-DMA forward kernel (bias / ReLU / dropout epilogue, no mask, no split-K)
+    bool nt256 = tile_req == TILE_256x256 && !ta && !tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 &&
+                 env_glds();
+    for (int j = 0; j < sub.nprob && nt256; ++j) {
+      const GemmProblem& q = sub.p[j];
+      nt256 = q.K % 32 == 0 && q.splitk == 1 && !q.bias_grad && !q.Y && (uintptr_t)q.C % 16 == 0 && q.sC % 8 == 0 &&
+              q.ldc % 8 == 0 &&
+              (!q.bias || ((uintptr_t)q.bias % 16 == 0 && q.sBias % 4 == 0));
+    }
+    const GemmTile tile = (tt256 || nt256) ? TILE_256x256 : (tile_req == TILE_256x256 ? (ta ? TILE_128x128 : TILE_128x64) : tile_req);
     const int BM = bm_of[tile], BN = bn_of[tile];
     int total = 0;
     for (int j = 0; j < sub.nprob; ++j) {
@@ -133,6 +143,7 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
                tile == TILE_128x128;
     for (int j = 0; j < sub.nprob && ttg; ++j) ttg = sub.p[j].K % 64 == 0;
     if (tt256) rc = gemm_dispatch_tt256(sub, total, stream);
+    else if (nt256) rc = gemm_dispatch_nt256(sub, total, stream);
     else if (ttg) rc = gemm_dispatch_tt_glds(sub, total, env_ttring(), stream);
     else if (glds) rc = gemm_dispatch_nt_glds(sub, total, tile, stream);
     else if (!ta && !tb) rc = gemm_dispatch_nt(sub, total, compute_f32, tile, am, bm, stream);

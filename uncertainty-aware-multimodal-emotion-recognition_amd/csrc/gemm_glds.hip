@@ -39,86 +39,6 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Epilogue straight from the accumulators.  The kernels below issue their MFMAs with the operands swapped
-// (D[n][m] += W-fragment x A-fragment), so a lane holds FOUR CONSECUTIVE COLUMNS n of one output row m:
-// acc[i][j] = C[m = row0 + wm*WTM + 16 i + li][n = col0 + wn*WTN + 16 j + 4 lg + {0..3}].  Bias, ReLU, dropout, the
-// (Y > 0) mask and the store are lane-local: no LDS staging, no barrier, one 8-byte (bf16) / 16-byte (fp32) store
-// per accumulator.  bias4[j] was loaded before the K loop.
-template <int TM, int TN, int WTM, int WTN>
-__device__ __forceinline__ void epilogue_direct(const GemmGroup& g, const __attribute__((address_space(4))) GemmProblem& p,
-                                                f32x4 (&acc)[TM][TN], const f32x4 (&bias4)[TN], int z, int row0, int col0,
-                                                int wm, int wn, int li, int lg) {
-  const int M = p.M, N = p.N;
-  const DropCtx dc = g.drop;
-  const int relu = p.relu, accumulate = p.accumulate, c_f32 = p.c_f32, y_f32 = p.y_f32, shift = p.drop_shift;
-  const int site = p.drop_site >= 0 ? p.drop_site : p.regen_site;
-  const unsigned dkey = site >= 0 ? drop_key(dc, site) : 0u;
-  const void* Yp = p.Y;
-  void* Cp = p.C;
-  const long long ldc = p.ldc, ldy = p.ldy, c_base = (long long)z * p.sC, y_base = (long long)z * p.sY;
-  const float ms = p.mask_scale;
-  const int nb = col0 + wn * WTN + 4 * lg, mb = row0 + wm * WTM + li;
-  // mask source first: all loads in flight together
-  f32x4 yv[TM][TN];
-  if (Yp) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int m = mb + 16 * i, n = nb + 16 * j;
-        yv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m < M && n < N) {
-          const long long yo = y_base + (long long)m * ldy + n;
-          if (y_f32) {
-            yv[i][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Yp) + yo);
-          } else {
-            const u32x2 y = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(Yp) + yo);
-            yv[i][j] = f32x4{__uint_as_float(y.x << 16), __uint_as_float(y.x & 0xFFFF0000u), __uint_as_float(y.y << 16),
-                             __uint_as_float(y.y & 0xFFFF0000u)};
-          }
-        }
-      }
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = mb + 16 * i;
-    if (m >= M) continue;
-    const unsigned rk = ((unsigned)m * 0x9E3779B1u) ^ dkey;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = nb + 16 * j;
-      if (n >= N) continue;   // N % 4 == 0: a 4-column group is all in or all out
-      f32x4 v = acc[i][j] + bias4[j];
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (site >= 0) {
-        const unsigned dcol = (unsigned)(n + z * N);   // batched problems: the column index continues across the batch
-        if (shift == 0) {
-          v.x = mix32(rk ^ (dcol * 0x85EBCA77u)) < dc.thresh ? v.x * dc.scale : 0.f;
-          v.y = mix32(rk ^ ((dcol + 1) * 0x85EBCA77u)) < dc.thresh ? v.y * dc.scale : 0.f;
-          v.z = mix32(rk ^ ((dcol + 2) * 0x85EBCA77u)) < dc.thresh ? v.z * dc.scale : 0.f;
-          v.w = mix32(rk ^ ((dcol + 3) * 0x85EBCA77u)) < dc.thresh ? v.w * dc.scale : 0.f;
-        } else {
-          const float f = mix32(rk ^ ((dcol >> shift) * 0x85EBCA77u)) < dc.thresh ? dc.scale : 0.f;
-          v.x *= f; v.y *= f; v.z *= f; v.w *= f;
-        }
-      }
-      if (Yp) {
-        const f32x4 y = yv[i][j];
-        v.x = y.x > 0.f ? v.x * ms : 0.f; v.y = y.y > 0.f ? v.y * ms : 0.f;
-        v.z = y.z > 0.f ? v.z * ms : 0.f; v.w = y.w > 0.f ? v.w * ms : 0.f;
-      }
-      const long long co = c_base + (long long)m * ldc + n;
-      if (c_f32) {
-        float* cp = reinterpret_cast<float*>(Cp) + co;
-        if (accumulate) v += *reinterpret_cast<const f32x4*>(cp);
-        *reinterpret_cast<f32x4*>(cp) = v;
-      } else {
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(Cp) + co) = u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
-      }
-    }
-  }
-}
-
 // pieces (1 KiB wave-instructions) each wave issues per K-tile
 template <int BM, int BN> struct Glds { static constexpr int PA = BM / 32, PB = BN / 32, LPT = PA + PB; };
 
@@ -277,7 +197,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_gl
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(warm0), "s"(warm1), "s"(warm2), "s"(warm3) : "memory");
   KSTAMP(4);
-  epilogue_direct<TM, TN, WTM, WTN>(g, p, acc, bias4, z, row0, col0, wm, wn, li, lg);
+  epilogue_direct<TM, TN, WTM, WTN, true>(g, p, acc, bias4, z, row0, col0, wm, wn, li, lg);
 #ifdef MMDEER_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
