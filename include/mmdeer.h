@@ -180,6 +180,32 @@ int mmdeer_nig_loss(const float* gamma, const float* nu, const float* alpha, con
 int mmdeer_dropout_mask(int site, int rows, int cols, float dropout_p, uint64_t seed, uint64_t offset,
                         unsigned char* out, void* stream);
 
+/* ---- optimiser step on the device (reference src/training/training.py:121-150, 219-224) ------------
+ * clip_grad_norm_(max_grad_norm) + torch.optim.AdamW (decoupled weight decay, eps 1e-8 in the reference) on the flat
+ * gradient buffer of mmdeer_backward.  Updates the fp32 master parameters in place and refreshes, in `workspace`,
+ * the packed copies mmdeer_forward / mmdeer_backward read -- so the next mmdeer_forward may pass repack = 0.
+ * `lr` is a HOST array with one learning rate per live parameter (ABI order): the reference's three parameter
+ * groups (0.5 lr for names containing "encoder", lr otherwise) reduce to that.  No host synchronisation. */
+typedef struct {
+  int32_t batch;              /* batch size the workspace was sized for */
+  int32_t compute_f32;        /* dtype of the packed matrices, as in mmdeer_forward */
+  int32_t pack_transposed;    /* 1: also refresh the W^T copies used by mmdeer_backward */
+  int32_t step;               /* 1-based step count t (bias corrections 1 - beta^t) */
+  float beta1, beta2, eps, weight_decay;
+  float max_grad_norm;        /* > 0: gradients *= min(1, max_grad_norm / (||g||_2 + 1e-6)); <= 0: no clipping */
+  float grad_scale;           /* gradients are multiplied by this first (dataset weight); 1 = none */
+  const float* lr;            /* host array [mmdeer_num_params()] */
+  void** params;              /* fp32 master parameters (device), canonical order, updated in place */
+  const float* grads;         /* flat gradient buffer, mmdeer_flat_elems() floats */
+  float* exp_avg;             /* flat first moments  (mmdeer_flat_elems() floats, zero before the first step) */
+  float* exp_avg_sq;          /* flat second moments */
+  float* grad_norm;           /* device scalar out (may be NULL): global gradient norm before clipping */
+  void* workspace;
+  size_t workspace_bytes;
+  void* stream;
+} mmdeer_adamw_args;
+int mmdeer_adamw_step(const mmdeer_adamw_args* a);
+
 /* ---- side rows (a8, a9, a14), forward only --------------------------------------------------------
  * Their Linear(+ReLU) layers run on mmdeer_gemm and the LayerNorm on mmdeer_layernorm_fwd; the two entry points
  * below are the parts that are neither.

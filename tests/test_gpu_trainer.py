@@ -81,3 +81,51 @@ def test_launcher_quick_run(tmp_path):
     assert len(rep["history"]["train_loss"]) == 2
     assert rep["sample_predictions"]["nig_keys"] == ["gamma", "nu", "alpha", "beta"]
     assert np.array(rep["sample_predictions"]["predictions"]).shape == (4, 3)
+
+
+def test_fused_adamw_matches_torch_adamw_with_clipping():
+    """optim.FusedAdamW (mmdeer_adamw_step) against clip_grad_norm_ + torch.optim.AdamW on the same gradients, three
+    steps, two learning-rate groups; and the packed weights it leaves behind drive the next forward."""
+    import copy
+
+    from mmdeer.model import ModelConfig, MultimodalDEER
+    from mmdeer.optim import FusedAdamW
+
+    torch.manual_seed(0)
+    m1 = MultimodalDEER(ModelConfig(compute_dtype="fp32", seed=3)).to("cuda:0").train()
+    m2 = copy.deepcopy(m1)
+    b = synth.make_batch(48, seed=5)
+    a, v, t, y = (torch.from_numpy(b[k]).to("cuda:0") for k in ("audio", "video", "text", "targets"))
+
+    def groups(m):
+        enc = [p for n, p in m.named_parameters() if "projection" in n]
+        rest = [p for n, p in m.named_parameters() if "projection" not in n]
+        return [{"params": enc, "lr": 5e-4}, {"params": rest, "lr": 1e-3}]
+
+    o1 = FusedAdamW(m1, groups(m1), weight_decay=0.01, eps=1e-8, max_grad_norm=0.5)
+    o2 = torch.optim.AdamW(groups(m2), weight_decay=0.01, eps=1e-8)
+    def worst_diff():
+        return max(((p1 - p2).abs().max().item(), n) for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()))
+
+    for step in range(3):
+        m1._step = m2._step = 10 + step          # identical dropout masks
+        l1 = m1.train_step(a, v, t, y)
+        l2 = m2.train_step(a, v, t, y)
+        assert float(l1["total_loss"]) == pytest.approx(float(l2["total_loss"]), rel=1e-5)
+        n1 = o1.step()
+        n2 = torch.nn.utils.clip_grad_norm_([p for p in m2.parameters() if p.grad is not None], 0.5)
+        o2.step()
+        assert float(n1) == pytest.approx(float(n2), rel=1e-5)
+        if step == 0:
+            # identical gradients in: the two updates may differ by rounding only
+            w = worst_diff()
+            assert w[0] < 2.5e-7, w          # one ulp at |p| ~ 1 (LayerNorm weights)
+    # later steps: Adam normalises every element's update to ~lr, so elements whose gradient is rounding noise
+    # (dead units) legitimately diverge by a fraction of lr; everything else stays together
+    diffs = torch.cat([(p1 - p2).abs().flatten() for p1, p2 in zip(m1.parameters(), m2.parameters())])
+    assert (diffs > 2e-6).float().mean().item() < 1e-3
+    assert diffs.max().item() < 3e-3
+    # the fused step refreshed the packed copies: an eval forward through each model agrees
+    m1.eval(); m2.eval()
+    out1, out2 = m1(a, v, t), m2(a, v, t)
+    assert torch.allclose(out1["mu_all"], out2["mu_all"], rtol=1e-4, atol=1e-5)

@@ -59,6 +59,17 @@ class BackwardArgs(C.Structure):
     ]
 
 
+class AdamWArgs(C.Structure):
+    _fields_ = [
+        ("batch", c_int), ("compute_f32", c_int), ("pack_transposed", c_int), ("step", c_int),
+        ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
+        ("max_grad_norm", c_float), ("grad_scale", c_float),
+        ("lr", C.POINTER(c_float)), ("params", C.POINTER(c_void_p)), ("grads", c_void_p),
+        ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("grad_norm", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("stream", c_void_p),
+    ]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("bias_grad", c_void_p), ("Y", c_void_p),
@@ -96,6 +107,7 @@ SYMBOLS = [
     ("mmdeer_nig_stats_elems", c_ll, [c_int]),
     ("mmdeer_nig_loss", c_int, [c_void_p] * 12 + [c_int, C.POINTER(LossCfg), c_void_p]),
     ("mmdeer_dropout_mask", c_int, [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p]),
+    ("mmdeer_adamw_step", c_int, [C.POINTER(AdamWArgs)]),
     ("mmdeer_cross_modal_attn_fwd", c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     ("mmdeer_lstm_cell_t1", c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_convert", c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p]),

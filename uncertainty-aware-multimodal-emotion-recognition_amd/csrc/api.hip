@@ -11,6 +11,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "nig.h"
+#include "optim.h"
 #include "rowops.h"
 
 namespace mmdeer {
@@ -290,6 +291,32 @@ int check_common(int batch, const void* ws, size_t ws_bytes, int f32) {
   return 0;
 }
 
+// W^T copies (compute dtype) of the matrices whose dX the backward chain needs, at their flat offsets in L.wtpack
+int pack_transposed_weights(const void* const* params, const Layout& L, int f32, hipStream_t s) {
+  PackTTable tt{};
+  for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
+    if (!kParams[i].is_matrix || i == P_AUD_W || i == P_VID_W || i == P_TXT_W || i >= P_EV2_W) continue;  // no dX needed
+    const int k = tt.nmat++;
+    tt.src[k] = reinterpret_cast<const float*>(params[i]);
+    tt.dst_off[k] = kParams[i].off;
+    tt.rows[k] = kParams[i].rows; tt.cols[k] = kParams[i].cols;
+    if (i >= P_EV0_W && i < P_EV0_W + 3) {   // the three stacked first head layers: one [256][3*128] image
+      tt.dst_off[k] = kParams[P_EV0_W].off;
+      tt.ld_dst[k] = 3 * EV1;
+      tt.dst_col[k] = (i - P_EV0_W) * EV1;
+    }
+  }
+  return launch_pack_transposed(tt, L.wtpack, f32, s);
+}
+
+// bf16 mode: the [256][128] zero-padded copy of audio_projection.weight
+int pad_audio_weight(const void* const* params, const Layout& L, hipStream_t s) {
+  PadTable pt{};
+  pt.src[0] = params[P_AUD_W]; pt.dst[0] = L.wa_pad; pt.src_f32[0] = 1; pt.rows[0] = INTER; pt.cols[0] = AUD; pt.ld_dst[0] = AUD_PAD;
+  pt.nseg = 1;
+  return launch_pad_cols(pt, s);
+}
+
 }  // namespace
 }  // namespace mmdeer
 
@@ -338,31 +365,11 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     }
     TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
     // W^T copies for the backward dX GEMMs (only when this call trains: inference never reads them)
-    if (a->training || a->targets) {
-      PackTTable tt{};
-      for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
-        if (!kParams[i].is_matrix || i == P_AUD_W || i == P_VID_W || i == P_TXT_W || i >= P_EV2_W) continue;  // no dX needed
-        const int k = tt.nmat++;
-        tt.src[k] = reinterpret_cast<const float*>(a->params[i]);
-        tt.dst_off[k] = kParams[i].off;
-        tt.rows[k] = kParams[i].rows; tt.cols[k] = kParams[i].cols;
-        if (i >= P_EV0_W && i < P_EV0_W + 3) {   // the three stacked first head layers: one [256][3*128] image
-          tt.dst_off[k] = kParams[P_EV0_W].off;
-          tt.ld_dst[k] = 3 * EV1;
-          tt.dst_col[k] = (i - P_EV0_W) * EV1;
-        }
-      }
-      TRY(launch_pack_transposed(tt, L.wtpack, f32, s));
-    }
+    if (a->training || a->targets) TRY(pack_transposed_weights(a->params, L, f32, s));
   }
   const bool wa_pending = a->repack && !f32;   // the padded bf16 copy of audio_projection.weight follows the parameters
   if (B == 0) {
-    if (wa_pending) {
-      PadTable pt{};
-      pt.src[0] = a->params[P_AUD_W]; pt.dst[0] = L.wa_pad; pt.src_f32[0] = 1; pt.rows[0] = INTER; pt.cols[0] = AUD; pt.ld_dst[0] = AUD_PAD;
-      pt.nseg = 1;
-      TRY(launch_pad_cols(pt, s));
-    }
+    if (wa_pending) TRY(pad_audio_weight(a->params, L, s));
     return 0;
   }
   MMDEER_CHECK(a->audio && a->video && a->text, "audio / video / text must be non-NULL");
@@ -599,6 +606,41 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   TRY(launch_reduce_partials(rt, s));
   for (int b = 0; b < 3; ++b)
     if (a->bucket_events[b]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[b], s));
+  return 0;
+}
+
+// ------------------------------------------------------------------ optimiser step
+int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
+  MMDEER_CHECK(a != nullptr, "args is NULL");
+  const int f32 = a->compute_f32 ? 1 : 0;
+  TRY(check_common(a->batch, a->workspace, a->workspace_bytes, f32));
+  MMDEER_CHECK(a->params && a->grads && a->exp_avg && a->exp_avg_sq && a->lr, "adamw: params / grads / exp_avg / exp_avg_sq / lr must be non-NULL");
+  MMDEER_CHECK(a->step >= 1, "adamw: step must be >= 1 (got %d)", a->step);
+  MMDEER_CHECK(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps > 0.f, "adamw: bad betas / eps");
+  hipStream_t s = (hipStream_t)a->stream;
+  const Layout L = make_layout(a->workspace, a->batch, f32);
+  AdamTable t{};
+  t.nseg = MMDEER_NUM_PARAMS;
+  for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
+    MMDEER_CHECK(a->params[i] != nullptr && ((uintptr_t)a->params[i] % 16) == 0, "adamw: params[%d] (%s) must be non-NULL and 16-byte aligned", i, kParams[i].name);
+    t.param[i] = reinterpret_cast<float*>(a->params[i]);
+    t.off[i] = kParams[i].off;
+    t.n[i] = kParams[i].rows * kParams[i].cols;
+    t.is_vec[i] = kParams[i].is_matrix ? 0 : 1;
+    t.lr[i] = a->lr[i];
+  }
+  t.grads = a->grads; t.exp_avg = a->exp_avg; t.exp_avg_sq = a->exp_avg_sq;
+  t.partials = L.slab;              // the split-K slab is idle between backward passes
+  t.norm_out = a->grad_norm;
+  t.flat_elems = MMDEER_FLAT_ELEMS;
+  t.beta1 = a->beta1; t.beta2 = a->beta2; t.eps = a->eps; t.weight_decay = a->weight_decay;
+  t.bias_corr1 = 1.f - powf(a->beta1, (float)a->step);
+  t.bias_corr2 = 1.f - powf(a->beta2, (float)a->step);
+  t.max_norm = a->max_grad_norm; t.grad_scale = a->grad_scale;
+  TRY(launch_adamw_pack(t, L.wpack, f32, L.vpack, s));
+  const void* const* cparams = const_cast<const void* const*>(a->params);
+  if (a->pack_transposed) TRY(pack_transposed_weights(cparams, L, f32, s));
+  if (!f32) TRY(pad_audio_weight(cparams, L, s));
   return 0;
 }
 

@@ -82,6 +82,8 @@ class _State:
         self.workspaces: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self.generation = 0
         self.packed_key = None
+        self.param_gen = 0        # bumped by in-place parameter updates torch cannot see (optim.FusedAdamW)
+        self.last_train = None    # (workspace, batch) of the most recent train_step
 
 
 class _ForwardFn(torch.autograd.Function):
@@ -212,6 +214,8 @@ class MultimodalDEER(nn.Module):
         self._flat_grad: Optional[torch.Tensor] = None
         self._step_flat: Optional[torch.Tensor] = None
         self._step_views = None
+        self._grads_bound = False
+        self._ptr_cache = None     # (tuple of data_ptrs, ctypes array) of the live parameters
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -244,7 +248,7 @@ class MultimodalDEER(nn.Module):
         return ws
 
     def _param_key(self, ws: torch.Tensor):
-        return (ws.data_ptr(),) + tuple((p.data_ptr(), p._version) for p in self._live)
+        return (ws.data_ptr(), self._st.param_gen) + tuple((p.data_ptr(), p._version) for p in self._live)
 
     def _launch_forward(self, audio, video, text, targets, prof_events=None):
         lib = _lib.load()
@@ -259,9 +263,12 @@ class MultimodalDEER(nn.Module):
             audio, video, text = audio.float(), video.float(), text.float()
             in_bf16 = False
         dev = audio.device
-        for p in self._live:
-            if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
-                raise RuntimeError("mmdeer: parameters must be contiguous fp32 tensors on the inputs' device")
+        ptrs = tuple(p.data_ptr() for p in self._live)
+        if self._ptr_cache is None or self._ptr_cache[0] != ptrs or self._ptr_cache[2] != dev:
+            for p in self._live:
+                if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("mmdeer: parameters must be contiguous fp32 tensors on the inputs' device")
+            self._ptr_cache = (ptrs, (C.c_void_p * len(ptrs))(*ptrs), dev)
         ws = self._workspace(B, dev)
         key = self._param_key(ws)
         repack = key != self._st.packed_key
@@ -272,8 +279,7 @@ class MultimodalDEER(nn.Module):
         a.batch, a.compute_f32, a.training, a.inputs_bf16, a.repack = B, self.compute_f32, int(training), int(in_bf16), int(repack)
         a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), int(self._step)
         a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
-        arr = (C.c_void_p * len(self._live))(*[p.data_ptr() for p in self._live])
-        a.params = arr
+        a.params = self._ptr_cache[1]
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         f32 = dict(dtype=torch.float32, device=dev)
         nig = torch.empty(7, B, 3, **f32)
@@ -299,7 +305,7 @@ class MultimodalDEER(nn.Module):
                 "trimodal_features": trif, "av_attention": avw, "trimodal_attention": triw}
 
     def _launch_backward(self, ctx_or_meta, targets, g_mu=None, g_nu=None, g_alpha=None, g_beta=None,
-                         loss_out=None, bin_counts=None, events=None, flat=None):
+                         loss_out=None, bin_counts=None, events=None, flat=None, want_views=True):
         lib = _lib.load()
         if isinstance(ctx_or_meta, dict):
             meta = ctx_or_meta
@@ -339,10 +345,9 @@ class MultimodalDEER(nn.Module):
         a.stream = _lib.current_stream()
         _lib.check(lib.mmdeer_backward(C.byref(a)))
         self._flat_grad = flat
-        views = []
-        for p, off in zip(self._live, self._offsets):
-            views.append(flat[off:off + p.numel()].view(p.shape))
-        return views
+        if not want_views:
+            return None
+        return [flat[off:off + p.numel()].view(p.shape) for p, off in zip(self._live, self._offsets)]
 
     # ------------------------------------------------------------------ reference-facing API
     def forward(self, audio_features, video_features=None, text_features=None, targets=None) -> Dict[str, torch.Tensor]:
@@ -401,6 +406,7 @@ class MultimodalDEER(nn.Module):
         o = self._launch_forward(audio, video, text, targets, prof_events)
         meta = o["_meta"]
         dev = meta["ws"].device
+        self._st.last_train = (meta["ws"], meta["B"])
         loss_out = torch.empty(20, dtype=torch.float32, device=dev)
         bins = torch.empty(30, dtype=torch.int32, device=dev)
         # the fused path owns ONE persistent flat gradient buffer per device (zeroed once: the alignment gaps stay 0);
@@ -409,12 +415,16 @@ class MultimodalDEER(nn.Module):
             self._step_flat = torch.zeros(self._flat_elems, dtype=torch.float32, device=dev)
             self._step_views = None
         views = self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, events=events,
-                                      flat=self._step_flat)
+                                      flat=self._step_flat, want_views=self._step_views is None)
         if self._step_views is None:
             self._step_views = views
-        for p, g in zip(self._live, self._step_views):
-            if p.grad is not g:
-                p.grad = g
+            self._grads_bound = False
+        if (not self._grads_bound or self._live[0].grad is not self._step_views[0]
+                or self._live[-1].grad is not self._step_views[-1]):
+            for p, g in zip(self._live, self._step_views):
+                if p.grad is not g:
+                    p.grad = g
+            self._grads_bound = True
         d = loss_dict_from(loss_out, meta["B"])
         d["ece_bin_counts"] = bins.view(3, 10)
         d["_outputs"] = o

@@ -20,6 +20,7 @@ import torch
 
 from .metrics import validation_metrics
 from .model import MultimodalDEER
+from .optim import FusedAdamW
 
 
 @dataclass
@@ -30,6 +31,7 @@ class TrainingConfig:
     batch_size: int = 32
     num_epochs: int = 100
     scheduler_type: str = "cosine"
+    fused_optimizer: bool = True   # clip + AdamW + weight pack on the device (optim.FusedAdamW); False: torch.optim.AdamW
     warmup_epochs: int = 5
     patience: int = 10
     evidence_weight: float = 1.0
@@ -75,6 +77,10 @@ class DEERTrainer:
             (enc if "encoder" in name else att if "attention" in name else rest).append(p)
         lr = self.config.learning_rate
         groups = [g for g in ({"params": enc, "lr": lr * 0.5}, {"params": att, "lr": lr}, {"params": rest, "lr": lr}) if g["params"]]
+        if self.config.fused_optimizer:
+            # clip_grad_norm_ + AdamW + weight pack as one device-side step (optim.FusedAdamW)
+            return FusedAdamW(self.model, groups, lr=lr, weight_decay=self.config.weight_decay, eps=1e-8,
+                              max_grad_norm=self.config.gradient_clip)
         return torch.optim.AdamW(groups, weight_decay=self.config.weight_decay, eps=1e-8)
 
     def _create_scheduler(self):
@@ -106,13 +112,17 @@ class DEERTrainer:
                 a, v, t, y = unpack_batch(batch, self.device)
                 # no zero_grad(): the fused step overwrites every live gradient slice of the flat buffer
                 ld = self.model.train_step(a, v, t, y, events=events)     # forward + loss + backward, fused
-                if w != 1.0:
-                    self.model.flat_grad().mul_(w)                         # weighted_loss = total_loss * weight (:211-212)
                 if self.comm is not None:
                     self.comm.launch(self.model.flat_grad())
                     self.comm.wait(self.model.flat_grad())
-                norms.append(self.clip_gradients())
-                self.optimizer.step()
+                if isinstance(self.optimizer, FusedAdamW):
+                    # weighted_loss = total_loss * weight (:211-212) enters as a gradient scale; clip + step on the device
+                    norms.append(self.optimizer.step(grad_scale=w))
+                else:
+                    if w != 1.0:
+                        self.model.flat_grad().mul_(w)
+                    norms.append(self.clip_gradients())
+                    self.optimizer.step()
                 bs = a.shape[0]
                 sums += torch.stack([ld[k].double() for k in keys]) * bs    # accumulated on device: no .item() per batch
                 total += bs
