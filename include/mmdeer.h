@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 1
+#define MMDEER_ABI_VERSION 2
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -74,6 +74,8 @@ typedef struct mmdeer_forward_args {
   int32_t repack;           /* 1: parameters changed since the last call with this workspace */
   float dropout_p;
   uint64_t seed, offset;
+  const uint64_t* offset_dev; /* optional device counter added to `offset` when the kernels run: lets a captured HIP
+                               * graph draw fresh dropout masks on every replay (NULL: offset alone) */
   const void* audio;        /* [B, 84]  */
   const void* video;        /* [B, 256] */
   const void* text;         /* [B, 768] */
@@ -107,6 +109,7 @@ typedef struct mmdeer_backward_args {
   int32_t inputs_bf16;
   float dropout_p;
   uint64_t seed, offset;    /* the values given to the matching mmdeer_forward */
+  const uint64_t* offset_dev;
   const void* audio;
   const void* video;
   const void* text;

@@ -262,3 +262,30 @@ def test_state_dict_roundtrip_and_repack():
         assert not torch.allclose(o1, m2(a, v, t)["mu_all"])
         m2.load_state_dict(m1.state_dict())          # in-place copy_ bumps versions -> repack
         assert torch.equal(o1, m2(a, v, t)["mu_all"])
+
+
+def test_graph_captured_train_step_matches_eager():
+    """capture_train_step (HIP graph, dropout counter on the device) reproduces the eager steps: same losses and
+    gradients step by step, fresh masks on every replay."""
+    import copy
+
+    m1 = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=11)).to("cuda:0").train()
+    m2 = copy.deepcopy(m1)
+    b = synth.make_batch(256, seed=9)
+    a, v, t, y = (torch.from_numpy(b[k]).to("cuda:0") for k in ("audio", "video", "text", "targets"))
+    replay = m1.capture_train_step(a, v, t, y)       # runs one eager warm-up step (dropout step 1) before capturing
+    m2.train_step(a, v, t, y)                        # keep the eager twin's step counter in sync
+    losses = []
+    for _ in range(3):
+        d1 = replay()
+        d2 = m2.train_step(a, v, t, y)
+        assert float(d1["total_loss"]) == float(d2["total_loss"])
+        assert torch.equal(m1.flat_grad(), m2.flat_grad())
+        losses.append(float(d1["total_loss"]))
+    assert len(set(losses)) == 3                     # different dropout masks each replay
+    # new data goes in through the captured tensors
+    b2 = synth.make_batch(256, seed=10)
+    a.copy_(torch.from_numpy(b2["audio"])); v.copy_(torch.from_numpy(b2["video"]))
+    t.copy_(torch.from_numpy(b2["text"])); y.copy_(torch.from_numpy(b2["targets"]))
+    d1, d2 = replay(), m2.train_step(a, v, t, y)
+    assert float(d1["total_loss"]) == float(d2["total_loss"])

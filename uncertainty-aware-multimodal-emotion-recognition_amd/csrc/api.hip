@@ -121,10 +121,11 @@ Layout make_layout(void* base, int B, int f32) {
   return L;
 }
 
-DropCtx make_drop(float p, uint64_t seed, uint64_t offset) {
+DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev = nullptr) {
   DropCtx d;
   d.seed = seed;
   d.offset = offset;
+  d.offset_dev = reinterpret_cast<const unsigned long long*>(offset_dev);
   double keep = 1.0 - (double)p;
   if (keep < 0) keep = 0;
   double t = keep * 4294967296.0;
@@ -378,7 +379,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   Exec X;
   X.B = B; X.f32 = f32; X.es = f32 ? 4 : 2; X.L = &L; X.s = s;
   X.drop_on = a->training && a->dropout_p > 0.f;
-  X.dc = make_drop(a->dropout_p, a->seed, a->offset);
+  X.dc = make_drop(a->dropout_p, a->seed, a->offset, a->offset_dev);
   X.mask_scale = X.drop_on ? X.dc.scale : 1.f;
   const int in_f32 = a->inputs_bf16 ? 0 : 1;
   const size_t es = X.es;
@@ -475,7 +476,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   Exec X;
   X.B = B; X.f32 = f32; X.es = f32 ? 4 : 2; X.L = &L; X.s = s;
   X.drop_on = a->training && a->dropout_p > 0.f;
-  X.dc = make_drop(a->dropout_p, a->seed, a->offset);
+  X.dc = make_drop(a->dropout_p, a->seed, a->offset, a->offset_dev);
   X.mask_scale = X.drop_on ? X.dc.scale : 1.f;
   const int in_f32 = a->inputs_bf16 ? 0 : 1;
   const size_t es = X.es;

@@ -48,13 +48,18 @@ struct DropCtx {
   unsigned long long offset;  // step counter: advanced by the host every training step
   unsigned thresh;            // keep iff rnd < thresh ; thresh = floor((1-p) * 2^32)
   float scale;                // 1 / (1 - p)
+  const unsigned long long* offset_dev;   // optional device-resident counter added to `offset` (HIP-graph replays)
 };
 
 __host__ __device__ __forceinline__ unsigned drop_key(const DropCtx& d, int site) {
+  unsigned long long off = d.offset;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (d.offset_dev) off += *d.offset_dev;   // device code only: the host never holds a device counter
+#endif
   unsigned k = mix32((unsigned)d.seed ^ 0x9E3779B9u);
   k = mix32(k ^ (unsigned)(d.seed >> 32));
-  k = mix32(k ^ (unsigned)d.offset);
-  k = mix32(k ^ (unsigned)(d.offset >> 32) ^ ((unsigned)site * 0x85EBCA6Bu));
+  k = mix32(k ^ (unsigned)off);
+  k = mix32(k ^ (unsigned)(off >> 32) ^ ((unsigned)site * 0x85EBCA6Bu));
   return k;
 }
 __host__ __device__ __forceinline__ unsigned drop_rand1(unsigned key, unsigned row, unsigned c) {

@@ -250,7 +250,7 @@ class MultimodalDEER(nn.Module):
     def _param_key(self, ws: torch.Tensor):
         return (ws.data_ptr(), self._st.param_gen) + tuple((p.data_ptr(), p._version) for p in self._live)
 
-    def _launch_forward(self, audio, video, text, targets, prof_events=None):
+    def _launch_forward(self, audio, video, text, targets, prof_events=None, offset_dev=None):
         lib = _lib.load()
         audio, video, text = (_as_cuda_f32(t, n) for t, n in ((audio, "audio"), (video, "video"), (text, "text")))
         B = audio.shape[0]
@@ -273,11 +273,14 @@ class MultimodalDEER(nn.Module):
         key = self._param_key(ws)
         repack = key != self._st.packed_key
         training = self.training
-        if training:
+        if training and offset_dev is None:
             self._step += 1
         a = _lib.ForwardArgs()
         a.batch, a.compute_f32, a.training, a.inputs_bf16, a.repack = B, self.compute_f32, int(training), int(in_bf16), int(repack)
-        a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), int(self._step)
+        # graph mode: the step counter lives on the device (offset_dev) and the host-side offset is 0
+        step = 0 if offset_dev is not None else int(self._step)
+        a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), step
+        a.offset_dev = _lib.ptr(offset_dev)
         a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
         a.params = self._ptr_cache[1]
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -299,7 +302,7 @@ class MultimodalDEER(nn.Module):
         _lib.check(lib.mmdeer_forward(C.byref(a)))
         self._st.packed_key = key
         self._st.generation += 1
-        meta = dict(B=B, training=int(training), in_bf16=int(in_bf16), offset=int(self._step), ws=ws,
+        meta = dict(B=B, training=int(training), in_bf16=int(in_bf16), offset=step, offset_dev=offset_dev, ws=ws,
                     inputs=(audio, video, text), targets=targets)
         return {"_nig": nig, "_meta": meta, "fused_features": fused, "audiovisual_features": avf,
                 "trimodal_features": trif, "av_attention": avw, "trimodal_attention": triw}
@@ -323,6 +326,7 @@ class MultimodalDEER(nn.Module):
         a = _lib.BackwardArgs()
         a.batch, a.compute_f32, a.training, a.inputs_bf16 = B, self.compute_f32, meta["training"], meta["in_bf16"]
         a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), meta["offset"]
+        a.offset_dev = _lib.ptr(meta.get("offset_dev"))
         audio, video, text = meta["inputs"]
         a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
         a.workspace, a.workspace_bytes = meta["ws"].data_ptr(), meta["ws"].numel()
@@ -399,11 +403,11 @@ class MultimodalDEER(nn.Module):
         """The trainer hook (training.py:210): MultiTaskDEERLoss defaults, dict with a backprop-able 'total_loss'."""
         return multitask_deer_loss(predictions, targets, self.loss_cfg)
 
-    def train_step(self, audio, video, text, targets, events=None, prof_events=None) -> Dict[str, torch.Tensor]:
+    def train_step(self, audio, video, text, targets, events=None, prof_events=None, _offset_dev=None) -> Dict[str, torch.Tensor]:
         """Fused forward + MultiTaskDEERLoss + backward: two library calls, gradients land in one flat buffer
         (``.grad`` of every live parameter is a view of it).  Equivalent to
         ``compute_loss(model(a, v, t), y)['total_loss'].backward()``."""
-        o = self._launch_forward(audio, video, text, targets, prof_events)
+        o = self._launch_forward(audio, video, text, targets, prof_events, offset_dev=_offset_dev)
         meta = o["_meta"]
         dev = meta["ws"].device
         self._st.last_train = (meta["ws"], meta["B"])
@@ -432,6 +436,36 @@ class MultimodalDEER(nn.Module):
 
     def flat_grad(self) -> Optional[torch.Tensor]:
         return self._flat_grad
+
+    def capture_train_step(self, audio, video, text, targets, events=None):
+        """Capture ``train_step`` on these (static) input tensors into a HIP graph and return ``replay()``.
+
+        One step is ~45 kernel launches of 4-40 us each; enqueueing them from the host costs about as much as the GPU
+        needs to run them, a graph replay costs ~15 us.  ``replay()`` returns the same loss dict every time (its
+        tensors are overwritten in place); new data is fed by copying into ``audio/video/text/targets``.  Dropout
+        masks advance through a device-side counter (``offset_dev``), so replays draw fresh masks.  The packed
+        weight copies must be current at capture time and be kept current by ``optim.FusedAdamW`` (an eager call
+        between replays); shapes, dtype and train mode are frozen into the graph."""
+        if not self.training:
+            raise RuntimeError("capture_train_step: call .train() first")
+        for t in (audio, video, text, targets):
+            if not t.is_cuda:
+                raise RuntimeError("capture_train_step needs GPU tensors")
+        dev = audio.device
+        # eager warm-up: allocates the workspace and the persistent gradient buffer, packs the weights
+        self.train_step(audio, video, text, targets)
+        self._graph_counter = torch.full((), int(self._step), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._graph_counter.add_(1)
+            out = self.train_step(audio, video, text, targets, events=events, _offset_dev=self._graph_counter)
+        self._graph = graph
+
+        def replay():
+            graph.replay()
+            return out
+        return replay
 
 
 def _stack_pred(predictions: Dict[str, torch.Tensor], names) -> torch.Tensor:
