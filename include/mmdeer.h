@@ -101,7 +101,9 @@ int mmdeer_forward(const mmdeer_forward_args* a);
 /* Backward through the whole path, using the activations `mmdeer_forward` left in `workspace`.
  *   loss mode  (targets != NULL): d MultiTaskDEERLoss / d parameters; loss_out / bin_counts are filled.
  *   chain mode (targets == NULL): g_mu/g_nu/g_alpha/g_beta [B,3] are upstream gradients (each may be NULL).
- * grads: flat fp32 buffer of mmdeer_flat_elems() elements; every live parameter's slice is overwritten. */
+ * grads: flat fp32 buffer of mmdeer_flat_elems() elements, ZERO-INITIALISED ONCE by the caller: every slice that
+ * receives a gradient is overwritten by each call; the 64-element alignment gaps and the q/k thirds of the AV
+ * in_proj (which the reference also leaves at exactly zero: L = S = 1) are never written and keep those zeros. */
 typedef struct mmdeer_backward_args {
   int32_t batch;
   int32_t compute_f32;

@@ -53,15 +53,10 @@ __device__ __forceinline__ float dot8(const V8& a, const V8& b) {
   return s;
 }
 // sum over the 8 lanes of one head
-__device__ __forceinline__ float head_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  return v;
-}
+__device__ __forceinline__ float head_sum(float v) { return oct_sum(v); }
 // sum over the 8 heads (lanes with equal j)
 __device__ __forceinline__ float heads_sum(float v) {
-  v += __shfl_xor(v, 8, 64);
+  v += dpp_read<0x128>(v);          // row_ror:8 == lane ^ 8 inside a 16-lane row
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
   return v;

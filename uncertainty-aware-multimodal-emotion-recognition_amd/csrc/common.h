@@ -90,10 +90,33 @@ enum DropSite {
 };
 
 // ---------------------------------------------------------------- wave helpers (wave = 64 lanes)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums on DPP (data-parallel primitives: a lane permutation folded into the VALU op, a few cycles each)
+// instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32 -- an LDS-crossbar round trip of ~100 cycles per
+// step; the loss-statistics reduction alone was 35 x 6 of them.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_read(float v) {   // lanes outside ROW_MASK / without a source read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+// sum over aligned groups of 4 / 8 / 16 lanes, result in every lane of the group
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_read<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_read<0x4E>(v);   // quad_perm [2,3,0,1]
   return v;
+}
+__device__ __forceinline__ float oct_sum(float v) {
+  v = quad_sum(v);
+  return v + dpp_read<0x141>(v);   // row_half_mirror: the other quad of the 8-lane group
+}
+__device__ __forceinline__ float row_sum(float v) {
+  v = oct_sum(v);
+  return v + dpp_read<0x140>(v);   // row_mirror: the other half of the 16-lane row
+}
+// sum over the 64 lanes, result in every lane (fixed order: deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_sum(v);
+  v += dpp_read<0x142, 0xA>(v);    // row_bcast:15 -> rows 1 and 3 add the sum of the row below
+  v += dpp_read<0x143, 0xC>(v);    // row_bcast:31 -> rows 2 and 3 add rows 0 + 1: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---------------------------------------------------------------- error plumbing

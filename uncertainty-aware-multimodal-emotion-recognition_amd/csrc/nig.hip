@@ -229,11 +229,6 @@ __device__ __forceinline__ void store_chunk16(void* base, long long idx, const f
   }
 }
 
-__device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lanes of a quad, result in every lane
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  return v;
-}
 
 // ------------------------------------------------------------------ forward (+ loss statistics)
 template <bool F32>
