@@ -7,4 +7,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   ( cd /tmp && timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc/p$i -- python3 $ROOT/tools/pmc_gemm.py > $ROOT/gpurun_out/pmc/p$i.log 2>&1; echo "pass $i rc=$?" )
 done
-find gpurun_out/pmc -name "*counter_collection.csv" | head
+python tools/pmc_summary.py

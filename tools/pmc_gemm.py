@@ -12,8 +12,9 @@ from mmdeer import _lib  # noqa: E402
 lib = _lib.load()
 dev = torch.device("cuda:0")
 B = 4096
-CONFIGS = [("fwd512", B, 512, 512, 0, 0, 0, 1), ("fwd_inproj_t2", 2 * B, 1536, 512, 0, 0, 2, 1), ("fwd_inproj_t0", 2 * B, 1536, 512, 0, 0, 0, 1),
-           ("dx512", B, 512, 512, 0, 1, 0, 1), ("dw512_t2_sk8", 512, 512, B, 1, 1, 2, 8)]
+CONFIGS = [("fwd512_64x64", B, 512, 512, 0, 0, 0, 1), ("fwd_inproj_256x256", 2 * B, 1536, 512, 0, 0, 3, 1),
+           ("fwd_inproj_128x64", 2 * B, 1536, 512, 0, 0, 1, 1), ("dw_inproj_256x256_sk8", 1536, 512, 2 * B, 1, 1, 3, 8),
+           ("dw512_256x256_sk4", 512, 512, B, 1, 1, 3, 4)]
 for tag, M, N, K, ta, tw, tile, sk in CONFIGS:
     dt = torch.bfloat16
     A = torch.randn((K, M) if ta else (M, K), device=dev).to(dt)
