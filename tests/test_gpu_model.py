@@ -4,6 +4,7 @@ the CPU oracle and the golden vectors captured from the reference.
 Tolerances: fp32 config <= 1e-4 abs on mu / nu / alpha / beta (BASELINE north star);
 bf16 config gated on CCC >= 0.999 and a documented absolute band (SURVEY 7 "hard parts").
 """
+import json
 import os
 
 import numpy as np
@@ -289,3 +290,31 @@ def test_graph_captured_train_step_matches_eager():
     t.copy_(torch.from_numpy(b2["text"])); y.copy_(torch.from_numpy(b2["targets"]))
     d1, d2 = replay(), m2.train_step(a, v, t, y)
     assert float(d1["total_loss"]) == float(d2["total_loss"])
+
+
+def test_row_block_chain_path_matches_layered_path():
+    """MMDEER_CHAIN=1 (head layers as one row-block chain launch, csrc/chain.hip) reproduces the default layered
+    path: the switch is read once per process, so each mode runs in its own interpreter."""
+    import subprocess
+    import sys
+
+    code = (
+        "import torch, json, sys; sys.path.insert(0, %r)\n"
+        "from mmdeer import synth\n"
+        "from mmdeer.model import ModelConfig, MultimodalDEER\n"
+        "m = MultimodalDEER(ModelConfig(compute_dtype='bf16', seed=5)).to('cuda:0').train()\n"
+        "b = synth.make_batch(300, seed=3)\n"
+        "a, v, t, y = (torch.from_numpy(b[k]).to('cuda:0') for k in ('audio', 'video', 'text', 'targets'))\n"
+        "d = m.train_step(a, v, t, y)\n"
+        "g = m.flat_grad()\n"
+        "print(json.dumps({'loss': float(d['total_loss']), 'gsum': float(g.double().sum()), 'gabs': float(g.double().abs().sum())}))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, MMDEER_CHAIN=mode)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs["0"]["loss"] == pytest.approx(outs["1"]["loss"], rel=1e-6)
+    assert outs["0"]["gabs"] == pytest.approx(outs["1"]["gabs"], rel=1e-4)
+    assert outs["0"]["gsum"] == pytest.approx(outs["1"]["gsum"], rel=1e-3, abs=1e-6)

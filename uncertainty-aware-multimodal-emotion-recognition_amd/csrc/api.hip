@@ -8,6 +8,7 @@
 
 #include "../../include/mmdeer.h"
 #include "attention.h"
+#include "chain.h"
 #include "common.h"
 #include "gemm.h"
 #include "nig.h"
@@ -62,6 +63,10 @@ constexpr int P_EV2_W = MMDEER_P_HEAD0_EV6_WEIGHT, P_EV2_B = MMDEER_P_HEAD0_EV6_
 constexpr int AUD = MMDEER_AUDIO_DIM, VID = MMDEER_VIDEO_DIM, TXT = MMDEER_TEXT_DIM, INTER = MMDEER_INTER_DIM;
 constexpr int FUS = MMDEER_FUSION_DIM, HID = MMDEER_HIDDEN_DIM, EV1 = 128, EV2 = 64;
 constexpr int SPLITK_MAX = 8;
+// fragment-major images of the DEER-head weights (chain.hip): forward layers use W, backward layers W^T
+constexpr long long CH_FP0 = 0, CH_FP1 = CH_FP0 + 256LL * 512, CH_EV0 = CH_FP1 + 256LL * 256, CH_EV1 = CH_EV0 + 384LL * 256,
+                    CH_EV1T = CH_EV1 + 192LL * 128, CH_EV0T = CH_EV1T + 384LL * 64, CH_FP1T = CH_EV0T + 256LL * 384,
+                    CH_FP0T = CH_FP1T + 256LL * 256, CH_TOTAL = CH_FP0T + 512LL * 256;
 constexpr int AUD_PAD = 128;   // the 84 audio features padded to a K-tile multiple for the LDS-DMA kernels
 
 // ------------------------------------------------------------------ workspace layout
@@ -71,6 +76,7 @@ struct Layout {
   char* wtpack;  // transposed weight matrices (W^T, compute dtype) at the same flat offsets: dX runs as an NT GEMM
   char* wa_pad;  // bf16 mode: audio_projection.weight as [256][AUD_PAD] (zero-padded rows, 16-byte aligned)
   char* audio_pad;  // bf16 mode: the audio feature block as [B][AUD_PAD]
+  char* wchain;  // bf16 mode: fragment-major images of the head weights for the row-block chain kernel (CHAIN_* offsets)
   float* vpack;  // fp32 vectors, MMDEER_FLAT_ELEMS
   // saved activations (activation dtype unless noted)
   char *avin, *avv, *cat, *y_a2, *av, *xtok, *qkv, *obar, *pool, *y_t3, *tri, *y_o1, *fused, *h1, *h2, *e1, *e2;
@@ -97,6 +103,7 @@ Layout make_layout(void* base, int B, int f32) {
   L.vpack = reinterpret_cast<float*>(take((size_t)MMDEER_FLAT_ELEMS * 4));
   L.wa_pad = take((size_t)INTER * AUD_PAD * 2);
   L.audio_pad = take(Bz * AUD_PAD * 2);
+  L.wchain = take((size_t)CH_TOTAL * 2);
   auto act = [&](size_t rows, size_t cols) { return take(rows * cols * es); };
   auto f32buf = [&](size_t n) { return reinterpret_cast<float*>(take(n * 4)); };
   L.avin = act(2 * Bz, INTER); L.avv = act(2 * Bz, INTER); L.cat = act(Bz, 2 * INTER); L.y_a2 = act(Bz, INTER);
@@ -145,6 +152,19 @@ int ksteps_target(int f32) {
     if (v < 0) v = 0;
   }
   return v > 0 ? v : (f32 ? 8 : 16);
+}
+
+unsigned long long* g_chain_stamps = nullptr;   // diagnostic builds: set through mmdeer_debug_chain_stamps()
+
+// MMDEER_CHAIN=1: run the four head layers (forward) / their four dX products (backward) as one row-block chain
+// launch each (csrc/chain.hip) instead of four GEMM launches.  OFF by default: measured at B = 4096 the chain takes
+// 28.7 us against 4 x 6.3 us -- every 32-row workgroup re-streams all 626 KB of weights and each layer still pays a
+// cold first weight fetch, an epilogue store and a barrier, on 128 workgroups instead of 512.  Results are identical
+// (same MFMA order); kept as a measured alternative and covered by tests/test_gpu_model.py.
+int env_chain() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_CHAIN"); v = e ? atoi(e) : 0; }
+  return v;
 }
 
 int forced_tile() {
@@ -310,6 +330,31 @@ int pack_transposed_weights(const void* const* params, const Layout& L, int f32,
   return launch_pack_transposed(tt, L.wtpack, f32, s);
 }
 
+// bf16 mode: fragment-major images of the head weights for the chain kernel (forward: W, backward: W^T)
+int pack_chain_weights(const void* const* params, const Layout& L, int with_backward, hipStream_t s) {
+  TilePackTable t{};
+  auto seg = [&](int pid, long long dst, int rows, int cols, int ld, int transposed, int j0, int t0, int nks_total) {
+    const int k = t.nseg++;
+    t.src[k] = reinterpret_cast<const float*>(params[pid]); t.dst_off[k] = dst; t.rows[k] = rows; t.cols[k] = cols; t.ld[k] = ld;
+    t.transposed[k] = (unsigned char)transposed; t.j0[k] = j0; t.t0[k] = t0; t.nks_total[k] = nks_total;
+  };
+  seg(P_FP0_W, CH_FP0, HID, FUS, FUS, 0, 0, 0, FUS / 32);
+  seg(P_FP1_W, CH_FP1, HID, HID, HID, 0, 0, 0, HID / 32);
+  for (int h = 0; h < 3; ++h) {
+    seg(P_EV0_W + h, CH_EV0, EV1, HID, HID, 0, h * (EV1 / 16), 0, HID / 32);      // stacked along the output dimension
+    seg(P_EV1_W + h, CH_EV1, EV2, EV1, EV1, 0, h * (EV2 / 16), 0, EV1 / 32);      // block-diagonal: group h
+  }
+  if (with_backward) {
+    for (int h = 0; h < 3; ++h) {
+      seg(P_EV1_W + h, CH_EV1T, EV1, EV2, EV1, 1, h * (EV1 / 16), 0, EV2 / 32);   // (n = input col of head h, k = its 64 outputs)
+      seg(P_EV0_W + h, CH_EV0T, HID, EV1, HID, 1, 0, h * (EV1 / 32), 3 * EV1 / 32);   // k runs over the three stacked heads
+    }
+    seg(P_FP1_W, CH_FP1T, HID, HID, HID, 1, 0, 0, HID / 32);
+    seg(P_FP0_W, CH_FP0T, FUS, HID, FUS, 1, 0, 0, HID / 32);
+  }
+  return launch_tile_pack(t, L.wchain, s);
+}
+
 // bf16 mode: the [256][128] zero-padded copy of audio_projection.weight
 int pad_audio_weight(const void* const* params, const Layout& L, hipStream_t s) {
   PadTable pt{};
@@ -367,6 +412,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
     // W^T copies for the backward dX GEMMs (only when this call trains: inference never reads them)
     if (a->training || a->targets) TRY(pack_transposed_weights(a->params, L, f32, s));
+    if (!f32 && env_chain()) TRY(pack_chain_weights(a->params, L, (a->training || a->targets) ? 1 : 0, s));
   }
   const bool wa_pending = a->repack && !f32;   // the padded bf16 copy of audio_projection.weight follows the parameters
   if (B == 0) {
@@ -444,20 +490,40 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   // F12-F13: output_projection (fusion.py:162)
   TRY(X.run1(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ)));
   TRY(launch_ln_fwd(L.y_o1, L.fused, a->fused_features, L.mean_o1, L.rstd_o1, X.V(P_OP_G), X.V(P_OP_BT), B, FUS, f32, s));
-  // F14-F15: feature_processor (deer.py:246)
-  TRY(X.run1(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0)));
-  TRY(X.run1(X.fwd(L.h1, f32, HID, P_FP1_W, P_FP1_B, L.h2, HID, B, 1, SITE_FP1)));
-  // F16: the three DEERLayer first layers stacked into one N = 384 GEMM (deer.py:49)
-  {
-    GemmProblem p = X.fwd(L.h2, f32, HID, P_EV0_W, P_EV0_B, L.e1, 3 * EV1, B, 1, SITE_EV0);
-    p.N = 3 * EV1;
-    TRY(X.run1(p));
-  }
-  // F17: second layers, strided-batched over the heads (deer.py:52)
-  {
-    GemmProblem p = X.fwd(L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, L.e2, 3 * EV2, B, 1, SITE_EV1);
-    p.batch = 3; p.sA = EV1; p.sB = (long long)EV2 * EV1; p.sC = EV2; p.sBias = EV2;
-    TRY(X.run1(p));
+  if (!f32 && env_chain()) {
+    // F14-F17 (bf16): feature_processor (deer.py:246) and the first two layers of the three DEERLayers (deer.py:49-54)
+    // as ONE row-block chain launch (csrc/chain.hip); every layer output is still saved for the backward pass
+    ChainArgs c{};
+    c.nlayers = 4; c.B = B; c.in = reinterpret_cast<const bf16_t*>(L.fused); c.ld_in = FUS; c.K0 = FUS; c.drop = X.dc;
+    auto lin_ = [&](int i, long long pidW, int pidB, int N, int K, void* out, int site) {
+      ChainLayer& l = c.L[i];
+      l.W = reinterpret_cast<const bf16_t*>(L.wchain) + pidW; l.bias = X.V(pidB); l.N = N; l.K = K; l.groups = 1;
+      l.out = reinterpret_cast<bf16_t*>(out); l.ld_out = N; l.relu = 1; l.drop_site = X.drop_on ? site : -1; l.mask_scale = 1.f;
+    };
+    auto lin = [&](int i, long long img, int pidB, int N, int K, void* out, int site) { lin_(i, img, pidB, N, K, out, site); };
+    lin(0, CH_FP0, P_FP0_B, HID, FUS, L.h1, SITE_FP0);
+    lin(1, CH_FP1, P_FP1_B, HID, HID, L.h2, SITE_FP1);
+    lin(2, CH_EV0, P_EV0_B, 3 * EV1, HID, L.e1, SITE_EV0);            // three heads stacked: N = 384
+    lin(3, CH_EV1, P_EV1_B, 3 * EV2, EV1, L.e2, SITE_EV1);            // three heads block-diagonal: 3 x (128 -> 64)
+    c.L[3].groups = 3;
+    c.stamps = g_chain_stamps;
+    TRY(launch_chain(c, s));
+  } else {
+    // F14-F15: feature_processor (deer.py:246)
+    TRY(X.run1(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0)));
+    TRY(X.run1(X.fwd(L.h1, f32, HID, P_FP1_W, P_FP1_B, L.h2, HID, B, 1, SITE_FP1)));
+    // F16: the three DEERLayer first layers stacked into one N = 384 GEMM (deer.py:49)
+    {
+      GemmProblem p = X.fwd(L.h2, f32, HID, P_EV0_W, P_EV0_B, L.e1, 3 * EV1, B, 1, SITE_EV0);
+      p.N = 3 * EV1;
+      TRY(X.run1(p));
+    }
+    // F17: second layers, strided-batched over the heads (deer.py:52)
+    {
+      GemmProblem p = X.fwd(L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, L.e2, 3 * EV2, B, 1, SITE_EV1);
+      p.batch = 3; p.sA = EV1; p.sB = (long long)EV2 * EV1; p.sC = EV2; p.sBias = EV2;
+      TRY(X.run1(p));
+    }
   }
   // F18: last layer (64 -> 4), NIG activations, uncertainties and -- with targets -- the loss statistics
   TRY(launch_nig_fwd(L.e2, X.W(P_EV2_W), X.V(P_EV2_B), 64, L.evid, a->nig_out, a->targets, L.stats, B, f32, s));
@@ -518,21 +584,40 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // B1: last head layer + NIG activations (+ loss gradient)
   TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
                      L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
-  // evidence_net layer 3 (128 -> 64), batched over heads: dX masked by e1
-  {
-    GemmProblem p = X.dx(L.dz2, 3 * EV2, P_EV1_W, L.de1, 3 * EV1, B, L.e1, 3 * EV1);
-    p.batch = 3; p.sA = EV2; p.sB = (long long)EV2 * EV1; p.sC = EV1; p.sY = EV1;
-    TRY(X.run1(p));
+  if (!f32 && env_chain()) {
+    // the four dX GEMMs of the head (evidence_net layers 3 and 0, feature_processor) as one row-block chain launch
+    ChainArgs c{};
+    c.nlayers = 4; c.B = B; c.in = reinterpret_cast<const bf16_t*>(L.dz2); c.ld_in = 3 * EV2; c.K0 = 3 * EV2; c.drop = X.dc;
+    auto dxl = [&](int i, long long img, int N, int K, const void* mask, void* out) {
+      ChainLayer& l = c.L[i];
+      l.W = reinterpret_cast<const bf16_t*>(L.wchain) + img; l.N = N; l.K = K; l.groups = 1;
+      l.mask = reinterpret_cast<const bf16_t*>(mask); l.ld_mask = N; l.mask_scale = X.mask_scale;
+      l.out = reinterpret_cast<bf16_t*>(out); l.ld_out = N; l.drop_site = -1;
+    };
+    dxl(0, CH_EV1T, 3 * EV1, EV2, L.e1, L.de1);                       // per head: W^T [128][64]
+    c.L[0].groups = 3;
+    dxl(1, CH_EV0T, HID, 3 * EV1, L.h2, L.dh2);                       // W^T of the stacked heads: [256][384]
+    dxl(2, CH_FP1T, HID, HID, L.h1, L.dh1);
+    dxl(3, CH_FP0T, FUS, HID, nullptr, L.dfused);
+    c.stamps = g_chain_stamps ? g_chain_stamps + 16 : nullptr;
+    TRY(launch_chain(c, s));
+  } else {
+    // evidence_net layer 3 (128 -> 64), batched over heads: dX masked by e1
+    {
+      GemmProblem p = X.dx(L.dz2, 3 * EV2, P_EV1_W, L.de1, 3 * EV1, B, L.e1, 3 * EV1);
+      p.batch = 3; p.sA = EV2; p.sB = (long long)EV2 * EV1; p.sC = EV1; p.sY = EV1;
+      TRY(X.run1(p));
+    }
+    // evidence_net layer 0 (256 -> 3 x 128 stacked)
+    {
+      GemmProblem p = X.dx(L.de1, 3 * EV1, P_EV0_W, L.dh2, HID, B, L.h2, HID);
+      p.K = 3 * EV1; p.ldb = 3 * EV1;   // W^T of the stacked heads: [256][384]
+      TRY(X.run1(p));
+    }
+    // feature_processor
+    TRY(X.run1(X.dx(L.dh2, HID, P_FP1_W, L.dh1, HID, B, L.h1, HID)));
+    TRY(X.run1(X.dx(L.dh1, HID, P_FP0_W, L.dfused, FUS, B, nullptr, 0)));
   }
-  // evidence_net layer 0 (256 -> 3 x 128 stacked)
-  {
-    GemmProblem p = X.dx(L.de1, 3 * EV1, P_EV0_W, L.dh2, HID, B, L.h2, HID);
-    p.K = 3 * EV1; p.ldb = 3 * EV1;   // W^T of the stacked heads: [256][384]
-    TRY(X.run1(p));
-  }
-  // feature_processor
-  TRY(X.run1(X.dx(L.dh2, HID, P_FP1_W, L.dh1, HID, B, L.h1, HID)));
-  TRY(X.run1(X.dx(L.dh1, HID, P_FP0_W, L.dfused, FUS, B, nullptr, 0)));
   {
     GemmProblem q = X.dw(L.dz2, 3 * EV2, L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, G, B);
     q.batch = 3; q.sA = EV2; q.sB = EV1; q.sC = (long long)EV2 * EV1; q.sBiasGrad = EV2;
@@ -610,6 +695,11 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   return 0;
 }
 
+#ifdef MMDEER_STAMPS
+// diagnostic library only (not part of the ABI): 32 uint64 slots, forward chain stamps at [0,16), backward at [16,32)
+void mmdeer_debug_chain_stamps(void* p) { g_chain_stamps = reinterpret_cast<unsigned long long*>(p); }
+#endif
+
 // ------------------------------------------------------------------ optimiser step
 int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
   MMDEER_CHECK(a != nullptr, "args is NULL");
@@ -642,6 +732,7 @@ int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
   const void* const* cparams = const_cast<const void* const*>(a->params);
   if (a->pack_transposed) TRY(pack_transposed_weights(cparams, L, f32, s));
   if (!f32) TRY(pad_audio_weight(cparams, L, s));
+  if (!f32 && env_chain()) TRY(pack_chain_weights(cparams, L, a->pack_transposed, s));
   return 0;
 }
 
