@@ -292,9 +292,10 @@ def test_graph_captured_train_step_matches_eager():
     assert float(d1["total_loss"]) == float(d2["total_loss"])
 
 
-def test_row_block_chain_path_matches_layered_path():
-    """MMDEER_CHAIN=1 (head layers as one row-block chain launch, csrc/chain.hip) reproduces the default layered
-    path: the switch is read once per process, so each mode runs in its own interpreter."""
+def test_alternative_launch_plans_match_the_default():
+    """MMDEER_CHAIN=1 (head layers as one row-block chain launch, csrc/chain.hip) and MMDEER_SIDE=1 (weight-gradient
+    buckets on a side stream) reproduce the default plan: the switches are read once per process, so each mode runs in
+    its own interpreter."""
     import subprocess
     import sys
 
@@ -310,11 +311,13 @@ def test_row_block_chain_path_matches_layered_path():
         "print(json.dumps({'loss': float(d['total_loss']), 'gsum': float(g.double().sum()), 'gabs': float(g.double().abs().sum())}))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for mode in ("0", "1"):
-        env = dict(os.environ, MMDEER_CHAIN=mode)
+    # default | head layers as row-block chains | weight-gradient buckets on the library's side stream
+    for mode, extra in (("default", {}), ("chain", {"MMDEER_CHAIN": "1"}), ("side", {"MMDEER_SIDE": "1"})):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[mode] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert outs["0"]["loss"] == pytest.approx(outs["1"]["loss"], rel=1e-6)
-    assert outs["0"]["gabs"] == pytest.approx(outs["1"]["gabs"], rel=1e-4)
-    assert outs["0"]["gsum"] == pytest.approx(outs["1"]["gsum"], rel=1e-3, abs=1e-6)
+    for mode in ("chain", "side"):
+        assert outs["default"]["loss"] == pytest.approx(outs[mode]["loss"], rel=1e-6), mode
+        assert outs["default"]["gabs"] == pytest.approx(outs[mode]["gabs"], rel=1e-4), mode
+        assert outs["default"]["gsum"] == pytest.approx(outs[mode]["gsum"], rel=1e-3, abs=1e-6), mode

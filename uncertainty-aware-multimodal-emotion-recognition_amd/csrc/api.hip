@@ -167,6 +167,30 @@ int env_chain() {
   return v;
 }
 
+// MMDEER_SIDE=1: weight-gradient buckets run on a library-owned side stream, concurrently with the rest of the
+// backward chain (fork / join by events, capturable into a HIP graph)
+int env_side() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_SIDE"); v = e ? atoi(e) : 0; }
+  return v;
+}
+struct SideCtx {
+  hipStream_t s2 = nullptr;
+  hipEvent_t fork[3] = {nullptr, nullptr, nullptr}, join = nullptr;
+};
+SideCtx* get_side_ctx() {
+  static SideCtx ctx[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideCtx& c = ctx[dev];
+  if (!c.s2) {
+    if (hipStreamCreateWithFlags(&c.s2, hipStreamNonBlocking) != hipSuccess) { c.s2 = nullptr; return nullptr; }
+    for (int i = 0; i < 3; ++i) (void)hipEventCreateWithFlags(&c.fork[i], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c.join, hipEventDisableTiming);
+  }
+  return &c;
+}
+
 int forced_tile() {
   static int v = -2;
   if (v == -2) {
@@ -579,6 +603,38 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   GemmGroup dwg{};
   ReduceTable rt{};
   auto add_dw = [&](const GemmProblem& q) { dwg.p[dwg.nprob++] = q; };
+  // flush(bucket, last): launch what has been collected.  Default (one stream): nothing until the end, then one
+  // launch of everything.  MMDEER_SIDE=1: every bucket is launched as soon as its inputs exist, on the side stream.
+  SideCtx* sc = (env_side() && !f32) ? get_side_ctx() : nullptr;
+  auto flush = [&](int bucket, bool last) -> int {
+    if (!sc && !last) return 0;
+    hipStream_t ls = s;
+    if (sc) {
+      MMDEER_HIP(hipEventRecord(sc->fork[bucket], s));
+      MMDEER_HIP(hipStreamWaitEvent(sc->s2, sc->fork[bucket], 0));
+      ls = sc->s2;
+    }
+    Exec X2 = X;
+    X2.s = ls;
+    if (dwg.nprob > 0) {
+      if (X2.run(dwg) != 0) return -1;
+      for (int i = 0; i < dwg.nprob; ++i) Exec::add_slab_segments(rt, dwg.p[i], L.slab, G);
+    }
+    if (launch_reduce_partials(rt, ls) != 0) return -1;
+    if (sc && a->bucket_events[bucket]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[bucket], ls));
+    dwg = GemmGroup{};
+    rt = ReduceTable{};
+    if (last) {
+      if (sc) {
+        MMDEER_HIP(hipEventRecord(sc->join, sc->s2));
+        MMDEER_HIP(hipStreamWaitEvent(s, sc->join, 0));
+      } else {
+        for (int b = 0; b < 3; ++b)
+          if (a->bucket_events[b]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[b], s));
+      }
+    }
+    return 0;
+  };
 
   // ================= bucket 0: DEER head =================
   // B1: last head layer + NIG activations (+ loss gradient)
@@ -629,6 +685,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     add_dw(X.dw(L.dh1, HID, L.fused, f32, FUS, P_FP0_W, P_FP0_B, G, B));
     reduce_head(rt);
   }
+  TRY(flush(0, false));
 
   // ================= bucket 1: output_projection + trimodal fusion =================
   TRY(launch_ln_bwd(L.dfused, L.y_o1, L.mean_o1, L.rstd_o1, X.V(P_OP_G), L.dz_o1, L.part_ln_o1, B, FUS, f32, X.mask_scale, s));
@@ -649,6 +706,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     reduce_ln(rt, L.part_ln_o1, P_OP_G, FUS);
     reduce_ln(rt, L.part_ln_t3, P_TFF_G, FUS);
   }
+  TRY(flush(1, false));
 
   // ================= bucket 2: audio-visual fusion =================
   TRY(launch_ln_bwd(L.dav, L.y_a2, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), L.dz_a2, L.part_ln_a2, B, INTER, f32, X.mask_scale, s));
@@ -686,12 +744,8 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     else add_dw(X.dw(L.davin + (size_t)B * INTER * es, INTER, L.audio_pad, 0, AUD_PAD, P_AUD_W, P_AUD_B, G, B));    // padded copy of F0
     reduce_ln(rt, L.part_ln_a2, P_AVF_G, INTER);
   }
-  // ---- all weight gradients: one grouped split-K launch + one deterministic fold of every partial slab
-  TRY(X.run(dwg));
-  for (int i = 0; i < dwg.nprob; ++i) Exec::add_slab_segments(rt, dwg.p[i], L.slab, G);
-  TRY(launch_reduce_partials(rt, s));
-  for (int b = 0; b < 3; ++b)
-    if (a->bucket_events[b]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[b], s));
+  // ---- default: all weight gradients in one grouped split-K launch + one deterministic fold of every partial slab
+  TRY(flush(2, true));
   return 0;
 }
 
