@@ -153,7 +153,7 @@ def test_training_with_dropout_matches_oracle_given_the_same_masks():
     B = 40
     m = make_model(dropout=0.3, seed=123).train()
     b = batch(B, seed=11)
-    ld = m.train_step(b["audio"].to(DEV), b["video"].to(DEV), b["text"].to(DEV), b["targets"].to(DEV))
+    ld = m.train_step(b["audio"].to(DEV), b["video"].to(DEV), b["text"].to(DEV), b["targets"].to(DEV), return_features=True)
     masks = dump_masks(m, B, m._step)
     P = oracle_params(m, torch.float64, requires_grad=True)
     fo, ho, ldo, grads = O.train_step(P, b["audio"].double(), b["video"].double(), b["text"].double(),

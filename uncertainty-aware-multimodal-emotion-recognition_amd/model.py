@@ -250,7 +250,7 @@ class MultimodalDEER(nn.Module):
     def _param_key(self, ws: torch.Tensor):
         return (ws.data_ptr(), self._st.param_gen) + tuple((p.data_ptr(), p._version) for p in self._live)
 
-    def _launch_forward(self, audio, video, text, targets, prof_events=None, offset_dev=None):
+    def _launch_forward(self, audio, video, text, targets, prof_events=None, offset_dev=None, want_features=True):
         lib = _lib.load()
         audio, video, text = (_as_cuda_f32(t, n) for t, n in ((audio, "audio"), (video, "video"), (text, "text")))
         B = audio.shape[0]
@@ -286,13 +286,16 @@ class MultimodalDEER(nn.Module):
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         f32 = dict(dtype=torch.float32, device=dev)
         nig = torch.empty(7, B, 3, **f32)
-        fused = torch.empty(B, self.dims.fusion, **f32)
-        avf = torch.empty(B, self.dims.inter, **f32)
-        trif = torch.empty(B, self.dims.fusion, **f32)
-        avw = torch.empty(B, 2, **f32)
-        triw = torch.empty(B, 2, 2, **f32)
-        a.nig_out, a.fused_features, a.audiovisual_features = nig.data_ptr(), fused.data_ptr(), avf.data_ptr()
-        a.trimodal_features, a.av_attention, a.trimodal_attention = trif.data_ptr(), avw.data_ptr(), triw.data_ptr()
+        a.nig_out = nig.data_ptr()
+        fused = avf = trif = avw = triw = None
+        if want_features:   # fp32 copies of the fusion features / attention weights of the reference's output dict
+            fused = torch.empty(B, self.dims.fusion, **f32)
+            avf = torch.empty(B, self.dims.inter, **f32)
+            trif = torch.empty(B, self.dims.fusion, **f32)
+            avw = torch.empty(B, 2, **f32)
+            triw = torch.empty(B, 2, 2, **f32)
+            a.fused_features, a.audiovisual_features = fused.data_ptr(), avf.data_ptr()
+            a.trimodal_features, a.av_attention, a.trimodal_attention = trif.data_ptr(), avw.data_ptr(), triw.data_ptr()
         if targets is not None:
             targets = targets.contiguous().float()
             a.targets = targets.data_ptr()
@@ -403,11 +406,15 @@ class MultimodalDEER(nn.Module):
         """The trainer hook (training.py:210): MultiTaskDEERLoss defaults, dict with a backprop-able 'total_loss'."""
         return multitask_deer_loss(predictions, targets, self.loss_cfg)
 
-    def train_step(self, audio, video, text, targets, events=None, prof_events=None, _offset_dev=None) -> Dict[str, torch.Tensor]:
+    def train_step(self, audio, video, text, targets, events=None, prof_events=None, _offset_dev=None,
+                   return_features: bool = False) -> Dict[str, torch.Tensor]:
         """Fused forward + MultiTaskDEERLoss + backward: two library calls, gradients land in one flat buffer
         (``.grad`` of every live parameter is a view of it).  Equivalent to
         ``compute_loss(model(a, v, t), y)['total_loss'].backward()``."""
-        o = self._launch_forward(audio, video, text, targets, prof_events, offset_dev=_offset_dev)
+        # the fused step returns losses and gradients; the fp32 feature copies of forward()'s output dict are written
+        # only on request (24 MB of stores per step at B = 4096 that nothing in training reads)
+        o = self._launch_forward(audio, video, text, targets, prof_events, offset_dev=_offset_dev,
+                                 want_features=return_features)
         meta = o["_meta"]
         dev = meta["ws"].device
         self._st.last_train = (meta["ws"], meta["B"])
