@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 2
+#define MMDEER_ABI_VERSION 3
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -76,6 +76,8 @@ typedef struct mmdeer_forward_args {
   uint64_t seed, offset;
   const uint64_t* offset_dev; /* optional device counter added to `offset` when the kernels run: lets a captured HIP
                                * graph draw fresh dropout masks on every replay (NULL: offset alone) */
+  int32_t bump_offset_dev;  /* 1 (bf16 compute only): the first kernel of this call increments *offset_dev before
+                             * anything reads it, so a replayed graph needs no separate counter kernel */
   const void* audio;        /* [B, 84]  */
   const void* video;        /* [B, 256] */
   const void* text;         /* [B, 768] */

@@ -36,7 +36,7 @@ class LossCfg(C.Structure):
 class ForwardArgs(C.Structure):
     _fields_ = [
         ("batch", c_int), ("compute_f32", c_int), ("training", c_int), ("inputs_bf16", c_int), ("repack", c_int),
-        ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("offset_dev", c_void_p),
+        ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("offset_dev", c_void_p), ("bump_offset_dev", c_int),
         ("audio", c_void_p), ("video", c_void_p), ("text", c_void_p),
         ("params", C.POINTER(c_void_p)),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
@@ -143,7 +143,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 2:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 3:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         _LIB = lib
     return _LIB

@@ -419,6 +419,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   TRY(check_common(B, a->workspace, a->workspace_bytes, f32));
   MMDEER_CHECK(!(f32 && a->inputs_bf16), "bf16 inputs need compute_f32 = 0");
   MMDEER_CHECK(a->dropout_p >= 0.f && a->dropout_p < 1.f, "dropout_p must be in [0,1) (got %f)", a->dropout_p);
+  MMDEER_CHECK(!(a->bump_offset_dev && (f32 || B == 0)), "bump_offset_dev needs bf16 compute and a non-empty batch");
   hipStream_t s = (hipStream_t)a->stream;
   const Layout L = make_layout(a->workspace, B, f32);
   if (a->repack) {
@@ -460,6 +461,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     PadTable pt{};
     pt.src[0] = a->audio; pt.dst[0] = L.audio_pad; pt.src_f32[0] = in_f32; pt.rows[0] = B; pt.cols[0] = AUD; pt.ld_dst[0] = AUD_PAD;
     pt.nseg = 1;
+    if (a->bump_offset_dev && a->offset_dev) pt.bump = reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(a->offset_dev));
     if (wa_pending) {
       pt.src[1] = a->params[P_AUD_W]; pt.dst[1] = L.wa_pad; pt.src_f32[1] = 1; pt.rows[1] = INTER; pt.cols[1] = AUD; pt.ld_dst[1] = AUD_PAD;
       pt.nseg = 2;

@@ -250,7 +250,7 @@ class MultimodalDEER(nn.Module):
     def _param_key(self, ws: torch.Tensor):
         return (ws.data_ptr(), self._st.param_gen) + tuple((p.data_ptr(), p._version) for p in self._live)
 
-    def _launch_forward(self, audio, video, text, targets, prof_events=None, offset_dev=None, want_features=True):
+    def _launch_forward(self, audio, video, text, targets, prof_events=None, offset_dev=None, want_features=True, bump=False):
         lib = _lib.load()
         audio, video, text = (_as_cuda_f32(t, n) for t, n in ((audio, "audio"), (video, "video"), (text, "text")))
         B = audio.shape[0]
@@ -281,6 +281,7 @@ class MultimodalDEER(nn.Module):
         step = 0 if offset_dev is not None else int(self._step)
         a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), step
         a.offset_dev = _lib.ptr(offset_dev)
+        a.bump_offset_dev = int(bump)
         a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
         a.params = self._ptr_cache[1]
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -407,14 +408,14 @@ class MultimodalDEER(nn.Module):
         return multitask_deer_loss(predictions, targets, self.loss_cfg)
 
     def train_step(self, audio, video, text, targets, events=None, prof_events=None, _offset_dev=None,
-                   return_features: bool = False) -> Dict[str, torch.Tensor]:
+                   return_features: bool = False, _bump: bool = False) -> Dict[str, torch.Tensor]:
         """Fused forward + MultiTaskDEERLoss + backward: two library calls, gradients land in one flat buffer
         (``.grad`` of every live parameter is a view of it).  Equivalent to
         ``compute_loss(model(a, v, t), y)['total_loss'].backward()``."""
         # the fused step returns losses and gradients; the fp32 feature copies of forward()'s output dict are written
         # only on request (24 MB of stores per step at B = 4096 that nothing in training reads)
         o = self._launch_forward(audio, video, text, targets, prof_events, offset_dev=_offset_dev,
-                                 want_features=return_features)
+                                 want_features=return_features, bump=_bump)
         meta = o["_meta"]
         dev = meta["ws"].device
         self._st.last_train = (meta["ws"], meta["B"])
@@ -464,9 +465,11 @@ class MultimodalDEER(nn.Module):
         self._graph_counter = torch.full((), int(self._step), dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
+        in_kernel = not self.compute_f32     # bf16: the first kernel of the forward bumps the counter itself
         with torch.cuda.graph(graph):
-            self._graph_counter.add_(1)
-            out = self.train_step(audio, video, text, targets, events=events, _offset_dev=self._graph_counter)
+            if not in_kernel:
+                self._graph_counter.add_(1)
+            out = self.train_step(audio, video, text, targets, events=events, _offset_dev=self._graph_counter, _bump=in_kernel)
         self._graph = graph
 
         def replay():
