@@ -104,31 +104,35 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const PackTTable t
 // ------------------------------------------------------------------ LayerNorm forward
 constexpr int LN_MAX_VEC = 4;  // N <= 4 * 256 = 1024
 
-template <bool F32>
+// NV = column groups of 256 per lane pass; EXACT: N == NV * 256, so no per-lane bounds test guards a load (loads
+// under per-lane branches are closed by vmcnt(0) one at a time)
+template <bool F32, int NV, bool EXACT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* y, void* out, float* out32, float* mean, float* rstd,
                                                      const float* gamma, const float* beta, int M, int N) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;  // whole wave exits together
   const long long base = (long long)row * N;
-  f32x4 x[LN_MAX_VEC];
+  f32x4 x[NV], g[NV], b[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
-    if (c < N) {
+    if (EXACT || c < N) {
       x[i] = load4<F32>(y, base + c);
-      s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+      g[i] = *reinterpret_cast<const f32x4*>(gamma + c);
+      b[i] = *reinterpret_cast<const f32x4*>(beta + c);
     } else {
-      x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      x[i] = g[i] = b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
   }
   const float mu = wave_sum(s) / (float)N;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
-    if (c < N) {
+    if (EXACT || c < N) {
       f32x4 d = x[i] - mu;
       q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
     }
@@ -137,11 +141,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* y, void* out, f
   const float rs = 1.0f / sqrtf(var + 1e-5f);
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
-    if (c < N) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
-      f32x4 o = (x[i] - mu) * rs * g + b;
+    if (EXACT || c < N) {
+      f32x4 o = (x[i] - mu) * rs * g[i] + b[i];
       store4<F32>(out, base + c, o);
       if (out32) *reinterpret_cast<f32x4*>(out32 + base + c) = o;
     }
@@ -149,67 +152,89 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* y, void* out, f
 }
 
 // ------------------------------------------------------------------ LayerNorm backward (+ ReLU/dropout mask)
-template <bool F32>
+template <bool F32, int NV, bool EXACT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dout, const void* y, const float* mean, const float* rstd,
                                                      const float* gamma, void* dz, float* partial, int M, int N,
                                                      float mask_scale) {
-  __shared__ float red[4][2 * LN_MAX_VEC * 256];
+  __shared__ float red[4][2 * NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 g[LN_MAX_VEC], dg[LN_MAX_VEC], db[LN_MAX_VEC];
+  f32x4 g[NV], dg[NV], db[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
-    g[i] = (c < N) ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    g[i] = (EXACT || c < N) ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const long long base = (long long)row * N;
-    const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[LN_MAX_VEC], gd[LN_MAX_VEC], yv[LN_MAX_VEC];
-    float s1 = 0.f, s2 = 0.f;
+  // two rows per trip: both rows' loads are in flight before the first reduction (a wave owns 4+ rows; one row at a
+  // time the loop was a chain of load -> reduce -> store round trips)
+  const int stride = gridDim.x * 4;
+  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += 2 * stride) {
+    f32x4 yv[2][NV], d[2][NV];
+    float mu[2], rs[2];
+    bool live[2];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_VEC; ++i) {
-      const int c = lane * 4 + i * 256;
-      if (c < N) {
-        yv[i] = load4<F32>(y, base + c);
-        f32x4 d = load4<F32>(dout, base + c);
-        xh[i] = (yv[i] - mu) * rs;
-        gd[i] = d * g[i];
-        dg[i] += d * xh[i];
-        db[i] += d;
-        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
-        f32x4 t = gd[i] * xh[i];
-        s2 += (t.x + t.y) + (t.z + t.w);
+    for (int r = 0; r < 2; ++r) {
+      const int row = row0 + r * stride;
+      live[r] = row < M;
+      const int rr = live[r] ? row : row0;            // a dead second row re-reads the first (results discarded)
+      const long long base = (long long)rr * N;
+      mu[r] = mean[rr]; rs[r] = rstd[rr];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (EXACT || c < N) {
+          yv[r][i] = load4<F32>(y, base + c);
+          d[r][i] = load4<F32>(dout, base + c);
+        } else {
+          yv[r][i] = d[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
-    const float m1 = wave_sum(s1) / (float)N, m2 = wave_sum(s2) / (float)N;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_VEC; ++i) {
-      const int c = lane * 4 + i * 256;
-      if (c < N) {
-        f32x4 dy = (gd[i] - m1 - xh[i] * m2) * rs;
-        f32x4 o;
-        o.x = yv[i].x > 0.f ? dy.x * mask_scale : 0.f;
-        o.y = yv[i].y > 0.f ? dy.y * mask_scale : 0.f;
-        o.z = yv[i].z > 0.f ? dy.z * mask_scale : 0.f;
-        o.w = yv[i].w > 0.f ? dy.w * mask_scale : 0.f;
-        store4<F32>(dz, base + c, o);
+    for (int r = 0; r < 2; ++r) {
+      if (!live[r]) continue;                         // wave-uniform
+      const long long base = (long long)(row0 + r * stride) * N;
+      f32x4 xh[NV], gd[NV];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        xh[i] = (yv[r][i] - mu[r]) * rs[r];
+        gd[i] = d[r][i] * g[i];
+        dg[i] += d[r][i] * xh[i];
+        db[i] += d[r][i];
+        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+        const f32x4 t = gd[i] * xh[i];
+        s2 += (t.x + t.y) + (t.z + t.w);
+      }
+      const float m1 = wave_sum(s1) / (float)N, m2 = wave_sum(s2) / (float)N;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (EXACT || c < N) {
+          const f32x4 dy = (gd[i] - m1 - xh[i] * m2) * rs[r];
+          f32x4 o;
+          o.x = yv[r][i].x > 0.f ? dy.x * mask_scale : 0.f;
+          o.y = yv[r][i].y > 0.f ? dy.y * mask_scale : 0.f;
+          o.z = yv[r][i].z > 0.f ? dy.z * mask_scale : 0.f;
+          o.w = yv[r][i].w > 0.f ? dy.w * mask_scale : 0.f;
+          store4<F32>(dz, base + c, o);
+        }
       }
     }
   }
   // combine the 4 waves' column partials, one [2][N] slab per workgroup (deterministic; summed by reduce_partials)
 #pragma unroll
-  for (int i = 0; i < LN_MAX_VEC; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + i * 256;
     *reinterpret_cast<f32x4*>(&red[wave][c]) = dg[i];
-    *reinterpret_cast<f32x4*>(&red[wave][LN_MAX_VEC * 256 + c]) = db[i];
+    *reinterpret_cast<f32x4*>(&red[wave][NV * 256 + c]) = db[i];
   }
   __syncthreads();
   float* slab = partial + (long long)blockIdx.x * 2 * N;
   for (int c = threadIdx.x; c < N; c += 256) {
     slab[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    const int o = LN_MAX_VEC * 256 + c;
+    const int o = NV * 256 + c;
     slab[N + c] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
   }
 }
@@ -356,8 +381,10 @@ int launch_ln_fwd(const void* y, void* out, float* out32, float* mean, float* rs
   MMDEER_CHECK(N % 4 == 0 && N <= LN_MAX_VEC * 256, "layernorm: N=%d unsupported (multiple of 4, <= 1024)", N);
   if (M == 0) return 0;
   const int grid = (M + 3) / 4;
-  if (act_f32) hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, y, out, out32, mean, rstd, gamma, beta, M, N);
-  else hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, y, out, out32, mean, rstd, gamma, beta, M, N);
+#define LN_FWD(F, NV, EX) hipLaunchKernelGGL((ln_fwd_kernel<F, NV, EX>), dim3(grid), dim3(256), 0, s, y, out, out32, mean, rstd, gamma, beta, M, N)
+  if (act_f32) { if (N == 256) LN_FWD(true, 1, true); else if (N == 512) LN_FWD(true, 2, true); else LN_FWD(true, LN_MAX_VEC, false); }
+  else { if (N == 256) LN_FWD(false, 1, true); else if (N == 512) LN_FWD(false, 2, true); else LN_FWD(false, LN_MAX_VEC, false); }
+#undef LN_FWD
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
@@ -372,8 +399,10 @@ int launch_ln_bwd(const void* dout, const void* y, const float* mean, const floa
                   void* dz, float* partial, int M, int N, int act_f32, float mask_scale, hipStream_t s) {
   MMDEER_CHECK(N % 4 == 0 && N <= LN_MAX_VEC * 256, "layernorm: N=%d unsupported (multiple of 4, <= 1024)", N);
   const int grid = ln_bwd_nparts(M);
-  if (act_f32) hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, dout, y, mean, rstd, gamma, dz, partial, M, N, mask_scale);
-  else hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, dout, y, mean, rstd, gamma, dz, partial, M, N, mask_scale);
+#define LN_BWD(F, NV, EX) hipLaunchKernelGGL((ln_bwd_kernel<F, NV, EX>), dim3(grid), dim3(256), 0, s, dout, y, mean, rstd, gamma, dz, partial, M, N, mask_scale)
+  if (act_f32) { if (N == 256) LN_BWD(true, 1, true); else if (N == 512) LN_BWD(true, 2, true); else LN_BWD(true, LN_MAX_VEC, false); }
+  else { if (N == 256) LN_BWD(false, 1, true); else if (N == 512) LN_BWD(false, 2, true); else LN_BWD(false, LN_MAX_VEC, false); }
+#undef LN_BWD
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
