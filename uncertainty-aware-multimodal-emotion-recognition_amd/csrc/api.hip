@@ -230,7 +230,9 @@ GemmTile pick_tile(const GemmGroup& g) {
     }
     if (plain && t256 >= 160 && t256 <= 256) return TILE_256x256;
   }
-  if (tiles[1] >= 512) return TILE_128x64;
+  static int t128 = -1;   // MMDEER_T128: smallest 128x64 tile count that selects the 128x64 kernel
+  if (t128 < 0) { const char* e = getenv("MMDEER_T128"); t128 = e ? atoi(e) : 512; }
+  if (tiles[1] >= t128) return TILE_128x64;
   return TILE_64x64;
 }
 
