@@ -128,8 +128,10 @@ typedef struct mmdeer_backward_args {
   float* grads;
   float* loss_out;          /* [MMDEER_LOSS_OUT] or NULL */
   int32_t* bin_counts;      /* [3][10] ECE bin populations or NULL */
-  /* optional: hipEvent_t handles recorded after gradient buckets complete (for overlapping the DP all-reduce):
-   * bucket 0 = head (params 28..49), 1 = output_projection + trimodal (12..27), 2 = audio-visual (0..11) */
+  /* optional: hipEvent_t handles recorded when a gradient bucket of the flat buffer is final:
+   * bucket 0 = head (params 28..49), 1 = output_projection + trimodal (12..27), 2 = audio-visual (0..11).
+   * In the default launch plan all weight gradients are produced by one grouped launch at the end of the pass, so
+   * the three events are recorded together; with MMDEER_SIDE=1 each one follows its own bucket. */
   void* bucket_events[3];
   void* stream;
 } mmdeer_backward_args;

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two gloo ranks exchange bucketed gradients (the same BucketedAllReduce object the
+"""N > 1 path on CPU: two gloo ranks exchange the flat gradient buffer (the same BucketedAllReduce object the
 GPU bench uses over RCCL), and rank-sharded synthetic batches reassemble the global batch."""
 import os
 import socket

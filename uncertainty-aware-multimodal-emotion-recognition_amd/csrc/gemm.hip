@@ -10,7 +10,6 @@ int gemm_dispatch_nt(const GemmGroup& g, int total, int compute_f32, GemmTile ti
 int gemm_dispatch_nx(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
 int gemm_dispatch_tt(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
 int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStream_t s);
-int gemm_dispatch_tt_glds(const GemmGroup& g, int total, int ring, hipStream_t s);
 int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s);
 int gemm_dispatch_nt256(const GemmGroup& g, int total, hipStream_t s);
 
@@ -18,11 +17,6 @@ namespace {
 int env_xcd() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MMDEER_XCD"); v = e ? atoi(e) : 1; }
-  return v;
-}
-int env_ttring() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_TTRING"); v = e ? atoi(e) : 2; }
   return v;
 }
 // MMDEER_GLDS=0 forces the register-staged kernel for NT problems (A/B comparison, debugging)
@@ -48,6 +42,13 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
   MMDEER_CHECK((int)tile_req >= 0 && (int)tile_req <= 3, "gemm: bad tile id %d", (int)tile_req);
   g.xcd_remap = env_xcd();
   const int ta = g.p[0].trans_a ? 1 : 0, tb = g.p[0].trans_b ? 1 : 0;
+  // the whole group can run on the 256x256 weight-gradient kernel (it alone tolerates padded, half-valid row ends)
+  bool pad256 = tile_req == TILE_256x256 && ta && tb && !compute_f32 && env_glds();
+  for (int i = 0; i < g.nprob && pad256; ++i) {
+    const GemmProblem& q = g.p[i];
+    pad256 = !q.a_f32 && !q.b_f32 && q.K % 32 == 0 && q.c_f32 && !q.bias && !q.relu && !q.Y && q.drop_site < 0 && q.regen_site < 0 &&
+             q.lda % 8 == 0 && q.ldb % 8 == 0 && q.sA % 8 == 0 && q.sB % 8 == 0;
+  }
   for (int i = 0; i < g.nprob; ++i) {
     GemmProblem& p = g.p[i];
     MMDEER_CHECK((p.trans_a ? 1 : 0) == ta && (p.trans_b ? 1 : 0) == tb, "gemm[%d]: all problems of a launch must share trans flags", i);
@@ -76,13 +77,14 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
       MMDEER_CHECK(p.a_f32 && p.b_f32, "gemm[%d]: fp32 compute needs fp32 operands", i);
       p.a_mode = p.b_mode = SRC_F32;
     } else {
-      // 16-byte loads of a bf16 source need 16-byte aligned rows AND no half-valid chunk (extent multiple of 8)
-      // (a transposed operand may end in a half-valid chunk when its rows are padded: the extra columns are read
-      //  from inside the row and only feed outputs that are never stored)
+      // 16-byte loads of a bf16 source need 16-byte aligned rows AND no half-valid chunk (extent multiple of 8).
+      // Exception, 256x256 weight-gradient kernel only (pad256): a transposed operand may end in a half-valid chunk
+      // when its rows are padded -- the extra columns are read from inside the row and only feed outputs that are
+      // never stored (the padded audio block: 84 valid columns in 128-element rows).
       const bool av16 = p.lda % 8 == 0 && p.sA % 8 == 0 &&
-                        (p.trans_a ? (p.M % 8 == 0 || (p.batch == 1 && p.lda >= (p.M + 7) / 8 * 8)) : p.K % 8 == 0);
+                        (p.trans_a ? (p.M % 8 == 0 || (pad256 && p.batch == 1 && p.lda >= (p.M + 7) / 8 * 8)) : p.K % 8 == 0);
       const bool bv16 = p.ldb % 8 == 0 && p.sB % 8 == 0 &&
-                        (p.trans_b ? (p.N % 8 == 0 || (p.batch == 1 && p.ldb >= (p.N + 7) / 8 * 8)) : p.K % 8 == 0);
+                        (p.trans_b ? (p.N % 8 == 0 || (pad256 && p.batch == 1 && p.ldb >= (p.N + 7) / 8 * 8)) : p.K % 8 == 0);
       p.a_mode = p.a_f32 ? SRC_F32 : (av16 ? SRC_BF16_V16 : SRC_BF16_V8);
       p.b_mode = p.b_f32 ? SRC_F32 : (bv16 ? SRC_BF16_V16 : SRC_BF16_V8);
     }
@@ -138,13 +140,8 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
                 tile != TILE_128x128;
     for (int j = 0; j < sub.nprob && glds; ++j)
       glds = sub.p[j].K % 64 == 0 && sub.p[j].splitk == 1 && !sub.p[j].bias_grad;
-    // LDS-DMA + transposed-read path for weight gradients (both operands stored [K][cols])
-    bool ttg = ta && tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 && env_glds() && !sub.stamps &&
-               tile == TILE_128x128;
-    for (int j = 0; j < sub.nprob && ttg; ++j) ttg = sub.p[j].K % 64 == 0;
     if (tt256) rc = gemm_dispatch_tt256(sub, total, stream);
     else if (nt256) rc = gemm_dispatch_nt256(sub, total, stream);
-    else if (ttg) rc = gemm_dispatch_tt_glds(sub, total, env_ttring(), stream);
     else if (glds) rc = gemm_dispatch_nt_glds(sub, total, tile, stream);
     else if (!ta && !tb) rc = gemm_dispatch_nt(sub, total, compute_f32, tile, am, bm, stream);
     else if (!ta && tb) rc = gemm_dispatch_nx(sub, total, compute_f32, tile, am, bm, stream);

@@ -215,171 +215,6 @@ int launch_glds(const GemmGroup& g, int total, hipStream_t stream) {
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Weight-gradient GEMM  C[M,N] = sum_k A[k][m] * B[k][n]  (A = dY stored [K][M], B = X stored [K][N], K = batch
-// rows) with LDS-DMA staging and hardware-transposed fragment reads.
-//
-// Both operands are DMA-copied AS STORED: a K-tile is 64 k-rows x 128 columns = 64 rows of 256 B per operand
-// (1 KiB piece = 4 rows).  The MFMA fragments need 8 consecutive k for one column, i.e. a column walk of this
-// image: ds_read_b64_tr_b16 does exactly that (per 16-lane group a 4-row x 16-column block delivered
-// column-major), two reads per fragment.  No VALU transposition, no ds_write, no strided global loads.
-// Image swizzle ("plain 256-byte rows", cdna_hip_programming.md T10 (b)): the 16-byte chunk at slot p of row r
-// holds logical chunk p ^ f(r), f(r) = ((r & 3) << 2) | ((r >> 2) & 3), applied to the DMA source address and to
-// the read address alike.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ u32x4 tr_frag(const unsigned char* a0, const unsigned char* a1) {
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
-  const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
-  return u32x4{l.x, l.y, h.x, h.y};
-}
-
-template <int NST>
-__global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void gemm_tt_glds_kernel(const GemmGroup g) {
-  constexpr int BM = 128, BN = 128, TM = 4, TN = 4, WT = 64;
-  constexpr int OPER = 64 * 256, STAGE = 2 * OPER;   // bytes: one operand tile, one K-tile of both
-  constexpr int SPAD = BN + 4;
-  constexpr int LDS_BYTES = cmax(NST * STAGE, BM * SPAD * 4);
-  constexpr int LPT = 8;                              // DMA pieces per wave per K-tile (4 per operand)
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 15, lg = lane >> 4;
-
-  int bid = blockIdx.x;
-  if (g.xcd_remap) {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
-  }
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
-    if (i < g.nprob && bid >= g.tile_start[i]) pi = i;
-  typedef const __attribute__((address_space(4))) unsigned char* karg_ptr;
-  karg_ptr kbase = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-  const __attribute__((address_space(4))) GemmProblem& p =
-      *(const __attribute__((address_space(4))) GemmProblem*)(
-          kbase + __builtin_offsetof(GemmGroup, p) + (size_t)pi * sizeof(GemmProblem));
-  const int local = bid - g.tile_start[pi];
-  const int per_slice = p.tiles_m * p.tiles_n;
-  const int per_batch = per_slice * p.splitk;
-  const int z = local / per_batch;
-  const int rem_b = local - z * per_batch;
-  const int slice = rem_b / per_slice;
-  const int rem = rem_b - slice * per_slice;
-  const int tmb = rem / p.tiles_n, tnb = rem - tmb * p.tiles_n;
-  const int row0 = tmb * BM, col0 = tnb * BN;
-  const int M = p.M, N = p.N;
-  const int nk_all = p.K >> 6;   // K % 64 == 0 (checked by the launcher)
-  const int nk_per = (nk_all + p.splitk - 1) / p.splitk;
-  const int kt0 = slice * nk_per;
-  const int kt1 = (kt0 + nk_per < nk_all) ? kt0 + nk_per : nk_all;
-  const int nk = kt1 > kt0 ? kt1 - kt0 : 0;
-
-  // ---- DMA source pointers.  Piece (4j + wave) of an operand tile = k-rows 4(4j + wave) .. +3; lane l writes slot
-  //      (l & 15) of row (l >> 4) of the piece, so it fetches logical chunk (l & 15) ^ f(row), f = ((l>>4)<<2) | wave.
-  //      A chunk beyond the operand's width reads column 0 instead (it only feeds outputs that are never stored).
-  const int fsw = ((lane >> 4) << 2) | wave;
-  const int chunk = (lane & 15) ^ fsw;
-  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (long long)z * p.sA;
-  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B) + (long long)z * p.sB;
-  const long long lda = p.lda, ldb = p.ldb;
-  const long long krow = (long long)kt0 * 64 + 4 * wave + (lane >> 4);
-  const int ca = row0 + chunk * 8, cb = col0 + chunk * 8;
-  const bf16_t* pa = Ab + krow * lda + (ca < M ? ca : 0);
-  const bf16_t* pb = Bb + krow * ldb + (cb < N ? cb : 0);
-  auto issue = [&](int stage) __attribute__((always_inline)) {
-    unsigned char* sa = lds + stage * STAGE + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + 16 * j * lda),
-                                       (__attribute__((address_space(3))) void*)(sa + j * 4096), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + 16 * j * ldb),
-                                       (__attribute__((address_space(3))) void*)(sa + OPER + j * 4096), 16, 0, 0);
-    pa += 64 * lda;
-    pb += 64 * ldb;
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) bsum[i] = 0.f;
-  const bool do_bsum = (p.bias_grad != nullptr) && (tnb == 0) && (wn == 0);
-
-  // ---- transposed-read addressing.  Within a 16-lane group lane 4q + pp supplies the address of block row q,
-  //      columns 4pp .. 4pp+3; the block of MFMA k-step s is rows 32s + 8 lg + {0..3} (first read) / + {4..7}.
-  const int q = (lane & 15) >> 2, pp = lane & 3;
-  const int f1 = (q << 2) | ((2 * lg) & 3), f2 = (q << 2) | ((2 * lg + 1) & 3);
-  const int rowb = (8 * lg + q) * 256;                       // + 32*256*s, second read + 4*256
-  const int cbyte = (pp & 1) * 8;
-  // per fragment column block c16 (16 columns = 2 chunks): logical chunk = 2*c16 + (pp >> 1)
-  auto frag_addr = [&](int c16, int fx) __attribute__((always_inline)) { return (((2 * c16 + (pp >> 1)) ^ fx) * 16) + cbyte; };
-
-  // ---- prologue / ring
-#pragma unroll
-  for (int t = 0; t < NST - 1; ++t)
-    if (t < nk) issue(t);
-  int stage = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int younger = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
-    if (NST > 2 && younger >= 1) wait_vmcnt<LPT>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + NST - 1 < nk) issue(stage == 0 ? NST - 1 : stage - 1);
-    const unsigned char* sa = lds + stage * STAGE;
-    const unsigned char* sb = sa + OPER;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 fa[TM], fb[TN];
-      const int r1 = rowb + s * 32 * 256, r2 = r1 + 4 * 256;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int c16 = wm * (WT / 16) + i;
-        fa[i] = tr_frag(sa + r1 + frag_addr(c16, f1), sa + r2 + frag_addr(c16, f2));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int c16 = wn * (WT / 16) + j;
-        fb[j] = tr_frag(sb + r1 + frag_addr(c16, f1), sb + r2 + frag_addr(c16, f2));
-      }
-      if (do_bsum) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) bsum[i] += chunk_sum<bf16_t>(fa[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<bf16_t>(fa[i], fb[j], acc[i][j]);
-    }
-    stage = stage + 1 == NST ? 0 : stage + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  const bool sliced = p.splitk > 1;
-  if (do_bsum) {
-    float* bg = sliced ? p.slab_b + (long long)slice * p.slab_stride : p.bias_grad;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float v = bsum[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      const int r = row0 + wm * WT + i * 16 + li;
-      if (lg == 0 && r < M) bg[(long long)z * p.sBiasGrad + r] = v;
-    }
-  }
-  gemm_epilogue<BM, BN>(g, p, lds, acc, z, slice, row0, col0);
-}
-
 }  // namespace
 
 // caller guarantees: bf16 compute, both operands bf16 with ld % 8 == 0 and 16-byte aligned bases, K % 64 == 0,
@@ -392,14 +227,5 @@ int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStrea
   }
 }
 
-
-// caller guarantees: bf16 compute, trans_a = trans_b = 1, both operands bf16 with ld % 8 == 0, 16-byte aligned,
-// K (the reduction = batch rows) % 64 == 0, tile 128x128
-int gemm_dispatch_tt_glds(const GemmGroup& g, int total, int ring, hipStream_t s) {
-  if (ring <= 2) hipLaunchKernelGGL((gemm_tt_glds_kernel<2>), dim3(total), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_tt_glds_kernel<3>), dim3(total), dim3(256), 0, s, g);
-  MMDEER_HIP(hipGetLastError());
-  return 0;
-}
 
 }  // namespace mmdeer
