@@ -129,3 +129,26 @@ def test_fused_adamw_matches_torch_adamw_with_clipping():
     m1.eval(); m2.eval()
     out1, out2 = m1(a, v, t), m2(a, v, t)
     assert torch.allclose(out1["mu_all"], out2["mu_all"], rtol=1e-4, atol=1e-5)
+
+
+def test_trainer_graph_mode_matches_eager_mode(tmp_path):
+    """DEERTrainer with use_graph=True (captured train_step + FusedAdamW) follows the same trajectory as the eager
+    trainer: same data, same seeds, same dropout counters."""
+    import copy
+
+    from torch.utils.data import DataLoader, TensorDataset
+
+    b = synth.make_batch(96, seed=21)
+    ds = TensorDataset(*(torch.from_numpy(b[k]) for k in ("audio", "video", "text", "targets")))
+    m1 = MultimodalDEER(ModelConfig(compute_dtype="fp32", seed=4)).to("cuda:0")
+    m2 = copy.deepcopy(m1)
+    hist = []
+    for m, graph in ((m1, False), (m2, True)):
+        cfg = TrainingConfig(batch_size=32, num_epochs=1, output_dir=str(tmp_path / f"o{graph}"), log_dir=str(tmp_path / f"l{graph}"),
+                             checkpoint_dir=str(tmp_path / f"c{graph}"), use_graph=graph)
+        tr = DEERTrainer(m, cfg, device="cuda:0")
+        loaders = {"iemocap": DataLoader(ds, batch_size=32, shuffle=False)}
+        hist.append([tr.train_epoch(loaders)["total_loss"] for _ in range(2)])
+    assert hist[0] == pytest.approx(hist[1], rel=1e-5)
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.allclose(p1, p2, rtol=1e-4, atol=1e-6), n

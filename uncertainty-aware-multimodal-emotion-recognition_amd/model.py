@@ -460,8 +460,9 @@ class MultimodalDEER(nn.Module):
             if not t.is_cuda:
                 raise RuntimeError("capture_train_step needs GPU tensors")
         dev = audio.device
-        # eager warm-up: allocates the workspace and the persistent gradient buffer, packs the weights
-        self.train_step(audio, video, text, targets)
+        # eager warm-up: allocates the workspace and the persistent gradient buffer, packs the weights.  It is a real
+        # step on the given batch: its loss dict is returned as ``replay.first`` and its gradients are in place
+        first = self.train_step(audio, video, text, targets)
         self._graph_counter = torch.full((), int(self._step), dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
@@ -474,7 +475,9 @@ class MultimodalDEER(nn.Module):
 
         def replay():
             graph.replay()
+            self._step += 1          # keep the host-side step counter in line with the device-side one
             return out
+        replay.first = first
         return replay
 
 

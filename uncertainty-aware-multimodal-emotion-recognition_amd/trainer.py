@@ -32,6 +32,7 @@ class TrainingConfig:
     num_epochs: int = 100
     scheduler_type: str = "cosine"
     fused_optimizer: bool = True   # clip + AdamW + weight pack on the device (optim.FusedAdamW); False: torch.optim.AdamW
+    use_graph: bool = False        # replay train_step as a captured HIP graph for full batches of one shape (needs fused_optimizer)
     warmup_epochs: int = 5
     patience: int = 10
     evidence_weight: float = 1.0
@@ -99,6 +100,28 @@ class DEERTrainer:
         flat.mul_(torch.clamp(self.config.gradient_clip / (total + 1e-6), max=1.0))
         return total
 
+    # ---- optional HIP-graph replay of the step (config.use_graph): one graph per (batch size, dtype), fed through
+    #      static input tensors; batches of another shape (the last, ragged one) take the eager path
+    def _graph_ok(self, a: torch.Tensor) -> bool:
+        return bool(self.config.use_graph) and isinstance(self.optimizer, FusedAdamW) and a.is_cuda
+
+    def _graph_step(self, a, v, t, y):
+        key = (a.shape[0], a.dtype)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        entry = self._graphs.get(key)
+        if entry is None:
+            if self._graphs and key[0] < max(k[0] for k in self._graphs):
+                return None                      # a smaller tail batch: not worth a capture
+            static = tuple(x.clone() for x in (a, v, t, y.float()))
+            replay = self.model.capture_train_step(*static)
+            entry = self._graphs[key] = (static, replay)
+            return replay.first              # the capture's eager warm-up WAS this batch's step: gradients are in place
+        static, replay = entry
+        for dst, src in zip(static, (a, v, t, y)):
+            dst.copy_(src, non_blocking=True)
+        return replay()
+
     # ---- one epoch (training.py:176-245)
     def train_epoch(self, train_loaders: Dict[str, Iterable]) -> Dict[str, float]:
         self.model.train()
@@ -111,7 +134,9 @@ class DEERTrainer:
             for batch in loader:
                 a, v, t, y = unpack_batch(batch, self.device)
                 # no zero_grad(): the fused step overwrites every live gradient slice of the flat buffer
-                ld = self.model.train_step(a, v, t, y, events=events)     # forward + loss + backward, fused
+                ld = self._graph_step(a, v, t, y) if self._graph_ok(a) else None
+                if ld is None:
+                    ld = self.model.train_step(a, v, t, y, events=events)     # forward + loss + backward, fused
                 if self.comm is not None:
                     self.comm.launch(self.model.flat_grad())
                     self.comm.wait(self.model.flat_grad())
