@@ -230,6 +230,9 @@ GemmTile pick_tile(const GemmGroup& g) {
     }
     if (plain && t256 >= 160 && t256 <= 256) return TILE_256x256;
   }
+  // ~one 128x64 tile per CU: the 8-wave 128x64 kernel (launcher) moves 25 % fewer operand bytes than two 64x64
+  // workgroups per CU, and the K loop of those is bound by the CU's vector-memory path
+  if (!f32 && !g.p[0].trans_a && !g.p[0].trans_b && tiles[1] >= 200 && tiles[1] <= 320) return TILE_128x64;
   static int t128 = -1;   // MMDEER_T128: smallest 128x64 tile count that selects the 128x64 kernel
   if (t128 < 0) { const char* e = getenv("MMDEER_T128"); t128 = e ? atoi(e) : 512; }
   if (tiles[1] >= t128) return TILE_128x64;

@@ -34,13 +34,19 @@ namespace {
 #define KSTAMP(slot) do {} while (0)
 #endif
 
+int env_nt8() {   // MMDEER_NT8=0: never use the 8-wave 128x64 form
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_NT8"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // pieces (1 KiB wave-instructions) each wave issues per K-tile
-template <int BM, int BN> struct Glds { static constexpr int PA = BM / 32, PB = BN / 32, LPT = PA + PB; };
+template <int BM, int BN, int NW> struct Glds { static constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW), LPT = PA + PB; };
 
 // Problem 0 of the launch as plain scalar kernel arguments: they lead the kernarg segment and are preloaded into
 // SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count), so a workgroup of problem 0 -- all of
@@ -55,14 +61,19 @@ struct NtKernargs {   // mirror of the kernel's parameter list (for the offset o
   GemmGroup g;
 };
 
-template <int BM, int BN, int NST>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_glds_kernel(
+// NW = waves per workgroup: 4 (2 x 2, two workgroups per CU for the tiles up to 128x64) or 8 (4 x 2 on a 128x64 tile,
+// one workgroup per CU).  The K loop of the 64x64 kernel is bound by the CU's vector-memory path, not by latency:
+// two resident workgroups pull 2 x 16 KiB per K-tile at ~54 of the 64 B/clk the path delivers.  A 128x64 tile shared
+// by 8 waves covers the same outputs with 24 KiB (one weight tile instead of two), each wave keeping a 32x32 block.
+template <int BM, int BN, int NST, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_glds_kernel(
     const bf16_t* A0, const bf16_t* B0, int M0, int N0, int nk0, int lda0, int ldb0, int tiles_n0, int nt0, int nwg,
     const GemmGroup g) {
-  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+  constexpr int WTM = BM / (NW / 2), WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int LDS_BYTES = NST * STAGE;
-  constexpr int PA = Glds<BM, BN>::PA, PB = Glds<BM, BN>::PB, LPT = Glds<BM, BN>::LPT;
+  constexpr int PA = Glds<BM, BN, NW>::PA, PB = Glds<BM, BN, NW>::PB, LPT = Glds<BM, BN, NW>::LPT;
+  static_assert(PA >= 1 && PB >= 1, "every wave issues at least one piece per operand");
   static_assert(NST >= 3 && NST <= 4, "ring depth");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
@@ -111,12 +122,12 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_gl
   const bf16_t* pb[PB];
 #pragma unroll
   for (int j = 0; j < PA; ++j) {
-    const int row = row0 + (4 * j + wave) * 8 + r8;
+    const int row = row0 + (NW * j + wave) * 8 + r8;
     pa[j] = Ab + (long long)(row < M ? row : 0) * lda + kchunk;
   }
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
-    const int row = col0 + (4 * j + wave) * 8 + r8;
+    const int row = col0 + (NW * j + wave) * 8 + r8;
     pb[j] = Bb + (long long)(row < N ? row : 0) * ldb + kchunk;
   }
   auto issue = [&](int stage) __attribute__((always_inline)) {   // DMA one K-tile into `stage`, advance the pointers
@@ -124,13 +135,13 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_gl
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[j],
-                                       (__attribute__((address_space(3))) void*)(sa + j * 4096), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sa + j * NW * 1024), 16, 0, 0);
       pa[j] += 64;
     }
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[j],
-                                       (__attribute__((address_space(3))) void*)(sa + A_BYTES + j * 4096), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sa + A_BYTES + j * NW * 1024), 16, 0, 0);
       pb[j] += 64;
     }
   };
@@ -204,11 +215,11 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_nt_gl
   KSTAMP(5);
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int NW>
 int launch_glds(const GemmGroup& g, int total, hipStream_t stream) {
   const GemmProblem& q = g.p[0];
   const int nt0 = q.batch == 1 ? g.tile_start[1] : 0;   // tile_start[nprob..] = total
-  hipLaunchKernelGGL((gemm_nt_glds_kernel<BM, BN, NST>), dim3(total), dim3(256), 0, stream,
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<BM, BN, NST, NW>), dim3(total), dim3(NW * 64), 0, stream,
                      reinterpret_cast<const bf16_t*>(q.A), reinterpret_cast<const bf16_t*>(q.B), q.M, q.N, q.K >> 6, q.lda,
                      q.ldb, q.tiles_n, nt0, g.xcd_remap ? total : 0, g);
   MMDEER_HIP(hipGetLastError());
@@ -221,9 +232,12 @@ int launch_glds(const GemmGroup& g, int total, hipStream_t stream) {
 // no transposition, no split-K
 int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStream_t s) {
   switch (tile) {
-    case TILE_64x64: return launch_glds<64, 64, 4>(g, total, s);
-    case TILE_128x64: return launch_glds<128, 64, 3>(g, total, s);   // 72 KiB ring: two workgroups per CU
-    default: return launch_glds<128, 128, 4>(g, total, s);
+    case TILE_64x64: return launch_glds<64, 64, 4, 4>(g, total, s);
+    case TILE_128x64:
+      // up to ~one workgroup per CU: the 8-wave form (96 KiB ring, one per CU); more tiles: 4 waves, 72 KiB ring, two per CU
+      if (total <= 320 && env_nt8()) return launch_glds<128, 64, 4, 8>(g, total, s);
+      return launch_glds<128, 64, 3, 4>(g, total, s);
+    default: return launch_glds<128, 128, 4, 4>(g, total, s);
   }
 }
 
