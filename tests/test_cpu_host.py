@@ -128,3 +128,29 @@ def test_shard_rows_partitions_the_batch():
         assert spans[0][0] == 0 and spans[-1][1] == total
         for (b0, e0), (b1, e1) in zip(spans, spans[1:]):
             assert e0 == b1 and e0 >= b0
+
+
+def test_fused_adamw_argument_checks_without_a_gpu():
+    """optim.FusedAdamW validates its configuration on the host and refuses to step without gradients of a
+    train_step (no silent torch fallback)."""
+    import torch
+
+    from mmdeer.model import ModelConfig, MultimodalDEER
+    from mmdeer.optim import FusedAdamW
+
+    m = MultimodalDEER(ModelConfig())
+    with pytest.raises(ValueError):
+        FusedAdamW(m, lr=-1.0)
+    live = m.live_parameters()
+    with pytest.raises(ValueError):
+        FusedAdamW(m, [{"params": live[:3]}])                       # trainable parameters left out
+    with pytest.raises(NotImplementedError):
+        FusedAdamW(m, [{"params": live[:3], "weight_decay": 0.1}, {"params": live[3:]}])   # per-group decay
+    opt = FusedAdamW(m, [{"params": live[:10], "lr": 5e-5}, {"params": live[10:]}], lr=1e-4)
+    assert [g["lr"] for g in opt.param_groups] == [5e-5, 1e-4]
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.5)     # torch schedulers drive it unchanged
+    with pytest.raises(RuntimeError):
+        opt.step()
+    sd = opt.state_dict()
+    assert sd["step"] == 0 and sd["exp_avg"] is None
+    del sched
