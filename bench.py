@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="samples per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-comm", default="bf16", choices=["bf16", "fp32"],
+                    help="payload of the data-parallel gradient all-reduce (N > 1): bf16 halves the bytes over xGMI")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     args = ap.parse_args()
 
@@ -104,7 +106,7 @@ def main():
     a, v, t, y = (torch.from_numpy(data[k]).to(dev) for k in ("audio", "video", "text", "targets"))
     if args.dtype == "bf16":
         a, v, t = a.bfloat16(), v.bfloat16(), t.bfloat16()         # BASELINE configs 3-5: bf16 feature blocks
-    comm = BucketedAllReduce(device=dev, force=force_comm) if (world > 1 or force_comm) else None
+    comm = BucketedAllReduce(device=dev, force=force_comm, payload=args.grad_comm) if (world > 1 or force_comm) else None
     K, W = args.steps, args.warmup
     prof = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     for e0, e1 in prof:
@@ -116,7 +118,28 @@ def main():
     # One step = ~45 kernels of 4-40 us: launched one by one the host needs about as long as the GPU, so the step is
     # captured once into a HIP graph (dropout masks advance through a device-side counter) and replayed.
     ev = comm.events if comm else None
-    replay = None if args.eager else model.capture_train_step(a, v, t, y, events=ev)
+    comm_in_graph = False
+    replay = None
+    if not args.eager:
+        if comm and os.environ.get("MMDEER_GRAPH_COMM", "1") == "1":
+            # the gradient all-reduce is captured into the step's graph: enqueued from the host after every replay it
+            # cost ~85 us per step on a 1-rank group, inside the graph ~25 us (most of an RCCL call is host latency).
+            # Falls back to the host-enqueued form if the collective cannot be captured.
+            def exchange():
+                comm.launch(model.flat_grad())
+                comm.wait()
+            try:
+                model.train_step(a, v, t, y)
+                exchange()                       # communicator set up outside the capture
+                torch.cuda.synchronize()
+                replay = model.capture_train_step(a, v, t, y, events=ev, after=exchange)
+                comm_in_graph = True
+            except Exception as e:               # noqa: BLE001
+                print(f"[bench] all-reduce not capturable here ({type(e).__name__}: {e}); enqueueing it from the host", file=sys.stderr)
+                torch.cuda.synchronize()
+                replay = None
+        if replay is None:
+            replay = model.capture_train_step(a, v, t, y, events=ev)
 
     def one_step(i=None, optimize=False):
         # The metric is forward + loss + backward.  The packed bf16 / transposed weight copies the kernels read are
@@ -126,7 +149,7 @@ def main():
             ld = replay()
         else:
             ld = model.train_step(a, v, t, y, events=ev, prof_events=prof[i] if i is not None else None)
-        if comm:
+        if comm and not (comm_in_graph and replay is not None):
             comm.launch(model.flat_grad())
             comm.wait()
         if optimize:
@@ -188,7 +211,8 @@ def main():
                                    f"materialised in the flat buffer), B={B}/GPU, (B,84)+(B,256)+(B,768) {args.dtype} feature "
                                    f"blocks, random-init weights; optimiser step excluded as the metric defines "
                                    f"(it maintains the packed weight copies and is timed separately)", "global_batch": world * B,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
+                       "parallelism": (f"dp{world} (one process per GPU, flat-gradient all-reduce over RCCL, {args.grad_comm} payload)"
+                                       if world > 1 else "single")},
             "launch": "eager" if replay is None else "hip-graph replay",
             "final_loss": round(loss, 6),
             "train_step_with_optimizer_ms": round(full_elapsed / K * 1e3, 4),     # fwd + bwd + clip + AdamW + weight pack

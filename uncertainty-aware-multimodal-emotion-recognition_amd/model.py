@@ -445,7 +445,7 @@ class MultimodalDEER(nn.Module):
     def flat_grad(self) -> Optional[torch.Tensor]:
         return self._flat_grad
 
-    def capture_train_step(self, audio, video, text, targets, events=None):
+    def capture_train_step(self, audio, video, text, targets, events=None, after=None):
         """Capture ``train_step`` on these (static) input tensors into a HIP graph and return ``replay()``.
 
         One step is ~45 kernel launches of 4-40 us each; enqueueing them from the host costs about as much as the GPU
@@ -453,7 +453,9 @@ class MultimodalDEER(nn.Module):
         tensors are overwritten in place); new data is fed by copying into ``audio/video/text/targets``.  Dropout
         masks advance through a device-side counter (``offset_dev``), so replays draw fresh masks.  The packed
         weight copies must be current at capture time and be kept current by ``optim.FusedAdamW`` (an eager call
-        between replays); shapes, dtype and train mode are frozen into the graph."""
+        between replays); shapes, dtype and train mode are frozen into the graph.  ``after`` (optional callable) runs
+        inside the capture right after the step -- e.g. the data-parallel gradient all-reduce, so that it is replayed
+        with the step instead of being enqueued from the host every time."""
         if not self.training:
             raise RuntimeError("capture_train_step: call .train() first")
         for t in (audio, video, text, targets):
@@ -471,6 +473,8 @@ class MultimodalDEER(nn.Module):
             if not in_kernel:
                 self._graph_counter.add_(1)
             out = self.train_step(audio, video, text, targets, events=events, _offset_dev=self._graph_counter, _bump=in_kernel)
+            if after is not None:
+                after()
         self._graph = graph
 
         def replay():

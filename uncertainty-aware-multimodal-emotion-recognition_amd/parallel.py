@@ -18,25 +18,50 @@ import torch.distributed as dist
 
 class BucketedAllReduce:
     """Gradient all-reduce of the flat buffer (the name is kept from the bucketed design; ``events`` is None: the
-    library needs no per-bucket events any more, ``train_step(events=None)``)."""
+    library needs no per-bucket events any more, ``train_step(events=None)``).
+
+    ``payload``: ``'bf16'`` (default on the GPU) sends the gradients as bf16 -- half the bytes over xGMI, the payload
+    SURVEY 8e allows and the equivalent of torch DDP's ``bf16_compress_hook``: cast (``mmdeer_convert``), averaged
+    all-reduce, cast back into the fp32 buffer; ``'fp32'`` exchanges the buffer as it is."""
 
     def __init__(self, group: Optional["dist.ProcessGroup"] = None, device: Optional[torch.device] = None,
-                 force: bool = False):
+                 force: bool = False, payload: Optional[str] = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force and dist.is_initialized()    # run the collective even on a 1-rank group (rehearsal)
         self.cuda = device is not None and device.type == "cuda"
+        if payload is None:
+            payload = "bf16" if self.cuda else "fp32"
+        if payload not in ("bf16", "fp32"):
+            raise ValueError("payload must be 'bf16' or 'fp32'")
+        if payload == "bf16" and not self.cuda:
+            raise ValueError("the bf16 payload needs the GPU (RCCL) path")
+        self.payload = payload
         self.events = None
         self._work: List = []
+        self._half: Optional[torch.Tensor] = None
+
+    def _convert(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        from . import _lib
+        lib = _lib.load()
+        _lib.check(lib.mmdeer_convert(src.data_ptr(), int(src.dtype == torch.float32), dst.data_ptr(),
+                                      int(dst.dtype == torch.float32), src.numel(), _lib.current_stream()))
 
     def launch(self, flat: torch.Tensor) -> None:
         """Enqueue the all-reduce behind the backward pass (call right after ``model.train_step``)."""
         if self.world == 1 and not self.force:
             return
         if self.cuda:   # RCCL: averaged in the collective, ordered after the backward kernels on the current stream
-            self._work = [dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)]
+            if self.payload == "bf16":
+                if self._half is None or self._half.numel() != flat.numel() or self._half.device != flat.device:
+                    self._half = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+                self._convert(flat, self._half)
+                self._work = [dist.all_reduce(self._half, op=dist.ReduceOp.AVG, group=self.group, async_op=True)]
+            else:
+                self._work = [dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)]
         else:           # gloo (CPU tests): no AVG op
             self._work = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        self._flat = flat
 
     def wait(self, flat: Optional[torch.Tensor] = None) -> None:
         """Make the reduced gradients visible to the current stream (or the host for gloo)."""
@@ -44,6 +69,8 @@ class BucketedAllReduce:
             return
         for w in self._work:
             w.wait()
+        if self.cuda and self.payload == "bf16" and self._work:
+            self._convert(self._half, self._flat)
         if not self.cuda and flat is not None:
             flat.div_(self.world)
         self._work = []
