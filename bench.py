@@ -119,27 +119,38 @@ def main():
     # captured once into a HIP graph (dropout masks advance through a device-side counter) and replayed.
     ev = comm.events if comm else None
     comm_in_graph = False
+    comm_mode = "none"
     replay = None
     if not args.eager:
         if comm and os.environ.get("MMDEER_GRAPH_COMM", "1") == "1":
-            # the gradient all-reduce is captured into the step's graph: enqueued from the host after every replay it
-            # cost ~85 us per step on a 1-rank group, inside the graph ~25 us (most of an RCCL call is host latency).
-            # Falls back to the host-enqueued form if the collective cannot be captured.
+            # The gradient exchange is captured into the step's graph: enqueued from the host after every replay it cost
+            # ~85 us per step on a 1-rank group, inside the graph ~25 us (most of an RCCL call is host latency).
+            # Default: one all-reduce after the pass, inside the graph.  MMDEER_DP_OVERLAP=1: the backward pass in two
+            # calls with the all-reduce of buckets 0-1 on a side stream under the audio-visual part (splitting the
+            # weight-gradient launch costs ~45 us per step, so it only pays when the exchange itself is long).  Either
+            # falls back to the host-enqueued exchange if the capture fails.
             def exchange():
                 comm.launch(model.flat_grad())
                 comm.wait()
-            try:
-                model.train_step(a, v, t, y)
-                exchange()                       # communicator set up outside the capture
-                torch.cuda.synchronize()
-                replay = model.capture_train_step(a, v, t, y, events=ev, after=exchange)
-                comm_in_graph = True
-            except Exception as e:               # noqa: BLE001
-                print(f"[bench] all-reduce not capturable here ({type(e).__name__}: {e}); enqueueing it from the host", file=sys.stderr)
-                torch.cuda.synchronize()
-                replay = None
+            plans = [("overlapped in-graph", dict(comm=comm))] if os.environ.get("MMDEER_DP_OVERLAP", "0") == "1" else []
+            plans.append(("in-graph", dict(after=exchange)))
+            for name, kw in plans:
+                try:
+                    model.train_step(a, v, t, y)
+                    exchange()                       # communicator set up outside the capture
+                    torch.cuda.synchronize()
+                    replay = model.capture_train_step(a, v, t, y, events=ev, **kw)
+                    comm_in_graph, comm_mode = True, name
+                    break
+                except Exception as e:               # noqa: BLE001
+                    print(f"[bench] {name} exchange not capturable here ({type(e).__name__}: {e})", file=sys.stderr)
+                    torch.cuda.synchronize()
+                    replay = None
         if replay is None:
             replay = model.capture_train_step(a, v, t, y, events=ev)
+            comm_mode = "host-enqueued" if comm else "none"
+    elif comm:
+        comm_mode = "host-enqueued"
 
     def one_step(i=None, optimize=False):
         # The metric is forward + loss + backward.  The packed bf16 / transposed weight copies the kernels read are
@@ -211,9 +222,10 @@ def main():
                                    f"materialised in the flat buffer), B={B}/GPU, (B,84)+(B,256)+(B,768) {args.dtype} feature "
                                    f"blocks, random-init weights; optimiser step excluded as the metric defines "
                                    f"(it maintains the packed weight copies and is timed separately)", "global_batch": world * B,
-                       "parallelism": (f"dp{world} (one process per GPU, flat-gradient all-reduce over RCCL, {args.grad_comm} payload)"
-                                       if world > 1 else "single")},
+                       "parallelism": (f"dp{world} (one process per GPU, gradient all-reduce over RCCL, {args.grad_comm} payload, "
+                                        f"{comm_mode})" if world > 1 else "single")},
             "launch": "eager" if replay is None else "hip-graph replay",
+            "grad_exchange": comm_mode,
             "final_loss": round(loss, 6),
             "train_step_with_optimizer_ms": round(full_elapsed / K * 1e3, 4),     # fwd + bwd + clip + AdamW + weight pack
             "optimizer_ms": round((full_elapsed - elapsed) / K * 1e3, 4),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 3
+#define MMDEER_ABI_VERSION 4
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -133,6 +133,11 @@ typedef struct mmdeer_backward_args {
    * In the default launch plan all weight gradients are produced by one grouped launch at the end of the pass, so
    * the three events are recorded together; with MMDEER_SIDE=1 each one follows its own bucket. */
   void* bucket_events[3];
+  /* 0: the whole backward pass.  1 / 2: the pass in two calls -- 1 = head + output_projection + trimodal fusion
+   * including their weight gradients (buckets 0 and 1 of the flat buffer are final when it returns), 2 = the
+   * audio-visual remainder (bucket 2).  Lets a data-parallel caller start the all-reduce of buckets 0-1 (89 % of
+   * the gradient) while part 2 runs.  Both calls take the same arguments; 1 must precede 2. */
+  int32_t phase;
   void* stream;
 } mmdeer_backward_args;
 

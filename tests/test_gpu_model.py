@@ -321,3 +321,33 @@ def test_alternative_launch_plans_match_the_default():
         assert outs["default"]["loss"] == pytest.approx(outs[mode]["loss"], rel=1e-6), mode
         assert outs["default"]["gabs"] == pytest.approx(outs[mode]["gabs"], rel=1e-4), mode
         assert outs["default"]["gsum"] == pytest.approx(outs[mode]["gsum"], rel=1e-3, abs=1e-6), mode
+
+
+def test_two_phase_backward_equals_single_call():
+    """mmdeer_backward with phase = 1 then 2 (the data-parallel overlap plan) fills the flat gradient buffer with
+    exactly what the single call produces; after phase 1 buckets 0-1 are final and bucket 2 is still untouched."""
+    lib = _lib.load()
+    m = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=8)).to(DEV).train()
+    b = batch(512, seed=13)
+    a, v, t, y = (b[k].to(DEV) for k in ("audio", "video", "text", "targets"))
+    m.train_step(a, v, t, y)
+    ref = m.flat_grad().clone()
+    lo = int(lib.mmdeer_bucket_end(2))
+
+    o = m._launch_forward(a, v, t, y, want_features=False)
+    meta = o["_meta"]
+    meta["offset"] = meta["offset"]            # same dropout step as the forward just run
+    # re-run the reference with the SAME dropout step for a bitwise comparison
+    flat0 = torch.zeros_like(ref)
+    loss0 = torch.empty(20, device=DEV)
+    m._launch_backward(meta, meta["targets"], loss_out=loss0, flat=flat0, want_views=False, phase=0)
+    flat = torch.zeros_like(ref)
+    loss = torch.empty(20, device=DEV)
+    m._launch_backward(meta, meta["targets"], loss_out=loss, flat=flat, want_views=False, phase=1)
+    torch.cuda.synchronize()
+    assert torch.equal(flat[lo:], flat0[lo:])
+    assert float(flat[:lo].abs().sum()) == 0.0
+    m._launch_backward(meta, meta["targets"], loss_out=loss, flat=flat, want_views=False, phase=2)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, flat0)
+    assert torch.equal(loss, loss0)

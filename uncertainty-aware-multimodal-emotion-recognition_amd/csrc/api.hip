@@ -613,6 +613,9 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // flush(bucket, last): launch what has been collected.  Default (one stream): nothing until the end, then one
   // launch of everything.  MMDEER_SIDE=1: every bucket is launched as soon as its inputs exist, on the side stream.
   SideCtx* sc = (env_side() && !f32) ? get_side_ctx() : nullptr;
+  const int phase = a->phase;
+  MMDEER_CHECK(phase >= 0 && phase <= 2, "backward: phase must be 0, 1 or 2 (got %d)", phase);
+  int ev_done = phase == 2 ? 2 : 0;   // first bucket whose event has not been recorded yet
   auto flush = [&](int bucket, bool last) -> int {
     if (!sc && !last) return 0;
     hipStream_t ls = s;
@@ -628,21 +631,20 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
       for (int i = 0; i < dwg.nprob; ++i) Exec::add_slab_segments(rt, dwg.p[i], L.slab, G);
     }
     if (launch_reduce_partials(rt, ls) != 0) return -1;
-    if (sc && a->bucket_events[bucket]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[bucket], ls));
+    // every bucket up to this one is final now
+    for (int b = ev_done; b <= bucket; ++b)
+      if (a->bucket_events[b]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[b], ls));
+    ev_done = bucket + 1;
     dwg = GemmGroup{};
     rt = ReduceTable{};
-    if (last) {
-      if (sc) {
-        MMDEER_HIP(hipEventRecord(sc->join, sc->s2));
-        MMDEER_HIP(hipStreamWaitEvent(s, sc->join, 0));
-      } else {
-        for (int b = 0; b < 3; ++b)
-          if (a->bucket_events[b]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[b], s));
-      }
+    if (last && sc) {
+      MMDEER_HIP(hipEventRecord(sc->join, sc->s2));
+      MMDEER_HIP(hipStreamWaitEvent(s, sc->join, 0));
     }
     return 0;
   };
 
+  if (phase != 2) {
   // ================= bucket 0: DEER head =================
   // B1: last head layer + NIG activations (+ loss gradient)
   TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
@@ -713,7 +715,9 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     reduce_ln(rt, L.part_ln_o1, P_OP_G, FUS);
     reduce_ln(rt, L.part_ln_t3, P_TFF_G, FUS);
   }
-  TRY(flush(1, false));
+  TRY(flush(1, phase == 1));
+  if (phase == 1) return 0;
+  }   // phase != 2
 
   // ================= bucket 2: audio-visual fusion =================
   TRY(launch_ln_bwd(L.dav, L.y_a2, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), L.dz_a2, L.part_ln_a2, B, INTER, f32, X.mask_scale, s));

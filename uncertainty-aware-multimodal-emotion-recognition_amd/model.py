@@ -312,7 +312,7 @@ class MultimodalDEER(nn.Module):
                 "trimodal_features": trif, "av_attention": avw, "trimodal_attention": triw}
 
     def _launch_backward(self, ctx_or_meta, targets, g_mu=None, g_nu=None, g_alpha=None, g_beta=None,
-                         loss_out=None, bin_counts=None, events=None, flat=None, want_views=True):
+                         loss_out=None, bin_counts=None, events=None, flat=None, want_views=True, phase=0):
         lib = _lib.load()
         if isinstance(ctx_or_meta, dict):
             meta = ctx_or_meta
@@ -350,6 +350,7 @@ class MultimodalDEER(nn.Module):
         if events is not None:
             for i, ev in enumerate(events):
                 a.bucket_events[i] = ev.cuda_event
+        a.phase = int(phase)
         a.stream = _lib.current_stream()
         _lib.check(lib.mmdeer_backward(C.byref(a)))
         self._flat_grad = flat
@@ -408,7 +409,7 @@ class MultimodalDEER(nn.Module):
         return multitask_deer_loss(predictions, targets, self.loss_cfg)
 
     def train_step(self, audio, video, text, targets, events=None, prof_events=None, _offset_dev=None,
-                   return_features: bool = False, _bump: bool = False) -> Dict[str, torch.Tensor]:
+                   return_features: bool = False, _bump: bool = False, comm=None) -> Dict[str, torch.Tensor]:
         """Fused forward + MultiTaskDEERLoss + backward: two library calls, gradients land in one flat buffer
         (``.grad`` of every live parameter is a view of it).  Equivalent to
         ``compute_loss(model(a, v, t), y)['total_loss'].backward()``."""
@@ -426,8 +427,21 @@ class MultimodalDEER(nn.Module):
         if self._step_flat is None or self._step_flat.device != dev:
             self._step_flat = torch.zeros(self._flat_elems, dtype=torch.float32, device=dev)
             self._step_views = None
-        views = self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, events=events,
-                                      flat=self._step_flat, want_views=self._step_views is None)
+        if comm is not None and getattr(comm, "active", False):
+            # data parallel, overlapped: the backward pass in two calls; the all-reduce of buckets 0-1 (head, output
+            # projection, trimodal fusion: 89 % of the gradient) runs on the communicator's side stream while the
+            # audio-visual part of the pass, its weight gradients and their reduction are computed
+            lo = int(_lib.load().mmdeer_bucket_end(2))
+            self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, flat=self._step_flat,
+                                  want_views=False, phase=1)
+            comm.launch_range(self._step_flat, lo, self._flat_elems)
+            views = self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, flat=self._step_flat,
+                                          want_views=self._step_views is None, phase=2)
+            comm.launch_range(self._step_flat, 0, lo)
+            comm.join()
+        else:
+            views = self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, events=events,
+                                          flat=self._step_flat, want_views=self._step_views is None)
         if self._step_views is None:
             self._step_views = views
             self._grads_bound = False
@@ -445,7 +459,7 @@ class MultimodalDEER(nn.Module):
     def flat_grad(self) -> Optional[torch.Tensor]:
         return self._flat_grad
 
-    def capture_train_step(self, audio, video, text, targets, events=None, after=None):
+    def capture_train_step(self, audio, video, text, targets, events=None, after=None, comm=None):
         """Capture ``train_step`` on these (static) input tensors into a HIP graph and return ``replay()``.
 
         One step is ~45 kernel launches of 4-40 us each; enqueueing them from the host costs about as much as the GPU
@@ -464,7 +478,7 @@ class MultimodalDEER(nn.Module):
         dev = audio.device
         # eager warm-up: allocates the workspace and the persistent gradient buffer, packs the weights.  It is a real
         # step on the given batch: its loss dict is returned as ``replay.first`` and its gradients are in place
-        first = self.train_step(audio, video, text, targets)
+        first = self.train_step(audio, video, text, targets, comm=comm)
         self._graph_counter = torch.full((), int(self._step), dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
@@ -472,7 +486,8 @@ class MultimodalDEER(nn.Module):
         with torch.cuda.graph(graph):
             if not in_kernel:
                 self._graph_counter.add_(1)
-            out = self.train_step(audio, video, text, targets, events=events, _offset_dev=self._graph_counter, _bump=in_kernel)
+            out = self.train_step(audio, video, text, targets, events=events, _offset_dev=self._graph_counter, _bump=in_kernel,
+                                  comm=comm)
             if after is not None:
                 after()
         self._graph = graph

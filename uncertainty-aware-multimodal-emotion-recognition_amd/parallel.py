@@ -40,6 +40,7 @@ class BucketedAllReduce:
         self.events = None
         self._work: List = []
         self._half: Optional[torch.Tensor] = None
+        self._side: Optional["torch.cuda.Stream"] = None
 
     def _convert(self, src: torch.Tensor, dst: torch.Tensor) -> None:
         from . import _lib
@@ -62,6 +63,36 @@ class BucketedAllReduce:
         else:           # gloo (CPU tests): no AVG op
             self._work = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
         self._flat = flat
+
+    # ---- overlapped form (GPU): the exchange of a slice of the flat buffer on a side stream, forked from / joined to
+    #      the current stream by events -- capturable into a HIP graph together with the step (model.train_step(comm=...))
+    @property
+    def active(self) -> bool:
+        return self.cuda and (self.world > 1 or self.force)
+
+    def launch_range(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        """All-reduce ``flat[lo:hi]`` on the side stream, ordered after everything enqueued on the current stream."""
+        if not self.active or hi <= lo:
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=flat.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            view = flat[lo:hi]
+            if self.payload == "bf16":
+                if self._half is None or self._half.numel() != flat.numel() or self._half.device != flat.device:
+                    self._half = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+                half = self._half[lo:hi]
+                self._convert(view, half)
+                dist.all_reduce(half, op=dist.ReduceOp.AVG, group=self.group)
+                self._convert(half, view)
+            else:
+                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+
+    def join(self) -> None:
+        """The current stream waits for the exchanges launched with ``launch_range``."""
+        if self.active and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def wait(self, flat: Optional[torch.Tensor] = None) -> None:
         """Make the reduced gradients visible to the current stream (or the host for gloo)."""
