@@ -238,6 +238,15 @@ int mmdeer_cross_modal_attn_fwd(const void* q, const void* k_audio, const void* 
 int mmdeer_lstm_cell_t1(const void* gates, int ld_gates, void* out, int ld_out, int B, int hidden, int ndir, int act_f32,
                         void* stream);
 
+/* ---- streaming evaluation statistics (reference src/utils/metrics.py:59-125) ---------------------------
+ * pred / target / unc: [B][3] fp32 (unc may be NULL).  acc: device double[3][8], zeroed by the caller before the first
+ * batch; every call adds {n, sum p, sum t, sum p^2, sum t^2, sum pt, sum |p-t|, sum (p-t)^2} per emotion dimension over
+ * the rows without NaN -- CCC, Pearson, MAE and RMSE follow from these 24 numbers, so validation copies 192 bytes to the
+ * host instead of (N, 3) arrays.  sample_err / sample_unc (optional, [B]): per-sample mean |error| / mean uncertainty for
+ * the quantile-binned calibration error (metrics.py:214-279). */
+int mmdeer_eval_accumulate(const float* pred, const float* target, const float* unc, double* acc, float* sample_err,
+                           float* sample_unc, int B, void* stream);
+
 /* fp32 <-> bf16 conversion of a contiguous device buffer (n % 4 == 0) */
 int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream);
 

@@ -185,3 +185,38 @@ def test_graph_replay_with_fused_optimizer_trains(dtype):
     with torch.no_grad():
         out2 = m2(a, v, t)
     assert torch.allclose(out["mu_all"], out2["mu_all"], rtol=1e-5, atol=1e-6)
+
+
+def test_streaming_metrics_match_host_metrics():
+    """metrics.StreamingMetrics (mmdeer_eval_accumulate, fp64 sums on the device) against the numpy formulas of the
+    reference's metrics module, over ragged batches, with NaN rows and a constant column."""
+    from mmdeer.metrics import StreamingMetrics, validation_metrics
+
+    rng = np.random.default_rng(5)
+    n = 3000
+    tgt = np.tanh(rng.normal(size=(n, 3))).astype(np.float32)
+    pred = (0.8 * tgt + 0.3 * rng.normal(size=(n, 3)) + np.array([0.05, -0.1, 0.0])).astype(np.float32)
+    unc = np.abs(rng.normal(size=(n, 3))).astype(np.float32) * 0.5
+    pred[17, 1] = np.nan                      # masked by the reference's _clean()
+    sm = StreamingMetrics("cuda:0")
+    i = 0
+    for bs in (1, 255, 256, 1000, 7, n):      # ragged batches
+        j = min(n, i + bs)
+        if j > i:
+            sm.update(*(torch.from_numpy(x[i:j]).to("cuda:0") for x in (pred, tgt, unc)))
+        i = j
+    got = sm.compute()
+    ref = validation_metrics(pred, tgt, None)
+    for k, v in ref.items():
+        if k != "ece":
+            assert got[k] == pytest.approx(v, rel=1e-6, abs=1e-9), k
+    # calibration error: same per-sample reduction as the reference (NaN-free copy: np.quantile cannot take NaN)
+    pred2 = pred.copy(); pred2[17, 1] = 0.0
+    sm2 = StreamingMetrics("cuda:0")
+    sm2.update(*(torch.from_numpy(x).to("cuda:0") for x in (pred2, tgt, unc)))
+    assert sm2.compute()["ece"] == pytest.approx(validation_metrics(pred2, tgt, unc)["ece"], rel=1e-5)
+    # a constant prediction column has no correlation: CCC = 0 as in the reference
+    pred3 = pred2.copy(); pred3[:, 2] = 0.25
+    sm3 = StreamingMetrics("cuda:0")
+    sm3.update(*(torch.from_numpy(x).to("cuda:0") for x in (pred3, tgt, unc)))
+    assert sm3.compute()["ccc_dominance"] == 0.0

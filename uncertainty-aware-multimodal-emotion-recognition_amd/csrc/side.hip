@@ -89,6 +89,50 @@ __global__ __launch_bounds__(256) void lstm_cell_t1_kernel(const void* gates, in
   }
 }
 
+// ---- streaming evaluation statistics (reference src/utils/metrics.py:59-125, src/training/training.py:
+//      316-353): per emotion dimension the sufficient statistics of CCC / Pearson / MAE / RMSE, accumulated in fp64
+//      across validation batches, so the (N, 3) prediction arrays never travel to the host.
+//      acc[d][8] += {n, sum p, sum t, sum p^2, sum t^2, sum p t, sum |p - t|, sum (p - t)^2} over the rows where neither
+//      value is NaN (the reference masks them).  Block 3 writes the per-sample mean |error| and mean uncertainty that
+//      the quantile-binned calibration error needs (2 floats per sample instead of 9).
+__global__ __launch_bounds__(256) void eval_accumulate_kernel(const float* pred, const float* target, const float* unc,
+                                                              double* acc, float* sample_err, float* sample_unc, int B) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 3) {
+    if (!sample_err && !sample_unc) return;
+    for (int b = tid; b < B; b += 256) {
+      float e = 0.f, u = 0.f;
+      for (int d = 0; d < 3; ++d) {
+        e += fabsf(pred[b * 3 + d] - target[b * 3 + d]);
+        if (unc) u += unc[b * 3 + d];
+      }
+      if (sample_err) sample_err[b] = e / 3.f;
+      if (sample_unc) sample_unc[b] = u / 3.f;
+    }
+    return;
+  }
+  __shared__ double sm[8][256];
+  const int d = blockIdx.x;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = tid; b < B; b += 256) {
+    const float pf = pred[b * 3 + d], tf = target[b * 3 + d];
+    if (pf != pf || tf != tf) continue;
+    const double p = pf, t = tf, e = p - t;
+    s[0] += 1.0; s[1] += p; s[2] += t; s[3] += p * p; s[4] += t * t; s[5] += p * t; s[6] += fabs(e); s[7] += e * e;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sm[k][tid] = s[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sm[k][tid] += sm[k][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < 8) acc[d * 8 + tid] += sm[tid][0];   // calls on one stream are ordered: a plain read-modify-write
+}
+
 }  // namespace
 }  // namespace mmdeer
 
@@ -130,6 +174,17 @@ int mmdeer_lstm_cell_t1(const void* gates, int ld_gates, void* out, int ld_out, 
   else
     hipLaunchKernelGGL(lstm_cell_t1_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gates, ld_gates, out,
                        ld_out, B, hidden, ndir);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int mmdeer_eval_accumulate(const float* pred, const float* target, const float* unc, double* acc, float* sample_err,
+                           float* sample_unc, int B, void* stream) {
+  MMDEER_CHECK(B >= 0, "eval_accumulate: batch must be >= 0 (got %d)", B);
+  if (B == 0) return 0;
+  MMDEER_CHECK(pred && target && acc, "eval_accumulate: pred / target / acc must be non-NULL");
+  MMDEER_CHECK(!sample_unc || unc, "eval_accumulate: sample_unc needs unc");
+  hipLaunchKernelGGL(eval_accumulate_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, pred, target, unc, acc, sample_err, sample_unc, B);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

@@ -83,3 +83,59 @@ def validation_metrics(predictions, targets, uncertainties: Optional[np.ndarray]
     out["ece"] = uncertainty_calibration_error(predictions, targets, uncertainties) if uncertainties is not None else 0.0
     out["ccc_overall"] = float(np.mean([out[f"ccc_{n}"] for n in DIMENSION_NAMES[: predictions.shape[1]]]))
     return out
+
+
+class StreamingMetrics:
+    """Validation metrics accumulated on the device: ``update(pred, target, unc)`` per batch is one launch
+    of ``mmdeer_eval_accumulate``; ``compute()`` copies 24 doubles (plus, for the calibration error, two floats per sample)
+    to the host and returns the dictionary of ``validation_metrics``."""
+
+    def __init__(self, device):
+        import torch
+        self._torch = torch
+        self.device = torch.device(device)
+        self.acc = torch.zeros(3, 8, dtype=torch.float64, device=self.device)
+        self._err, self._unc = [], []
+
+    def update(self, predictions, targets, uncertainties=None) -> None:
+        import ctypes  # noqa: F401
+        from . import _lib
+        torch = self._torch
+        p = predictions.detach().float().contiguous()
+        t = targets.detach().float().contiguous()
+        if p.shape != t.shape or p.dim() != 2 or p.shape[1] != 3 or not p.is_cuda:
+            raise ValueError("StreamingMetrics.update expects (B, 3) GPU tensors")
+        u = uncertainties.detach().float().contiguous() if uncertainties is not None else None
+        B = p.shape[0]
+        err = torch.empty(B, dtype=torch.float32, device=p.device) if u is not None else None
+        unc = torch.empty(B, dtype=torch.float32, device=p.device) if u is not None else None
+        lib = _lib.load()
+        _lib.check(lib.mmdeer_eval_accumulate(p.data_ptr(), t.data_ptr(), _lib.ptr(u), self.acc.data_ptr(), _lib.ptr(err),
+                                              _lib.ptr(unc), B, _lib.current_stream()))
+        if u is not None:
+            self._err.append(err)
+            self._unc.append(unc)
+
+    def compute(self) -> Dict[str, float]:
+        acc = self.acc.cpu().numpy()
+        out: Dict[str, float] = {}
+        for i, name in enumerate(DIMENSION_NAMES):
+            n, sp, st, spp, stt, spt, sabs, ssq = acc[i]
+            if n == 0:
+                out[f"ccc_{name}"], out[f"mae_{name}"], out[f"rmse_{name}"] = 0.0, float("inf"), float("inf")
+                continue
+            mp, mt = sp / n, st / n
+            vp, vt = max(spp / n - mp * mp, 0.0), max(stt / n - mt * mt, 0.0)
+            cov = spt / n - mp * mt
+            den = vp + vt + (mp - mt) ** 2
+            out[f"ccc_{name}"] = float(2.0 * cov / den) if (vp > 0 and vt > 0 and den != 0) else 0.0   # 2 rho sp st == 2 cov
+            out[f"mae_{name}"] = float(sabs / n)
+            out[f"rmse_{name}"] = float(np.sqrt(ssq / n))
+        if self._err:
+            torch = self._torch
+            e, u = torch.cat(self._err).cpu().numpy(), torch.cat(self._unc).cpu().numpy()
+            out["ece"] = uncertainty_calibration_error(e, np.zeros_like(e), u)   # |e - 0| = the per-sample mean error
+        else:
+            out["ece"] = 0.0
+        out["ccc_overall"] = float(np.mean([out[f"ccc_{n}"] for n in DIMENSION_NAMES]))
+        return out

@@ -18,7 +18,7 @@ from typing import Dict, Iterable, Optional
 import numpy as np
 import torch
 
-from .metrics import validation_metrics
+from .metrics import StreamingMetrics, validation_metrics
 from .model import MultimodalDEER
 from .optim import FusedAdamW
 
@@ -159,17 +159,20 @@ class DEERTrainer:
     @torch.no_grad()
     def validate_epoch(self, val_loaders: Dict[str, Iterable]) -> Dict[str, float]:
         self.model.eval()
-        preds, tgts, uncs, losses = [], [], [], []
+        # CCC / MAE / RMSE statistics are accumulated on the device batch by batch (mmdeer_eval_accumulate); only 24
+        # doubles and the per-sample (mean error, mean uncertainty) pairs of the calibration error reach the host
+        sm = StreamingMetrics(self.device)
+        losses = []
         for loader in val_loaders.values():
             for batch in loader:
                 a, v, t, y = unpack_batch(batch, self.device)
                 out = self.model(a, v, t)
                 p, u = self.model.get_predictions_and_uncertainties(out)
                 losses.append(self.model.compute_loss(out, y)["total_loss"])
-                preds.append(p); tgts.append(y); uncs.append(u)
-        if not preds:
+                sm.update(p, y, u)
+        if not losses:
             return {"val_loss": float("nan")}
-        m = validation_metrics(torch.cat(preds).cpu().numpy(), torch.cat(tgts).cpu().numpy(), torch.cat(uncs).cpu().numpy())
+        m = sm.compute()
         m["val_loss"] = float(torch.stack(losses).mean())
         return m
 
