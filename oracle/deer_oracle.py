@@ -352,6 +352,115 @@ def audio_encoder_features(P, x, prefix="", hidden=256):
     return _layer_norm(y, P[prefix + "output_projection.4.weight"], P[prefix + "output_projection.4.bias"])
 
 
+# --------------------------------------------------------------------------- Stack B
+# complete_project.CompleteDEERModel, eval-mode forward.  Parameter dict keyed by the reference's state_dict names
+# (audio_encoder.*, attention_module.*, fusion_module.*, prediction_heads.<dim>.*, calibration_layer.*).
+def _stackb_encoder(P, x, prefix, layers=3):
+    """EnhancedModalityEncoder -- complete_project.py:76-117: Linear-ReLU-LN, `layers` x (x + LN(ReLU(Lin x))), Linear."""
+    h = _layer_norm(torch.relu(_lin(x, P, prefix + ".input_projection.0")),
+                    P[prefix + ".input_projection.2.weight"], P[prefix + ".input_projection.2.bias"])
+    for i in range(layers):
+        q = f"{prefix}.encoder_layers.{i}.layers"          # ResidualBlock, complete_project.py:60-73
+        h = h + _layer_norm(torch.relu(_lin(h, P, q + ".0")), P[q + ".3.weight"], P[q + ".3.bias"])
+    return _lin(h, P, prefix + ".output_projection")
+
+
+def _stackb_mha(P, prefix, query, key, value, heads=8):
+    """MultiHeadAttention on (B, S, D) tensors -- complete_project.py:120-184 (eval: no dropout, no mask)."""
+    Bq, _, D = query.shape
+    hd = D // heads
+    split = lambda t: t.view(Bq, -1, heads, hd).transpose(1, 2)
+    Q, K, V = split(_lin(query, P, prefix + ".query_proj")), split(_lin(key, P, prefix + ".key_proj")), \
+        split(_lin(value, P, prefix + ".value_proj"))
+    w = torch.softmax(Q @ K.transpose(-2, -1) / math.sqrt(hd), dim=-1)
+    o = (w @ V).transpose(1, 2).contiguous().view(Bq, -1, D)
+    return _lin(o, P, prefix + ".output_proj")
+
+
+def _stackb_uncertainty(P, x, prefix):
+    """UncertaintyEstimator -- complete_project.py:187-213: D -> D/2 -> D/4 -> 1, sigmoid."""
+    h = torch.relu(_lin(x, P, prefix + ".0"))
+    h = torch.relu(_lin(h, P, prefix + ".3"))
+    return torch.sigmoid(_lin(h, P, prefix + ".5"))
+
+
+def stackb_attention(P, audio, video, text, heads=8, prefix="attention_module"):
+    """UncertaintyAwareAttention -- complete_project.py:216-304."""
+    a3, v3, t3 = audio.unsqueeze(1), video.unsqueeze(1), text.unsqueeze(1)
+    ue = prefix + ".uncertainty_estimator.estimator"
+    ua, uv, ut = (_stackb_uncertainty(P, x, ue) for x in (audio, video, text))
+    sa = prefix + ".self_attention"
+    a_self, v_self, t_self = (_stackb_mha(P, sa, x, x, x, heads).squeeze(1) for x in (a3, v3, t3))
+    ca = prefix + ".cross_attention"      # text is the query, the modality itself key and value (:270-273)
+    a_cross, v_cross, t_cross = (_stackb_mha(P, ca, t3, x, x, heads).squeeze(1) for x in (a3, v3, t3))
+    wi = torch.cat([a_self, v_self, t_self, ua, uv, ut], dim=1)
+    wn = prefix + ".weight_network"
+    w = torch.softmax(_lin(torch.relu(_lin(wi, P, wn + ".0")), P, wn + ".3"), dim=1)
+    return {"audio": w[:, 0:1] * a_self + (1 - ua) * a_cross,
+            "video": w[:, 1:2] * v_self + (1 - uv) * v_cross,
+            "text": w[:, 2:3] * t_self + (1 - ut) * t_cross,
+            "attention_weights": w, "modality_uncertainties": torch.cat([ua, uv, ut], dim=1)}
+
+
+def stackb_fusion(P, audio, video, text, prefix="fusion_module"):
+    """HierarchicalFusionModule -- complete_project.py:307-366."""
+    def stage(x, q):   # Linear, ReLU, Dropout, LayerNorm, Linear, ReLU
+        h = _layer_norm(torch.relu(_lin(x, P, q + ".0")), P[q + ".3.weight"], P[q + ".3.bias"])
+        return torch.relu(_lin(h, P, q + ".4"))
+    av = stage(torch.cat([audio, video], dim=1), prefix + ".av_fusion")
+    tri_in = torch.cat([av, text], dim=1)
+    gate = torch.sigmoid(_lin(tri_in, P, prefix + ".fusion_gate.0"))
+    tri = stage(tri_in, prefix + ".trimodal_fusion")
+    return gate * tri + (1 - gate) * av
+
+
+def stackb_head(P, x, prefix):
+    """DEERPredictionHead -- complete_project.py:369-418."""
+    q = prefix + ".evidence_network"
+    e = _lin(torch.relu(_lin(torch.relu(_lin(x, P, q + ".0")), P, q + ".3")), P, q + ".6")
+    mu = e[:, 0]
+    nu = F.softplus(e[:, 1]) + 1e-6
+    alpha = F.softplus(e[:, 2]) + 1.0
+    beta = F.softplus(e[:, 3]) + 1e-6
+    alea = beta / (alpha - 1)
+    epi = beta / (nu * (alpha - 1))
+    return {"mu": mu, "nu": nu, "alpha": alpha, "beta": beta, "aleatoric_uncertainty": alea,
+            "epistemic_uncertainty": epi, "uncertainty": alea + epi}
+
+
+def stackb_calibration(P, unc, prefix="calibration_layer"):
+    """UncertaintyCalibrationLayer -- complete_project.py:421-459: temperature, then a shared 1-32-16-1 MLP per entry."""
+    s = unc / P[prefix + ".temperature"].unsqueeze(0)
+    q = prefix + ".calibration_network"
+    cols = []
+    for i in range(unc.shape[1]):
+        h = torch.relu(_lin(s[:, i:i + 1], P, q + ".0"))
+        h = torch.relu(_lin(h, P, q + ".2"))
+        cols.append(torch.sigmoid(_lin(h, P, q + ".4")))
+    return torch.cat(cols, dim=1)
+
+
+def stackb_forward(P, audio, video, text, heads=8, layers=3):
+    """CompleteDEERModel.forward -- complete_project.py:517-589."""
+    enc = [_stackb_encoder(P, x, n, layers) for x, n in
+           ((audio, "audio_encoder"), (video, "video_encoder"), (text, "text_encoder"))]
+    att = stackb_attention(P, *enc, heads=heads)
+    fused = stackb_fusion(P, att["audio"], att["video"], att["text"])
+    out = {}
+    for d in DIM_NAMES:
+        for k, v in stackb_head(P, fused, f"prediction_heads.{d}").items():
+            out[f"{d}_{k}"] = v
+    out["mu_all"] = torch.stack([out[f"{d}_mu"] for d in DIM_NAMES], dim=1)
+    out["uncertainty_all"] = torch.stack([out[f"{d}_uncertainty"] for d in DIM_NAMES], dim=1)
+    out["calibrated_uncertainty"] = stackb_calibration(P, out["uncertainty_all"])
+    out["attention_weights"] = att["attention_weights"]
+    out["modality_uncertainties"] = att["modality_uncertainties"]
+    out["fused_features"] = fused
+    out["encoded"] = enc
+    out["attended"] = [att["audio"], att["video"], att["text"]]
+    return out
+
+
 # --------------------------------------------------------------------------- metric
 def ccc(x, y):
     """Concordance correlation coefficient, population variance -- metrics.py:85-101."""

@@ -16,6 +16,8 @@ What is captured (SURVEY 8c golden-vector plan):
     NIG parameters incl. extreme pre-activations and empty / single-element ECE bins.
   * side_kernels.npz      -- deer.CrossModalAttention, HierarchicalDEERFusion's three
     encoders, EnhancedAudioEncoder feature branch (eval).
+  * stackb_B9.npz         -- complete_project.CompleteDEERModel, eval-mode forward with
+    closed-form parameters (`python tests/golden/make_golden.py stackb` regenerates only this one).
 """
 import os
 import sys
@@ -176,19 +178,8 @@ def capture_losses():
 
 
 def fill_module(mod, tag):
-    """Closed-form fill of an arbitrary reference module; returns the numpy state."""
-    sd = {}
-    for name, p in mod.state_dict().items():
-        n = p.numel()
-        u = synth.uniform01(synth._stream_of(tag + "." + name), n) * 2.0 - 1.0
-        if p.dim() >= 2:
-            fan_out, fan_in = p.shape[0], p.shape[1]
-            w = u * np.sqrt(6.0 / (fan_in + fan_out))
-        elif name.endswith("weight"):
-            w = 1.0 + 0.1 * u       # LayerNorm gamma
-        else:
-            w = 0.05 * u
-        sd[name] = w.reshape(tuple(p.shape)).astype(np.float32)
+    """Closed-form fill of an arbitrary reference module (synth.module_fill); returns the numpy state."""
+    sd = synth.module_fill(tag, {k: tuple(v.shape) for k, v in mod.state_dict().items()})
     mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return sd
 
@@ -231,7 +222,28 @@ def capture_side():
     return out
 
 
+def capture_stackb():
+    """complete_project.CompleteDEERModel, eval forward."""
+    import json
+    import complete_project as ref_cp  # (reference)
+    model = ref_cp.CompleteDEERModel(ref_cp.ModelConfig()).eval()
+    fill_module(model, "stackb")
+    B = 9
+    batch = synth.make_batch(B, seed=78)
+    with torch.no_grad():
+        o = model(*(torch.from_numpy(batch[k]) for k in ("audio", "video", "text")))
+    out = {"out." + k: tnp(v) for k, v in o.items()}
+    with open(os.path.join(HERE, "stackb_state_dict_names.json"), "w") as fh:
+        json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, fh, indent=0)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "stackb":
+        np.savez_compressed(os.path.join(HERE, "stackb_B9.npz"), **capture_stackb())
+        print("stackb_B9.npz", os.path.getsize(os.path.join(HERE, "stackb_B9.npz")), "bytes")
+        return
+    np.savez_compressed(os.path.join(HERE, "stackb_B9.npz"), **capture_stackb())
     for B in (1, 7, 32):
         np.savez_compressed(os.path.join(HERE, f"stackc_B{B}.npz"), **capture_stackc(B, seed=42))
     miss = {}

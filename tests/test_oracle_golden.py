@@ -213,3 +213,34 @@ def test_ccc_formula():
         xn.var() + yn.var() + (xn.mean() - yn.mean()) ** 2)
     assert O.ccc(x, y) == pytest.approx(ref, rel=1e-12)
     assert O.ccc(x, x) == pytest.approx(1.0)
+
+
+def _stackb_params(golden_dir, dtype=torch.float32):
+    import json
+    with open(os.path.join(golden_dir, "stackb_state_dict_names.json")) as fh:
+        shapes = json.load(fh)
+    return {k: torch.from_numpy(v).to(dtype) for k, v in synth.module_fill("stackb", shapes).items()}
+
+
+def test_stackb_eval_forward(golden_dir):
+    """complete_project.CompleteDEERModel: every output of the reference's eval forward."""
+    g = _load(golden_dir, "stackb_B9.npz")
+    P = _stackb_params(golden_dir)
+    b = synth.make_batch(9, seed=78)
+    with torch.no_grad():
+        o = O.stackb_forward(P, *(torch.from_numpy(b[k]) for k in ("audio", "video", "text")))
+    keys = [k[4:] for k in g if k.startswith("out.")]
+    assert len(keys) == 27
+    for k in keys:
+        np.testing.assert_allclose(o[k].numpy(), g["out." + k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def test_stackb_single_key_attention_is_two_linears(golden_dir):
+    """With one key the softmax is exactly 1, so MultiHeadAttention == output_proj(value_proj(value)) bit for bit --
+    the identity the HIP path of mmdeer.stackb relies on."""
+    P = _stackb_params(golden_dir)
+    x = torch.from_numpy(synth.normal(901, 5 * 256).reshape(5, 1, 256).astype(np.float32))
+    q = torch.from_numpy(synth.normal(902, 5 * 256).reshape(5, 1, 256).astype(np.float32))
+    full = O._stackb_mha(P, "attention_module.cross_attention", q, x, x)
+    short = O._lin(O._lin(x, P, "attention_module.cross_attention.value_proj"), P, "attention_module.cross_attention.output_proj")
+    assert torch.equal(full, short)

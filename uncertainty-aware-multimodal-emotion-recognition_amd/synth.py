@@ -69,6 +69,26 @@ def _stream_of(name: str) -> int:
     return h & 0x3FFFFFFF
 
 
+def module_fill(tag: str, shapes) -> "dict[str, np.ndarray]":
+    """Closed-form fp32 parameters for an arbitrary module, keyed by state_dict name (``shapes``: name -> shape).
+
+    Matrices: Xavier-range uniforms; ``*.weight`` vectors (LayerNorm gamma) and ``*temperature``: 1 + 0.1 u; other
+    vectors (biases): 0.05 u.  ``tests/golden/make_golden.py`` fills the reference modules with exactly this."""
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(int(d) for d in shape)
+        n = int(np.prod(shape))
+        u = uniform01(_stream_of(tag + "." + name), n) * 2.0 - 1.0
+        if len(shape) >= 2:
+            w = u * np.sqrt(6.0 / (shape[0] + shape[1]))
+        elif name.endswith("weight") or name.endswith("temperature"):
+            w = 1.0 + 0.1 * u
+        else:
+            w = 0.05 * u
+        out[name] = w.reshape(shape).astype(np.float32)
+    return out
+
+
 def make_batch(batch: int, seed: int = 42, dims: Dims = DEFAULT_DIMS,
                row_offset: int = 0) -> Dict[str, np.ndarray]:
     """Synthetic (audio, video, text, targets) float32 batch.
