@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 4
+#define MMDEER_ABI_VERSION 5
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -246,6 +246,54 @@ int mmdeer_lstm_cell_t1(const void* gates, int ld_gates, void* out, int ld_out, 
  * the quantile-binned calibration error (metrics.py:214-279). */
 int mmdeer_eval_accumulate(const float* pred, const float* target, const float* unc, double* acc, float* sample_err,
                            float* sample_unc, int B, void* stream);
+
+/* ---- Stack B: complete_project.CompleteDEERModel, eval forward -----------------------------------------
+ * Every Linear(+ReLU) of the model runs on mmdeer_gemm; with a single key the reference's MultiHeadAttention
+ * (complete_project.py:120-184) is output_proj(value_proj(value)) exactly, i.e. two more GEMMs.  The four entry points
+ * below are the remaining row-wise pieces.  Activations ("act") are fp32 when act_f32 != 0, else bf16; parameters and
+ * the listed outputs are fp32.  encoder_dim 256 / fusion_dim 512 (ModelConfig defaults, complete_project.py:33-56).
+ *
+ * out = x + LayerNorm(y) row by row (ResidualBlock, complete_project.py:60-73); x == NULL: plain LayerNorm (the
+ * Linear-ReLU-LayerNorm stems, :84-88, 315-333).  N is 256 or 512; eps 1e-5, biased variance. */
+int mmdeer_stackb_residual_ln(const void* y, int ld_y, const void* x, int ld_x, const float* gamma, const float* beta,
+                              void* out, int ld_out, int M, int N, int act_f32, void* stream);
+
+/* Tail of UncertaintyAwareAttention.forward (complete_project.py:262-304), one call per batch:
+ *   u_m     = sigmoid(est_w3 . h2[3 b + m] + est_b3)                  uncertainty_estimator.estimator.5 + Sigmoid
+ *   hidden  = relu(pre[b] + sum_m u_m * wn_w1_unc[:, m])              the 3 uncertainty columns of weight_network.0
+ *   weights = softmax(wn_w2 hidden + wn_b2)                           weight_network.3 + Softmax(dim=1)
+ *   final_m = weights_m * self_out[b, m] + (1 - u_m) * cross_out[b, m]
+ * audio / video land in columns 0..255 / 256..511 of out_av (the av_fusion input), text in columns 0..255 of out_text. */
+typedef struct mmdeer_stackb_attn_args {
+  const void* h2;            /* act [3B][64]: estimator hidden layer 2 of the interleaved (b, modality) rows */
+  const void* pre;           /* act [B][256]: weight_network.0 over the 768 self-attention columns + bias, no ReLU */
+  const void* self_out;      /* act [B][768] */
+  const void* cross_out;     /* act [B][768] */
+  const float* est_w3;       /* [64] */
+  const float* est_b3;       /* [1] */
+  const float* wn_w1_unc;    /* &weight_network.0.weight[0][768]; rows ld_w1_unc apart (771 in the reference layout) */
+  const float* wn_w2;        /* [3][256] */
+  const float* wn_b2;        /* [3] */
+  void* out_av;              /* act, row stride ld_av >= 512 */
+  void* out_text;            /* act, row stride ld_text >= 256 */
+  float* weights;            /* [B][3]  'attention_weights' */
+  float* uncertainties;      /* [B][3]  'modality_uncertainties' */
+  int32_t ld_w1_unc, ld_av, ld_text, B, act_f32;
+  void* stream;
+} mmdeer_stackb_attn_args;
+int mmdeer_stackb_attn_mix(const mmdeer_stackb_attn_args* a);
+
+/* HierarchicalFusionModule's gated combination (complete_project.py:360-364):
+ * out = sigmoid(gate_logits) * tri + (1 - sigmoid(gate_logits)) * av, [B][N] act matrices with their own row strides. */
+int mmdeer_stackb_gate_mix(const void* gate_logits, int ld_g, const void* tri, int ld_t, const void* av, int ld_av, void* out,
+                           int ld_out, int B, int N, int act_f32, void* stream);
+
+/* DEERPredictionHead constraints + uncertainties (complete_project.py:395-418) and UncertaintyCalibrationLayer
+ * (:421-459).  ev: fp32 [B][ld_ev], the raw (mu, nu, alpha, beta) outputs of head d at columns 4 d .. 4 d + 3.
+ * out: eight fp32 [B][3] planes -- mu, nu, alpha, beta, aleatoric, epistemic, total, calibrated.
+ * temperature [3]; calibration_network: w1 [32], b1 [32], w2 [16][32], b2 [16], w3 [16], b3 [1]. */
+int mmdeer_stackb_head(const float* ev, int ld_ev, const float* temperature, const float* w1, const float* b1, const float* w2,
+                       const float* b2, const float* w3, const float* b3, float* out, int B, void* stream);
 
 /* fp32 <-> bf16 conversion of a contiguous device buffer (n % 4 == 0) */
 int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream);

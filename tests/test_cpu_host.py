@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/mmdeer.h but not exported"
     bound = {n for n, _, _ in _lib.SYMBOLS}
     assert bound == set(declared), (bound ^ set(declared))
-    assert lib.mmdeer_abi_version() == 4
+    assert lib.mmdeer_abi_version() == 5
     assert b"gfx950" in lib.mmdeer_version()
 
 
@@ -154,3 +154,22 @@ def test_fused_adamw_argument_checks_without_a_gpu():
     sd = opt.state_dict()
     assert sd["step"] == 0 and sd["exp_avg"] is None
     del sched
+
+
+def test_stackb_state_dict_matches_the_reference_names():
+    """mmdeer.stackb.CompleteDEERModel exposes complete_project.CompleteDEERModel's state_dict keys and shapes
+    (captured by tests/golden/make_golden.py), Xavier/zero/one initialisation, and has no CPU compute path."""
+    import json
+    import torch
+    from mmdeer import stackb
+    with open(os.path.join(os.path.dirname(__file__), "golden", "stackb_state_dict_names.json")) as fh:
+        shapes = json.load(fh)
+    m = stackb.create_complete_deer_model()
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == shapes
+    sd = m.state_dict()
+    assert float(sd["calibration_layer.temperature"].sum()) == 3.0
+    assert float(sd["audio_encoder.input_projection.0.bias"].abs().sum()) == 0.0
+    w = sd["fusion_module.av_fusion.0.weight"]
+    assert float(w.abs().max()) <= (6.0 / (512 + 512)) ** 0.5 + 1e-6 and float(w.std()) > 0.02
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.eval()(torch.zeros(2, 84), torch.zeros(2, 256), torch.zeros(2, 768))

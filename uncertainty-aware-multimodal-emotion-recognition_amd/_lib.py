@@ -82,6 +82,16 @@ class GemmArgs(C.Structure):
     ]
 
 
+class StackBAttnArgs(C.Structure):
+    _fields_ = [
+        ("h2", c_void_p), ("pre", c_void_p), ("self_out", c_void_p), ("cross_out", c_void_p),
+        ("est_w3", c_void_p), ("est_b3", c_void_p), ("wn_w1_unc", c_void_p), ("wn_w2", c_void_p), ("wn_b2", c_void_p),
+        ("out_av", c_void_p), ("out_text", c_void_p), ("weights", c_void_p), ("uncertainties", c_void_p),
+        ("ld_w1_unc", c_int), ("ld_av", c_int), ("ld_text", c_int), ("B", c_int), ("act_f32", c_int),
+        ("stream", c_void_p),
+    ]
+
+
 # every symbol include/mmdeer.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mmdeer_version", C.c_char_p, []),
@@ -111,6 +121,10 @@ SYMBOLS = [
     ("mmdeer_cross_modal_attn_fwd", c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     ("mmdeer_lstm_cell_t1", c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_eval_accumulate", c_int, [c_void_p] * 6 + [c_int, c_void_p]),
+    ("mmdeer_stackb_residual_ln", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("mmdeer_stackb_attn_mix", c_int, [C.POINTER(StackBAttnArgs)]),
+    ("mmdeer_stackb_gate_mix", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("mmdeer_stackb_head", c_int, [c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
     ("mmdeer_convert", c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p]),
 ]
 
@@ -144,7 +158,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 4:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 5:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         _LIB = lib
     return _LIB

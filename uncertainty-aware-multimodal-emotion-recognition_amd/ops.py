@@ -67,6 +67,59 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+def linear_into(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
+                relu: bool = False, compute: str = "fp32") -> torch.Tensor:
+    """``out = relu?(x @ weight.T + bias)`` on ``mmdeer_gemm`` with no copies: ``x`` / ``weight`` / ``out`` are 2-D
+    views with unit inner stride (column blocks of wider buffers are fine); ``x`` and ``weight`` already have the
+    compute dtype, ``out`` is the compute dtype or fp32."""
+    _check_dev(x, weight, bias, out)
+    dt = _act_dtype(compute)
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or out.shape != (M, N):
+        raise ValueError(f"linear_into: shapes {tuple(x.shape)} x {tuple(weight.shape)} -> {tuple(out.shape)} do not match")
+    if x.dtype != dt or weight.dtype != dt or out.dtype not in (dt, torch.float32):
+        raise ValueError("linear_into: operands must have the compute dtype (out: compute dtype or fp32)")
+    if x.stride(1) != 1 or weight.stride(1) != 1 or out.stride(1) != 1 or N % 4 or K % 4:
+        raise ValueError("linear_into: unit inner strides and N, K multiples of 4 are required")
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        raise ValueError("linear_into: bias must be contiguous fp32")
+    if M == 0:
+        return out
+    a = _lib.GemmArgs()
+    a.A, a.W, a.C = x.data_ptr(), weight.data_ptr(), out.data_ptr()
+    a.bias = _lib.ptr(bias)
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldw, a.ldc = x.stride(0), weight.stride(0), out.stride(0)
+    f32 = int(dt == torch.float32)
+    a.a_f32 = a.w_f32 = a.compute_f32 = f32
+    a.c_f32 = int(out.dtype == torch.float32)
+    a.relu = int(relu)
+    a.tile = -1
+    a.drop_site = a.regen_site = -1
+    a.mask_scale = 1.0
+    a.stream = _lib.current_stream()
+    _lib.check(_lib.load().mmdeer_gemm(C.byref(a)))
+    return out
+
+
+def residual_layer_norm(y: torch.Tensor, x: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                        out: torch.Tensor) -> torch.Tensor:
+    """``out = x + LayerNorm(y)`` (``x`` None: plain LayerNorm) on ``mmdeer_stackb_residual_ln``; 2-D views of one
+    activation dtype, N in (256, 512).  ``out`` may alias ``x``."""
+    _check_dev(y, x, gamma, beta, out)
+    M, N = y.shape
+    for t in (x, out):
+        if t is not None and (t.shape != (M, N) or t.dtype != y.dtype or t.stride(1) != 1):
+            raise ValueError("residual_layer_norm: operands must share shape and dtype and have unit inner stride")
+    if y.stride(1) != 1 or y.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("residual_layer_norm: y must be fp32 or bf16 with unit inner stride")
+    _lib.check(_lib.load().mmdeer_stackb_residual_ln(
+        y.data_ptr(), y.stride(0), _lib.ptr(x), x.stride(0) if x is not None else 0, gamma.data_ptr(), beta.data_ptr(),
+        out.data_ptr(), out.stride(0), M, N, int(y.dtype == torch.float32), _lib.current_stream()))
+    return out
+
+
 def layer_norm(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
     """nn.LayerNorm(N) (eps 1e-5, biased variance) on ``mmdeer_layernorm_fwd``; returns fp32 (M, N)."""
     _check_dev(y, gamma, beta)
