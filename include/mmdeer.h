@@ -249,8 +249,8 @@ int mmdeer_eval_accumulate(const float* pred, const float* target, const float* 
 
 /* ---- Stack B: complete_project.CompleteDEERModel, eval forward -----------------------------------------
  * Every Linear(+ReLU) of the model runs on mmdeer_gemm; with a single key the reference's MultiHeadAttention
- * (complete_project.py:120-184) is output_proj(value_proj(value)) exactly, i.e. two more GEMMs.  The four entry points
- * below are the remaining row-wise pieces.  Activations ("act") are fp32 when act_f32 != 0, else bf16; parameters and
+ * (complete_project.py:120-184) is output_proj(value_proj(value)) exactly, i.e. two more GEMMs.  The four single
+ * operators below are the remaining row-wise pieces; mmdeer_stackb_forward (further down) strings everything together.  Activations ("act") are fp32 when act_f32 != 0, else bf16; parameters and
  * the listed outputs are fp32.  encoder_dim 256 / fusion_dim 512 (ModelConfig defaults, complete_project.py:33-56).
  *
  * out = x + LayerNorm(y) row by row (ResidualBlock, complete_project.py:60-73); x == NULL: plain LayerNorm (the
@@ -284,9 +284,10 @@ typedef struct mmdeer_stackb_attn_args {
 int mmdeer_stackb_attn_mix(const mmdeer_stackb_attn_args* a);
 
 /* HierarchicalFusionModule's gated combination (complete_project.py:360-364):
- * out = sigmoid(gate_logits) * tri + (1 - sigmoid(gate_logits)) * av, [B][N] act matrices with their own row strides. */
+ * out = sigmoid(gate_logits) * tri + (1 - sigmoid(gate_logits)) * av, [B][N] act matrices with their own row strides;
+ * out32 (optional): a dense fp32 [B][N] copy for the caller ('fused_features'). */
 int mmdeer_stackb_gate_mix(const void* gate_logits, int ld_g, const void* tri, int ld_t, const void* av, int ld_av, void* out,
-                           int ld_out, int B, int N, int act_f32, void* stream);
+                           int ld_out, float* out32, int B, int N, int act_f32, void* stream);
 
 /* DEERPredictionHead constraints + uncertainties (complete_project.py:395-418) and UncertaintyCalibrationLayer
  * (:421-459).  ev: fp32 [B][ld_ev], the raw (mu, nu, alpha, beta) outputs of head d at columns 4 d .. 4 d + 3.
@@ -294,6 +295,60 @@ int mmdeer_stackb_gate_mix(const void* gate_logits, int ld_g, const void* tri, i
  * temperature [3]; calibration_network: w1 [32], b1 [32], w2 [16][32], b2 [16], w3 [16], b3 [1]. */
 int mmdeer_stackb_head(const float* ev, int ld_ev, const float* temperature, const float* w1, const float* b1, const float* w2,
                        const float* b2, const float* w3, const float* b3, float* out, int B, void* stream);
+
+/* The whole eval forward as ONE call: 25 launches per batch (26 in bf16 mode), the three encoders / the layers that
+ * share an input side by side in grouped GEMM launches.  `mmdeer_stackb_weights` is the device-side operand image the
+ * host builds once per parameter update from the reference's state_dict (mmdeer/stackb.py does it): matrices ("W") in
+ * the compute dtype (fp32 when compute_f32 != 0, else bf16), row-major [out][in] as nn.Linear stores them, stacked
+ * where layers run in one launch; vectors fp32. */
+typedef struct mmdeer_stackb_weights {
+  int32_t audio_dim, video_dim, text_dim;   /* ModelConfig input widths, multiples of 4 */
+  int32_t encoder_layers;                   /* ResidualBlocks per encoder */
+  int32_t audio_ld;             /* row stride of enc_in_w[0]: audio_dim in fp32; bf16: a multiple of 64, columns >= audio_dim zero */
+  const void* enc_in_w[3];      /* W [256][audio_ld | video_dim | text_dim]      <m>_encoder.input_projection.0.weight */
+  const float* enc_in_vec;      /* [3][3][256]  per modality: .0.bias, .2.weight, .2.bias */
+  const void* enc_res_w;        /* W [layers][3][256][256]                       encoder_layers.<l>.layers.0.weight per modality */
+  const float* enc_res_vec;     /* [layers][3][3][256]  per layer and modality: layers.0.bias, layers.3.weight, layers.3.bias */
+  const void* enc_out_w;        /* W [3][256][256]                               output_projection.weight */
+  const float* enc_out_b;       /* [3][256] */
+  const void* value_w;          /* W [512][256]  self_attention.value_proj over cross_attention.value_proj */
+  const float* value_b;         /* [512] */
+  const void* attn_out_w;       /* W [2][256][256]  self / cross output_proj */
+  const float* attn_out_b;      /* [2][256] */
+  const void* est_w1;  const float* est_b1;   /* W [128][256]   uncertainty_estimator.estimator.0 */
+  const void* est_w2;  const float* est_b2;   /* W [64][128]    .3 */
+  const float* est_w3; const float* est_b3;   /* [64], [1]      .5 */
+  const void* wn_w1;   const float* wn_b1;    /* W [256][768]: the feature columns of weight_network.0.weight */
+  const float* wn_w1_unc;                     /* [256][3]: its three uncertainty columns */
+  const float* wn_w2;  const float* wn_b2;    /* [3][256], [3]  weight_network.3 */
+  const void* av_w0;   const void* av_w4;     /* W [512][512] each  fusion_module.av_fusion.0 / .4 */
+  const float* av_vec;                        /* [4][512]: .0.bias, .3.weight, .3.bias, .4.bias */
+  const void* tri_w0;  const void* tri_w4;    /* W [512][768], [512][512]  trimodal_fusion.0 / .4 */
+  const float* tri_vec;                       /* [4][512] */
+  const void* gate_w;  const float* gate_b;   /* W [512][768], [512]  fusion_gate.0 */
+  const void* head_w0; const float* head_b0;  /* W [768][512], [768]: evidence_network.0 of valence, arousal, dominance stacked */
+  const void* head_w3; const float* head_b3;  /* W [3][128][256], [3][128] */
+  const void* head_w6; const float* head_b6;  /* W [3][4][128],  [3][4] */
+  const float* calibration[7];                /* temperature [3]; calibration_network w1 [32], b1 [32], w2 [16][32], b2 [16], w3 [16], b3 [1] */
+} mmdeer_stackb_weights;
+
+typedef struct mmdeer_stackb_forward_args {
+  int32_t batch;
+  int32_t compute_f32;            /* 1: exact-fp32 MFMA path; 0: bf16 operands, fp32 accumulation */
+  const float* audio;             /* [B][audio_dim] fp32, dense */
+  const float* video;             /* [B][video_dim] */
+  const float* text;              /* [B][text_dim] */
+  const mmdeer_stackb_weights* weights;
+  void* workspace;                /* >= mmdeer_stackb_workspace_bytes(batch, compute_f32, audio_ld), 256-byte aligned */
+  size_t workspace_bytes;
+  float* planes;                  /* [8][B][3]: mu, nu, alpha, beta, aleatoric, epistemic, total, calibrated */
+  float* attention_weights;       /* [B][3] */
+  float* modality_uncertainties;  /* [B][3] */
+  float* fused_features;          /* [B][512] or NULL */
+  void* stream;
+} mmdeer_stackb_forward_args;
+size_t mmdeer_stackb_workspace_bytes(int batch, int compute_f32, int audio_ld);
+int mmdeer_stackb_forward(const mmdeer_stackb_forward_args* a);
 
 /* fp32 <-> bf16 conversion of a contiguous device buffer (n % 4 == 0) */
 int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream);

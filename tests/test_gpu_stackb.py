@@ -84,6 +84,42 @@ def test_stackb_missing_modality_and_empty_batch():
     assert out["mu_all"].shape == (0, 3) and out["fused_features"].shape == (0, 512) and out["valence_mu"].shape == (0,)
 
 
+def test_stackb_other_encoder_depths_and_input_widths():
+    """encoder_layers and the input widths are ModelConfig fields (complete_project.py:33-56), not constants."""
+    O = _oracle()
+    for layers, dims, compute, tol in ((1, (40, 64, 128), "fp32", dict(rtol=3e-4, atol=3e-5)), (0, (84, 256, 768), "fp32", dict(rtol=3e-4, atol=3e-5)),
+                                       (4, (200, 256, 768), "bf16", dict(rtol=0.08, atol=0.06))):
+        cfg = stackb.ModelConfig(audio_dim=dims[0], video_dim=dims[1], text_dim=dims[2], encoder_layers=layers)
+        m = stackb.CompleteDEERModel(cfg, compute_dtype=compute)
+        P = {k: torch.from_numpy(v) for k, v in synth.module_fill(f"stackb.l{layers}", {k: tuple(v.shape) for k, v in m.state_dict().items()}).items()}
+        m.load_state_dict(P)
+        m = m.to("cuda:0").eval()
+        xs = [torch.from_numpy(synth.normal(700 + i, 37 * d).reshape(37, d).astype(np.float32)) for i, d in enumerate(dims)]
+        out = m(*(x.cuda() for x in xs))
+        with torch.no_grad():
+            ref = O.stackb_forward(P, *xs, layers=layers)
+        for k in TENSOR_KEYS:
+            np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), err_msg=f"layers={layers} {k}", **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N", [256, 512])
+def test_residual_layer_norm_operator(dtype, N):
+    from mmdeer import ops
+    M = 133
+    y = torch.from_numpy(synth.normal(810, M * N).reshape(M, N).astype(np.float32)).cuda().to(dtype)
+    x = torch.from_numpy(synth.normal(811, M * 2 * N).reshape(M, 2 * N).astype(np.float32)).cuda().to(dtype)[:, N:]   # a column block
+    g = torch.from_numpy((1 + 0.1 * synth.normal(812, N)).astype(np.float32)).cuda()
+    b = torch.from_numpy((0.1 * synth.normal(813, N)).astype(np.float32)).cuda()
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-2)
+    for res in (None, x):
+        out = ops.residual_layer_norm(y, res, g, b, torch.empty(M, N, dtype=dtype, device="cuda:0"))
+        ref = torch.nn.functional.layer_norm(y.float(), (N,), g, b, 1e-5) + (res.float() if res is not None else 0)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), **tol)
+    with pytest.raises(RuntimeError, match="256 or 512"):
+        ops.residual_layer_norm(y[:, :128], None, g, b, torch.empty(M, 128, dtype=dtype, device="cuda:0"))
+
+
 def test_stackb_interface():
     m, _ = _model("fp32")
     assert {k: list(v.shape) for k, v in m.state_dict().items()} == _shapes()

@@ -92,6 +92,33 @@ class StackBAttnArgs(C.Structure):
     ]
 
 
+class StackBWeights(C.Structure):
+    _fields_ = [
+        ("audio_dim", c_int), ("video_dim", c_int), ("text_dim", c_int), ("encoder_layers", c_int), ("audio_ld", c_int),
+        ("enc_in_w", c_void_p * 3), ("enc_in_vec", c_void_p), ("enc_res_w", c_void_p), ("enc_res_vec", c_void_p),
+        ("enc_out_w", c_void_p), ("enc_out_b", c_void_p), ("value_w", c_void_p), ("value_b", c_void_p),
+        ("attn_out_w", c_void_p), ("attn_out_b", c_void_p),
+        ("est_w1", c_void_p), ("est_b1", c_void_p), ("est_w2", c_void_p), ("est_b2", c_void_p), ("est_w3", c_void_p), ("est_b3", c_void_p),
+        ("wn_w1", c_void_p), ("wn_b1", c_void_p), ("wn_w1_unc", c_void_p), ("wn_w2", c_void_p), ("wn_b2", c_void_p),
+        ("av_w0", c_void_p), ("av_w4", c_void_p), ("av_vec", c_void_p),
+        ("tri_w0", c_void_p), ("tri_w4", c_void_p), ("tri_vec", c_void_p),
+        ("gate_w", c_void_p), ("gate_b", c_void_p),
+        ("head_w0", c_void_p), ("head_b0", c_void_p), ("head_w3", c_void_p), ("head_b3", c_void_p), ("head_w6", c_void_p), ("head_b6", c_void_p),
+        ("calibration", c_void_p * 7),
+    ]
+
+
+class StackBForwardArgs(C.Structure):
+    _fields_ = [
+        ("batch", c_int), ("compute_f32", c_int),
+        ("audio", c_void_p), ("video", c_void_p), ("text", c_void_p),
+        ("weights", C.POINTER(StackBWeights)),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("planes", c_void_p), ("attention_weights", c_void_p), ("modality_uncertainties", c_void_p), ("fused_features", c_void_p),
+        ("stream", c_void_p),
+    ]
+
+
 # every symbol include/mmdeer.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mmdeer_version", C.c_char_p, []),
@@ -123,8 +150,10 @@ SYMBOLS = [
     ("mmdeer_eval_accumulate", c_int, [c_void_p] * 6 + [c_int, c_void_p]),
     ("mmdeer_stackb_residual_ln", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_stackb_attn_mix", c_int, [C.POINTER(StackBAttnArgs)]),
-    ("mmdeer_stackb_gate_mix", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("mmdeer_stackb_gate_mix", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_stackb_head", c_int, [c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
+    ("mmdeer_stackb_workspace_bytes", c_size_t, [c_int, c_int, c_int]),
+    ("mmdeer_stackb_forward", c_int, [C.POINTER(StackBForwardArgs)]),
     ("mmdeer_convert", c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p]),
 ]
 

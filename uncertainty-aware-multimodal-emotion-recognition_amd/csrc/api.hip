@@ -191,6 +191,9 @@ SideCtx* get_side_ctx() {
   return &c;
 }
 
+}  // namespace
+
+namespace {
 int forced_tile() {
   static int v = -2;
   if (v == -2) {
@@ -200,7 +203,10 @@ int forced_tile() {
   return v;
 }
 
+}  // namespace
+
 // smallest tile that still gives the chip >= ~2 workgroups per CU; otherwise the largest tile count wins
+// (declared in gemm.h: the Stack B executor in stackb.hip uses the same policy)
 GemmTile pick_tile(const GemmGroup& g) {
   const int ft = forced_tile();
   if (ft >= 0 && ft <= 3) return (GemmTile)ft;
@@ -238,6 +244,8 @@ GemmTile pick_tile(const GemmGroup& g) {
   if (tiles[1] >= t128) return TILE_128x64;
   return TILE_64x64;
 }
+
+namespace {
 
 // Builder for the executor's GEMM problems.  `es` = bytes of one activation element.
 struct Exec {

@@ -63,6 +63,9 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t 
 
 void gemm_problem_defaults(GemmProblem& p);
 
+// tile policy of the executors (api.hip): the MMDEER_TILE override, else by tile count and operand layout
+GemmTile pick_tile(const GemmGroup& g);
+
 // K-tile count of a problem for the given compute dtype (64 bf16 / 32 fp32 elements of K per tile)
 inline int gemm_ktiles(int K, int compute_f32) { const int kt = compute_f32 ? 32 : 64; return (K + kt - 1) / kt; }
 

@@ -3,10 +3,10 @@
 Same constructor protocol (``ModelConfig``), ``state_dict()`` keys and shapes, output dictionary and
 ``get_predictions_and_uncertainties`` as the reference class (complete_project.py:33-56, 462-602), so a reference
 checkpoint loads with ``load_state_dict`` and callers of ``model(audio, video, text)`` keep working.  The arithmetic
-runs on the HIP library only -- 33 ``mmdeer_gemm`` launches and the four ``mmdeer_stackb_*`` row kernels per batch;
-there is no CPU path.
+runs on the HIP library only -- one ``mmdeer_stackb_forward`` call per batch (25 kernel launches: grouped GEMMs plus
+the four ``mmdeer_stackb_*`` row kernels); there is no CPU path.
 
-How the batch is laid out (one allocation per intermediate, all row-major in HBM):
+How the batch is laid out (csrc/stackb.hip carves the intermediates out of one workspace, all row-major in HBM):
   * the three encoders write their (B, 256) outputs into column blocks of one (B, 768) matrix, which read as
     (3B, 256) is the (sample, modality)-interleaved row set that the shared-weight layers -- both attention blocks and
     the uncertainty estimator -- consume in a single GEMM each;
@@ -15,7 +15,9 @@ How the batch is laid out (one allocation per intermediate, all row-major in HBM
     (3B, 256) self-attention output read as (B, 768) is already ``cat([audio_self, video_self, text_self])``;
   * ``weight_network.0`` has K = 771: its 768 feature columns run as a GEMM, the three uncertainty columns are added
     in ``mmdeer_stackb_attn_mix`` together with the ReLU, the 256 -> 3 layer, the softmax and the final mix;
-  * the first layer of the three prediction heads is one N = 768 GEMM.
+  * the three encoders advance side by side: every encoder layer is one grouped / batched GEMM launch over the
+    modality-major (3, B, 256) hidden state plus one residual-LayerNorm launch;
+  * the first layer of the three prediction heads is one N = 768 GEMM, the other two are batched over the heads.
 
 Training (dropout, backward) is not built for this stack: the reference trains Stack C, which is the path
 ``mmdeer.model.MultimodalDEER`` accelerates end to end.  ``forward`` raises in training mode instead of silently
@@ -151,46 +153,66 @@ class CompleteDEERModel(nn.Module):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
 
-    # ---- device-side operand images (compute dtype, fused where layers share an input), rebuilt when a parameter changes
+    # ---- device-side operand image (include/mmdeer.h: mmdeer_stackb_weights), rebuilt when a parameter changes
     def _pack(self) -> dict:
         key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.compute_dtype,)
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
+        cfg = self.config
         dt = ops._act_dtype(self.compute_dtype)
-        w = lambda lin: lin.weight.detach().to(dt).contiguous()
-        b = lambda lin: lin.bias.detach().float().contiguous()
-        f32 = lambda t: t.detach().float().contiguous()
-        P = {"key": key, "enc": []}
-        for enc in (self.audio_encoder, self.video_encoder, self.text_encoder):
-            ip = enc.input_projection
-            P["enc"].append({
-                "in": (w(ip[0]), b(ip[0]), f32(ip[2].weight), f32(ip[2].bias)),
-                "res": [(w(r.layers[0]), b(r.layers[0]), f32(r.layers[3].weight), f32(r.layers[3].bias)) for r in enc.encoder_layers],
-                "out": (w(enc.output_projection), b(enc.output_projection))})
+        W = lambda *ts: (torch.stack([t.detach() for t in ts]) if len(ts) > 1 else ts[0].detach()).to(dt).contiguous()
+        V = lambda *ts: torch.stack([t.detach().float().reshape(-1) for t in ts]).contiguous()
+        encs = (self.audio_encoder, self.video_encoder, self.text_encoder)
+        keep = {}          # name -> tensor: keeps every image alive while the struct points at it
+        sw = _lib.StackBWeights()
+        sw.audio_dim, sw.video_dim, sw.text_dim, sw.encoder_layers = cfg.audio_dim, cfg.video_dim, cfg.text_dim, cfg.encoder_layers
+        # bf16: 84-wide rows are not 16-byte aligned -> the audio weight image is zero-padded to 128 columns
+        sw.audio_ld = cfg.audio_dim if dt == torch.float32 else (cfg.audio_dim + 127) // 128 * 128
+        for m, enc in enumerate(encs):
+            w = enc.input_projection[0].weight.detach()
+            if m == 0 and sw.audio_ld != cfg.audio_dim:
+                w = torch.nn.functional.pad(w, (0, sw.audio_ld - cfg.audio_dim))
+            keep[f"enc_in_w{m}"] = w.to(dt).contiguous()
+            sw.enc_in_w[m] = keep[f"enc_in_w{m}"].data_ptr()
+        keep["enc_in_vec"] = V(*[t for e in encs for t in (e.input_projection[0].bias, e.input_projection[2].weight, e.input_projection[2].bias)])
+        L = cfg.encoder_layers
+        if L:
+            keep["enc_res_w"] = W(*[e.encoder_layers[l].layers[0].weight for l in range(L) for e in encs])
+            keep["enc_res_vec"] = V(*[t for l in range(L) for e in encs
+                                      for t in (e.encoder_layers[l].layers[0].bias, e.encoder_layers[l].layers[3].weight, e.encoder_layers[l].layers[3].bias)])
+        keep["enc_out_w"] = W(*[e.output_projection.weight for e in encs])
+        keep["enc_out_b"] = V(*[e.output_projection.bias for e in encs])
         att = self.attention_module
         sa, ca = att.self_attention, att.cross_attention
-        P["value"] = (torch.cat([w(sa.value_proj), w(ca.value_proj)], 0).contiguous(), torch.cat([b(sa.value_proj), b(ca.value_proj)]))
-        P["self_out"], P["cross_out"] = (w(sa.output_proj), b(sa.output_proj)), (w(ca.output_proj), b(ca.output_proj))
+        keep["value_w"], keep["value_b"] = W(sa.value_proj.weight, ca.value_proj.weight), V(sa.value_proj.bias, ca.value_proj.bias)
+        keep["attn_out_w"], keep["attn_out_b"] = W(sa.output_proj.weight, ca.output_proj.weight), V(sa.output_proj.bias, ca.output_proj.bias)
         est = att.uncertainty_estimator.estimator
-        P["est"] = ((w(est[0]), b(est[0])), (w(est[3]), b(est[3])), f32(est[5].weight).view(-1), f32(est[5].bias))
-        wn = att.weight_network
-        D3 = 3 * self.config.encoder_dim
-        P["wn"] = (wn[0].weight.detach()[:, :D3].to(dt).contiguous(), b(wn[0]), wn[0].weight.detach()[:, D3:].float().contiguous(),
-                   f32(wn[3].weight), f32(wn[3].bias))
+        keep["est_w1"], keep["est_b1"] = W(est[0].weight), V(est[0].bias)
+        keep["est_w2"], keep["est_b2"] = W(est[3].weight), V(est[3].bias)
+        keep["est_w3"], keep["est_b3"] = V(est[5].weight), V(est[5].bias)
+        wn, D3 = att.weight_network, 3 * cfg.encoder_dim
+        keep["wn_w1"], keep["wn_b1"] = W(wn[0].weight[:, :D3]), V(wn[0].bias)
+        keep["wn_w1_unc"] = wn[0].weight.detach()[:, D3:].float().contiguous()
+        keep["wn_w2"], keep["wn_b2"] = wn[3].weight.detach().float().contiguous(), V(wn[3].bias)
         fu = self.fusion_module
         for name, seq in (("av", fu.av_fusion), ("tri", fu.trimodal_fusion)):
-            P[name] = ((w(seq[0]), b(seq[0])), (f32(seq[3].weight), f32(seq[3].bias)), (w(seq[4]), b(seq[4])))
-        P["gate"] = (w(fu.fusion_gate[0]), b(fu.fusion_gate[0]))
+            keep[name + "_w0"], keep[name + "_w4"] = W(seq[0].weight), W(seq[4].weight)
+            keep[name + "_vec"] = V(seq[0].bias, seq[3].weight, seq[3].bias, seq[4].bias)
+        keep["gate_w"], keep["gate_b"] = W(fu.fusion_gate[0].weight), V(fu.fusion_gate[0].bias)
         nets = [self.prediction_heads[n].evidence_network for n in DIM_NAMES]
-        P["head0"] = (torch.cat([w(n[0]) for n in nets], 0).contiguous(), torch.cat([b(n[0]) for n in nets]))
-        P["head3"] = [(w(n[3]), b(n[3])) for n in nets]
-        P["head6"] = [(w(n[6]), b(n[6])) for n in nets]
+        for k in (0, 3, 6):
+            keep[f"head_w{k}"], keep[f"head_b{k}"] = W(*[n[k].weight for n in nets]), V(*[n[k].bias for n in nets])
         cal = self.calibration_layer
         cn = cal.calibration_network
-        P["cal"] = (f32(cal.temperature), f32(cn[0].weight).view(-1), f32(cn[0].bias), f32(cn[2].weight), f32(cn[2].bias),
-                    f32(cn[4].weight).view(-1), f32(cn[4].bias))
-        self._packed = P
-        return P
+        keep["cal"] = [t.detach().float().reshape(-1).contiguous() for t in
+                       (cal.temperature, cn[0].weight, cn[0].bias, cn[2].weight, cn[2].bias, cn[4].weight, cn[4].bias)]
+        for name, _ in _lib.StackBWeights._fields_:
+            if name in keep and name != "cal":
+                setattr(sw, name, keep[name].data_ptr())
+        for i, t in enumerate(keep["cal"]):
+            sw.calibration[i] = t.data_ptr()
+        self._packed = {"key": key, "keep": keep, "struct": sw}
+        return self._packed
 
     @torch.no_grad()
     def forward(self, audio_features: torch.Tensor, video_features: torch.Tensor, text_features: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -204,69 +226,25 @@ class CompleteDEERModel(nn.Module):
         for x, k in zip(xs, (cfg.audio_dim, cfg.video_dim, cfg.text_dim)):
             if x.dim() != 2 or x.shape != (B, k):
                 raise ValueError(f"expected features of shape ({B}, {k}), got {tuple(x.shape)}")
-        c, dt = self.compute_dtype, ops._act_dtype(self.compute_dtype)
+        xs = [x.detach().float().contiguous() for x in xs]
         dev = xs[0].device
         P = self._pack()
         lib = _lib.load()
-        stream = _lib.current_stream()
-        new = lambda *s, dtype=dt: torch.empty(*s, dtype=dtype, device=dev)
-        D, Fd = cfg.encoder_dim, cfg.fusion_dim
-
-        # -- encoders (complete_project.py:76-117) -> column blocks of E
-        E = new(B, 3 * D)
-        tmp, h = new(B, D), new(B, D)
-        for m, (x, pe) in enumerate(zip(xs, P["enc"])):
-            wi, bi, g, be = pe["in"]
-            ops.linear_into(x.detach().to(dt).contiguous(), wi, bi, tmp, relu=True, compute=c)
-            ops.residual_layer_norm(tmp, None, g, be, h)
-            for wr, br, g, be in pe["res"]:
-                ops.linear_into(h, wr, br, tmp, relu=True, compute=c)
-                ops.residual_layer_norm(tmp, h, g, be, h)
-            ops.linear_into(h, pe["out"][0], pe["out"][1], E[:, m * D:(m + 1) * D], compute=c)
-        E3 = E.view(3 * B, D)
-
-        # -- UncertaintyAwareAttention (complete_project.py:216-304) on the interleaved rows
-        VV = ops.linear_into(E3, *P["value"], new(3 * B, 2 * D), compute=c)
-        S = ops.linear_into(VV[:, :D], *P["self_out"], new(3 * B, D), compute=c)
-        X = ops.linear_into(VV[:, D:], *P["cross_out"], new(3 * B, D), compute=c)
-        (w1, b1), (w2, b2), w3, b3 = P["est"]
-        H2 = ops.linear_into(ops.linear_into(E3, w1, b1, new(3 * B, D // 2), relu=True, compute=c), w2, b2, new(3 * B, D // 4),
-                             relu=True, compute=c)
-        wn_f, wn_b, wn_u, wn_w2, wn_b2 = P["wn"]
-        pre = ops.linear_into(S.view(B, 3 * D), wn_f, wn_b, new(B, D), compute=c)
-        AV, T = new(B, 2 * D), new(B, Fd + D)
-        weights, unc = new(B, 3, dtype=torch.float32), new(B, 3, dtype=torch.float32)
-        a = _lib.StackBAttnArgs()
-        a.h2, a.pre, a.self_out, a.cross_out = H2.data_ptr(), pre.data_ptr(), S.data_ptr(), X.data_ptr()
-        a.est_w3, a.est_b3, a.wn_w1_unc, a.wn_w2, a.wn_b2 = w3.data_ptr(), b3.data_ptr(), wn_u.data_ptr(), wn_w2.data_ptr(), wn_b2.data_ptr()
-        a.out_av, a.out_text = AV.data_ptr(), T[:, Fd:].data_ptr()
-        a.weights, a.uncertainties = weights.data_ptr(), unc.data_ptr()
-        a.ld_w1_unc, a.ld_av, a.ld_text, a.B, a.act_f32 = 3, AV.stride(0), T.stride(0), B, int(dt == torch.float32)
-        a.stream = stream
+        f32 = int(self.compute_dtype == "fp32")
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        planes, weights, unc, fused = new(8, B, 3), new(B, 3), new(B, 3), new(B, cfg.fusion_dim)
         if B:
-            _lib.check(lib.mmdeer_stackb_attn_mix(C.byref(a)))
-
-        # -- HierarchicalFusionModule (complete_project.py:307-366); av_fused lands in T[:, :512] next to the text block
-        def stage(x, p, out):
-            (w0, b0), (g, be), (w4, b4) = p
-            y = ops.linear_into(x, w0, b0, new(B, Fd), relu=True, compute=c)
-            ops.residual_layer_norm(y, None, g, be, y)
-            return ops.linear_into(y, w4, b4, out, relu=True, compute=c)
-        stage(AV, P["av"], T[:, :Fd])
-        G = ops.linear_into(T, *P["gate"], new(B, Fd), compute=c)
-        R = stage(T, P["tri"], new(B, Fd))
-        fused = new(B, Fd)
-        _lib.check(lib.mmdeer_stackb_gate_mix(G.data_ptr(), G.stride(0), R.data_ptr(), R.stride(0), T.data_ptr(), T.stride(0),
-                                              fused.data_ptr(), fused.stride(0), B, Fd, int(dt == torch.float32), stream))
-
-        # -- prediction heads + calibration (complete_project.py:369-459)
-        H0 = ops.linear_into(fused, *P["head0"], new(B, 3 * 256), relu=True, compute=c)
-        H3, ev = new(B, 3 * 128), new(B, 12, dtype=torch.float32)
-        for d in range(3):
-            ops.linear_into(H0[:, d * 256:(d + 1) * 256], *P["head3"][d], H3[:, d * 128:(d + 1) * 128], relu=True, compute=c)
-            ops.linear_into(H3[:, d * 128:(d + 1) * 128], *P["head6"][d], ev[:, 4 * d:4 * d + 4], compute=c)
-        planes = new(8, B, 3, dtype=torch.float32)
-        _lib.check(lib.mmdeer_stackb_head(ev.data_ptr(), ev.stride(0), *(t.data_ptr() for t in P["cal"]), planes.data_ptr(), B, stream))
+            nbytes = lib.mmdeer_stackb_workspace_bytes(B, f32, P["struct"].audio_ld)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            a = _lib.StackBForwardArgs()
+            a.batch, a.compute_f32 = B, f32
+            a.audio, a.video, a.text = (x.data_ptr() for x in xs)
+            a.weights = C.pointer(P["struct"])
+            a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+            a.planes, a.attention_weights, a.modality_uncertainties = planes.data_ptr(), weights.data_ptr(), unc.data_ptr()
+            a.fused_features = fused.data_ptr()
+            a.stream = _lib.current_stream()
+            _lib.check(lib.mmdeer_stackb_forward(C.byref(a)))
 
         out: Dict[str, torch.Tensor] = {}
         for d, name in enumerate(DIM_NAMES):
@@ -274,7 +252,7 @@ class CompleteDEERModel(nn.Module):
                 out[f"{name}_{key}"] = planes[k, :, d]
         out["mu_all"], out["uncertainty_all"], out["calibrated_uncertainty"] = planes[0], planes[6], planes[7]
         out["attention_weights"], out["modality_uncertainties"] = weights, unc
-        out["fused_features"] = fused.float() if dt != torch.float32 else fused
+        out["fused_features"] = fused
         return out
 
     def get_predictions_and_uncertainties(self, outputs: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
