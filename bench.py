@@ -71,6 +71,73 @@ def cpu_baseline(batch, seconds=12.0):
                       f"torch-CPU fp32, {dt:.1f} s"}
 
 
+def stackb_cpu_baseline(batch, seconds=10.0):
+    """Time the oracle's Stack B eval forward (torch-CPU fp32, no_grad) on all host cores for ~`seconds`."""
+    from mmdeer import stackb, synth
+    from oracle import deer_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    P = {k: v.detach().clone() for k, v in stackb.CompleteDEERModel().state_dict().items()}
+    b = synth.make_batch(batch, seed=42)
+    xs = [torch.from_numpy(b[k]) for k in ("audio", "video", "text")]
+    with torch.no_grad():
+        O.stackb_forward(P, *xs)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.stackb_forward(P, *xs)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds and n >= 3:
+                break
+    return {"value": round(batch * n / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} eval forwards of CompleteDEERModel at B={batch}, torch-CPU fp32, {dt:.1f} s"}
+
+
+def bench_stackb(args, dev, world, rank):
+    """--workload stackb_infer: samples/sec of the Stack B (complete_project.CompleteDEERModel) eval forward, replayed
+    as a HIP graph; every rank serves its own batch (replicas, no collective)."""
+    from mmdeer import stackb, synth
+    B, K, W = args.batch, args.steps, args.warmup
+    model = stackb.CompleteDEERModel(compute_dtype=args.dtype).to(dev).eval()
+    data = synth.make_batch(B, seed=42, row_offset=rank * B)
+    xs = [torch.from_numpy(data[k]).to(dev) for k in ("audio", "video", "text")]
+    step = (lambda: model(*xs)) if args.eager else model.capture(*xs).graph.replay
+    for _ in range(W):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt)
+    if rank != 0:
+        return
+    cfg = model.config
+    macs = ((cfg.audio_dim + cfg.video_dim + cfg.text_dim) * 256 + 3 * (cfg.encoder_layers + 1) * 256 * 256       # encoders
+            + 3 * (256 * 512 + 2 * 256 * 256 + 256 * 128 + 128 * 64) + 768 * 256                                   # attention
+            + 512 * 512 * 2 + 768 * 512 * 2 + 512 * 512 + 512 * 768 + 3 * (256 * 128 + 128 * 4))                   # fusion, heads
+    flops = 2.0 * macs * B
+    peak = BF16_MFMA_PEAK if args.dtype == "bf16" else F32_MFMA_PEAK
+    out = {"metric": "samples/sec (Stack B CompleteDEERModel eval forward)", "value": round(world * B * K / dt, 1), "unit": "samples/s",
+           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"complete_project.CompleteDEERModel eval forward, B={B} per GPU, Xavier-initialised weights",
+                      "launch": "eager" if args.eager else "hip-graph replay", "parallelism": f"replicas x{world}"},
+           "roofline": {"bound": "mfma", "achieved": round(flops * K / dt / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                        "frac": round(flops * K / dt / peak, 4), "traffic": None,
+                        "note": "whole forward (25 launches), algorithmic GEMM flops / wall time; the layers are 4-14 us launches bound by fixed launch cost, not MFMA"}}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = stackb_cpu_baseline(B)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +148,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-comm", default="bf16", choices=["bf16", "fp32"],
                     help="payload of the data-parallel gradient all-reduce (N > 1): bf16 halves the bytes over xGMI")
+    ap.add_argument("--workload", default="train_step", choices=["train_step", "stackb_infer"],
+                    help="train_step: the north-star line (default); stackb_infer: SURVEY 8f-1, CompleteDEERModel eval forward")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     args = ap.parse_args()
 
@@ -95,6 +164,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+
+    if args.workload == "stackb_infer":
+        bench_stackb(args, dev, world, rank)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     from mmdeer import synth
     from mmdeer.model import ModelConfig, MultimodalDEER

@@ -139,3 +139,16 @@ def test_stackb_interface():
     np.testing.assert_allclose((after - before).cpu().numpy(), np.tile(np.float32([1, 0, 0]), (4, 1)), atol=1e-5)
     with pytest.raises(NotImplementedError):
         stackb.CompleteDEERModel(stackb.ModelConfig(encoder_dim=128))
+
+
+def test_stackb_graph_replay_equals_eager():
+    m, _ = _model("bf16")
+    xs = [x.to("cuda:0") for x in _inputs(64, 21)]
+    replay = m.capture(*xs)
+    ys = [x.to("cuda:0") for x in _inputs(64, 22)]
+    got = {k: v.clone() for k, v in replay(*ys).items()}
+    want = m(*ys)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    again = replay(*xs)
+    assert torch.equal(again["mu_all"], m(*xs)["mu_all"])

@@ -19,13 +19,7 @@ def main():
                 m(*xs)
             torch.cuda.synchronize()
             eager = (time.perf_counter() - t0) / n
-            g = torch.cuda.CUDAGraph()
-            s = torch.cuda.Stream()
-            with torch.cuda.stream(s):
-                m(*xs)
-                torch.cuda.synchronize()
-                with torch.cuda.graph(g, stream=s):
-                    out = m(*xs)
+            g = m.capture(*xs).graph
             torch.cuda.synchronize()
             for _ in range(5):
                 g.replay()
