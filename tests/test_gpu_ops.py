@@ -153,10 +153,12 @@ def test_gemm_dw_padded_rows(tile, splitk):
     assert (dbias.double() - dY.double().sum(0)).abs().max().item() < 2e-2 * math.sqrt(Bt) / 4
 
 
-def test_gemm_256_tile_epilogue_matches_64_tile():
-    """The 256x256 forward kernel (bias + ReLU + dropout, bf16 in/out) against the 64x64 kernel on the same
-    inputs: the same products summed in a different order, the same dropout decisions."""
-    M, N, K = 777, 1024, 512
+@pytest.mark.parametrize("N", [1024, 768])
+def test_gemm_256_tile_epilogue_matches_64_tile(N):
+    """The 256-row forward kernel (bias + ReLU + dropout, bf16 in/out) against the 64x64 kernel on the same
+    inputs: the same products summed in a different order, the same dropout decisions.  N = 1024 runs as 256x256
+    tiles, N = 768 as 256x192 tiles (16 of them against 12)."""
+    M, K = 777, 512
     A, W, b = bf(rnd(M, K, seed=30)), bf(rnd(N, K, seed=31, scale=0.1)), rnd(N, seed=32)
     kw = dict(bias=b, relu=1, compute_f32=0, drop_site=4, p=0.3, seed=99, offset=7)
     o3 = run_gemm(A, W, M, N, K, tile=3, **kw).float()
@@ -166,6 +168,11 @@ def test_gemm_256_tile_epilogue_matches_64_tile():
     ref = torch.relu(A.double() @ W.double().t() + b.double())
     kept = o3 != 0
     assert ((o3.double() - ref / 0.7).abs() * kept).max().item() < 8e-2
+    # fp32 output: the register-direct epilogue of the same kernel
+    o3f = run_gemm(A, W, M, N, K, tile=3, c_dtype=torch.float32, **kw)
+    assert ((o3f == 0) == (o3 == 0)).float().mean().item() > 0.999
+    assert ((o3f - o3).abs() <= o3f.abs() * 2.0 ** -8 + 1e-6).all()        # o3 is o3f rounded to bf16
+    assert ((o3f.double() - ref / 0.7).abs() * (o3f != 0)).max().item() < 2e-2
 
 
 def test_gemm_dropout_matches_mask_dump():

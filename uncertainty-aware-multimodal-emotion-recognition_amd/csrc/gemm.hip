@@ -11,12 +11,17 @@ int gemm_dispatch_nx(const GemmGroup& g, int total, int compute_f32, GemmTile ti
 int gemm_dispatch_tt(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
 int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStream_t s);
 int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s);
-int gemm_dispatch_nt256(const GemmGroup& g, int total, hipStream_t s);
+int gemm_dispatch_nt256(const GemmGroup& g, int total, int bn, hipStream_t s);
 
 namespace {
 int env_xcd() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MMDEER_XCD"); v = e ? atoi(e) : 1; }
+  return v;
+}
+int env_nt192() {   // MMDEER_NT192=0: the forward 256-row kernel keeps 256-column tiles
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_NT192"); v = e ? atoi(e) : 1; }
   return v;
 }
 // MMDEER_GLDS=0 forces the register-staged kernel for NT problems (A/B comparison, debugging)
@@ -122,7 +127,18 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
               (!q.bias || ((uintptr_t)q.bias % 16 == 0 && q.sBias % 4 == 0));
     }
     const GemmTile tile = (tt256 || nt256) ? TILE_256x256 : (tile_req == TILE_256x256 ? (ta ? TILE_128x128 : TILE_128x64) : tile_req);
-    const int BM = bm_of[tile], BN = bn_of[tile];
+    int BM = bm_of[tile], BN = bn_of[tile];
+    if (nt256 && env_nt192()) {   // 256x192 tiles when they fill the chip in one round and 256x256 tiles do not
+      long long t256 = 0, t192 = 0;
+      bool ok = true;
+      for (int j = 0; j < sub.nprob; ++j) {
+        const GemmProblem& q = sub.p[j];
+        ok = ok && q.N % 192 == 0;
+        t256 += (long long)((q.M + 255) / 256) * ((q.N + 255) / 256) * q.batch;
+        t192 += (long long)((q.M + 255) / 256) * ((q.N + 191) / 192) * q.batch;
+      }
+      if (ok && t192 <= 256 && t192 > t256) BN = 192;
+    }
     int total = 0;
     for (int j = 0; j < sub.nprob; ++j) {
       GemmProblem& q = sub.p[j];
@@ -141,7 +157,7 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
     for (int j = 0; j < sub.nprob && glds; ++j)
       glds = sub.p[j].K % 64 == 0 && sub.p[j].splitk == 1 && !sub.p[j].bias_grad;
     if (tt256) rc = gemm_dispatch_tt256(sub, total, stream);
-    else if (nt256) rc = gemm_dispatch_nt256(sub, total, stream);
+    else if (nt256) rc = gemm_dispatch_nt256(sub, total, BN, stream);
     else if (glds) rc = gemm_dispatch_nt_glds(sub, total, tile, stream);
     else if (!ta && !tb) rc = gemm_dispatch_nt(sub, total, compute_f32, tile, am, bm, stream);
     else if (!ta && tb) rc = gemm_dispatch_nx(sub, total, compute_f32, tile, am, bm, stream);

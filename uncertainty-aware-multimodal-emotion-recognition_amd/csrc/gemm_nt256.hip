@@ -49,11 +49,16 @@ struct Nt256Kernargs {   // mirror of the kernel's parameter list (offset of `g`
   GemmGroup g;
 };
 
-// leading scalars = problem 0, preloaded into SGPRs (see gemm_glds.hip); nk counts 32-element K stages
+// leading scalars = problem 0, preloaded into SGPRs (see gemm_glds.hip); nk counts 32-element K stages.
+// BN = 256, or 192 (each wave 64x96): the in_proj (N = 1536) is 32 x 6 = 192 tiles of 256x256 -- a quarter of the 256
+// CUs idle -- but 32 x 8 = 256 tiles of 256x192.  The weight image in LDS keeps 256 rows either way (the DMA pieces
+// are 16 rows x 8 waves; the 64 extra rows are loaded and never read), so only fragment reads and the epilogue differ.
+template <int BN>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* A0, const bf16_t* B0, int M0, int N0, int nk0, int lda0,
                                                          int ldb0, int tiles_n0, int nt0, int nwg, const GemmGroup g) {
-  constexpr int BM = 256, BN = 256, KT = 32, NST = 4;
-  constexpr int TM = 4, TN = 8, WTM = 64, WTN = 128;
+  constexpr int BM = 256, KT = 32, NST = 4;
+  constexpr int TM = 4, TN = BN / 32, WTM = 64, WTN = BN / 2;
+  static_assert(BN == 256 || BN == 192, "tile widths of the forward 256-row kernel");
   constexpr int ROWB = 64;                      // bytes per image row (32 bf16)
   constexpr int OPER = BM * ROWB, STAGE = 2 * OPER;
   constexpr int LPT = 4;                        // DMA instructions per wave per stage
@@ -171,7 +176,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* A0, const
     if (kt + NST - 1 < nk) issue((stage + NST - 1) & (NST - 1));
     wait_lgkm0(fa[0], fa[1], fa[2], fa[3]);
     wait_lgkm0(fb[0], fb[1], fb[2], fb[3]);
-    wait_lgkm0(fb[4], fb[5], fb[6], fb[7]);
+    if constexpr (TN == 8) wait_lgkm0(fb[4], fb[5], fb[6], fb[7]);
+    else wait_lgkm0(fb[4], fb[5], fb[4], fb[5]);
     {
       const int younger = nk - 2 - kt;   // tiles after kt+1 that have been issued: own pieces of tile kt+1 must have landed
       if (younger >= 2) wait_vm<2 * LPT>();
@@ -231,11 +237,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* A0, const
     __syncthreads();
     bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC;
     const long long ldc = p.ldc;
-    const int cchunk = tid & 31, rsub = tid >> 5;                  // 32 chunks of 8 columns per row, 16 rows per pass
-    const int n = col0 + cchunk * 8;
+    constexpr int CPR = BN / 8;                                    // 16-byte chunks (8 columns) per row
 #pragma unroll 4
-    for (int r = rsub; r < BM; r += 16) {
-      const int m = row0 + r;
+    for (int e = tid; e < BM * CPR; e += 512) {
+      const int r = e / CPR, cchunk = e - r * CPR;
+      const int m = row0 + r, n = col0 + cchunk * 8;
       if (m >= M || n >= N) continue;
       const u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * CROW + cchunk * 16);
       bf16_t* dst = Cb + (long long)m * ldc + n;
@@ -252,13 +258,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* A0, const
 }  // namespace
 
 // caller guarantees: bf16 compute, no transposition, both operands bf16 with ld % 8 == 0 and 16-byte aligned, K % 32 == 0,
-// no split-K / bias_grad / Y mask, tiles counted 256x256
-int gemm_dispatch_nt256(const GemmGroup& g, int total, hipStream_t s) {
+// no split-K / bias_grad / Y mask, tiles counted 256 x bn (bn = 256 or 192)
+int gemm_dispatch_nt256(const GemmGroup& g, int total, int bn, hipStream_t s) {
   const GemmProblem& q = g.p[0];
   const int nt0 = q.batch == 1 ? g.tile_start[1] : 0;
-  hipLaunchKernelGGL(gemm_nt256_kernel, dim3(total), dim3(512), 0, s, reinterpret_cast<const bf16_t*>(q.A),
-                     reinterpret_cast<const bf16_t*>(q.B), q.M, q.N, q.K >> 5, q.lda, q.ldb, q.tiles_n, nt0,
-                     g.xcd_remap ? total : 0, g);
+  if (bn == 192)
+    hipLaunchKernelGGL(gemm_nt256_kernel<192>, dim3(total), dim3(512), 0, s, reinterpret_cast<const bf16_t*>(q.A),
+                       reinterpret_cast<const bf16_t*>(q.B), q.M, q.N, q.K >> 5, q.lda, q.ldb, q.tiles_n, nt0,
+                       g.xcd_remap ? total : 0, g);
+  else
+    hipLaunchKernelGGL(gemm_nt256_kernel<256>, dim3(total), dim3(512), 0, s, reinterpret_cast<const bf16_t*>(q.A),
+                       reinterpret_cast<const bf16_t*>(q.B), q.M, q.N, q.K >> 5, q.lda, q.ldb, q.tiles_n, nt0,
+                       g.xcd_remap ? total : 0, g);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
