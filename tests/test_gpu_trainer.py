@@ -220,3 +220,22 @@ def test_streaming_metrics_match_host_metrics():
     sm3 = StreamingMetrics("cuda:0")
     sm3.update(*(torch.from_numpy(x).to("cuda:0") for x in (pred3, tgt, unc)))
     assert sm3.compute()["ccc_dominance"] == 0.0
+
+
+def test_evaluate_deer_model_accepts_stack_b():
+    """evaluation.evaluate_deer_model over loaders for the Stack B model: streaming metrics equal the host metrics of
+    the concatenated predictions; no loss exists for this stack in the reference (NaN)."""
+    from mmdeer import stackb
+    from mmdeer.metrics import validation_metrics
+    m = stackb.CompleteDEERModel().to("cuda:0")
+    ld = loaders(96, 32, 9, True)
+    ev = evaluate_deer_model(m, ld, "cuda:0")
+    assert not m.training and np.isnan(ev["test_loss"])
+    preds, tgts, uncs = [], [], []
+    for b in ld["iemocap"]:
+        out = m(b["audio_features"].cuda(), b["video_features"].cuda(), b["text_features"].cuda())
+        p, u = m.get_predictions_and_uncertainties(out)
+        preds.append(p.cpu().numpy()); tgts.append(b["targets"].numpy()); uncs.append(u.cpu().numpy())
+    ref = validation_metrics(np.concatenate(preds), np.concatenate(tgts), np.concatenate(uncs))
+    for k in ("ccc_valence", "ccc_overall", "mae_arousal", "rmse_dominance"):
+        np.testing.assert_allclose(ev[k], ref[k], rtol=1e-5, atol=1e-6, err_msg=k)

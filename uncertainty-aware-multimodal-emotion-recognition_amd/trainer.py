@@ -156,25 +156,8 @@ class DEERTrainer:
         out["grad_norm"] = float(torch.stack(norms).mean()) if norms else 0.0
         return out
 
-    @torch.no_grad()
     def validate_epoch(self, val_loaders: Dict[str, Iterable]) -> Dict[str, float]:
-        self.model.eval()
-        # CCC / MAE / RMSE statistics are accumulated on the device batch by batch (mmdeer_eval_accumulate); only 24
-        # doubles and the per-sample (mean error, mean uncertainty) pairs of the calibration error reach the host
-        sm = StreamingMetrics(self.device)
-        losses = []
-        for loader in val_loaders.values():
-            for batch in loader:
-                a, v, t, y = unpack_batch(batch, self.device)
-                out = self.model(a, v, t)
-                p, u = self.model.get_predictions_and_uncertainties(out)
-                losses.append(self.model.compute_loss(out, y)["total_loss"])
-                sm.update(p, y, u)
-        if not losses:
-            return {"val_loss": float("nan")}
-        m = sm.compute()
-        m["val_loss"] = float(torch.stack(losses).mean())
-        return m
+        return evaluate_loaders(self.model, val_loaders, self.device)
 
     def evaluate_model(self, test_loaders: Dict[str, Iterable]) -> Dict[str, float]:
         m = self.validate_epoch(test_loaders)
@@ -217,9 +200,40 @@ class DEERTrainer:
                     "training_history": self.history, "training_time": training_time}, path)
 
 
-def evaluate_deer_model(model: MultimodalDEER, test_loaders, device=None) -> Dict[str, float]:
-    """evaluation.evaluate_deer_model (evaluation.py:785-808): metrics of the model on the test loaders."""
-    return DEERTrainer(model, TrainingConfig(), device).evaluate_model(test_loaders)
+@torch.no_grad()
+def evaluate_loaders(model, loaders: Dict[str, Iterable], device=None) -> Dict[str, float]:
+    """Validation pass of training.py:247-314 for any model of this package that maps (audio, video, text) to an output
+    dictionary understood by its ``get_predictions_and_uncertainties`` -- ``MultimodalDEER`` (Stack C) or
+    ``stackb.CompleteDEERModel`` (Stack B, which has no loss in the reference: ``val_loss`` is then NaN).
+
+    CCC / MAE / RMSE statistics are accumulated on the device batch by batch (mmdeer_eval_accumulate); only 24 doubles and
+    the per-sample (mean error, mean uncertainty) pairs of the calibration error reach the host."""
+    device = torch.device(device) if device is not None else next(model.parameters()).device
+    model.eval()
+    sm = StreamingMetrics(device)
+    has_loss = hasattr(model, "compute_loss")
+    losses, seen = [], False
+    for loader in loaders.values():
+        for batch in loader:
+            a, v, t, y = unpack_batch(batch, device)
+            out = model(a, v, t)
+            p, u = model.get_predictions_and_uncertainties(out)
+            if has_loss:
+                losses.append(model.compute_loss(out, y)["total_loss"])
+            sm.update(p, y.float(), u)
+            seen = True
+    if not seen:
+        return {"val_loss": float("nan")}
+    m = sm.compute()
+    m["val_loss"] = float(torch.stack(losses).mean()) if losses else float("nan")
+    return m
+
+
+def evaluate_deer_model(model, test_loaders, device=None) -> Dict[str, float]:
+    """evaluation.evaluate_deer_model (evaluation.py:785-808): metrics of the model on the test loaders (Stack C or B)."""
+    m = evaluate_loaders(model, test_loaders, device)
+    m["test_loss"] = m.pop("val_loss")
+    return m
 
 
 def profile_training_speed(model: MultimodalDEER, batch_size: int = 32, warmup: int = 10, iters: int = 100):
