@@ -304,12 +304,12 @@ def main():
             "final_loss": round(loss, 6),
             "train_step_with_optimizer_ms": round(full_elapsed / K * 1e3, 4),     # fwd + bwd + clip + AdamW + weight pack
             "optimizer_ms": round((full_elapsed - elapsed) / K * 1e3, 4),
-            "roofline": {"bound": "mfma", "kernel": ("gemm_nt256_kernel" if args.dtype == "bf16" else "gemm_group_kernel") + " (trimodal in_proj, M=2B K=512 N=1536)",
+            "roofline": {"bound": "mfma", "kernel": ("gemm_nt256_kernel<192>" if args.dtype == "bf16" else "gemm_group_kernel") + " (trimodal in_proj, M=2B K=512 N=1536)",
                          "achieved": round(achieved / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          # HBM-side bytes of one launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950
                          # + WRITE_SIZE, profiles/r01_pmc_gemm_kernels.txt); algorithmic bytes: A 8.39 + W 1.57 + C 25.17 MB
-                         "traffic": 46.5e6 if args.dtype == "bf16" and B == 4096 else None,
+                         "traffic": 44.3e6 if args.dtype == "bf16" and B == 4096 else None,   # profiles/r01_pmc_gemm_kernels_v2.txt
                          "algorithmic_bytes": 2 * B * 512 * 2 + 1536 * 512 * 2 + 2 * B * 1536 * 2,
                          "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(gemm_ms[len(gemm_ms) // 2] * 1e3, 2)},
         }
