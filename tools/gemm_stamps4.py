@@ -22,7 +22,7 @@ def run(tag, M, N, K, bias):
     W = torch.randn(N, K, device=dev).to(dt)
     b = torch.randn(N, device=dev) if bias else None
     Cm = torch.empty(M, N, device=dev, dtype=dt)
-    st = torch.zeros(256, dtype=torch.int64, device=dev)
+    st = torch.zeros(1024, dtype=torch.int64, device=dev)
     a = _lib.GemmArgs()
     a.A, a.W, a.C = A.data_ptr(), W.data_ptr(), Cm.data_ptr()
     a.bias = b.data_ptr() if bias else None
@@ -45,6 +45,18 @@ def run(tag, M, N, K, bias):
         print(f"   kt={kt}: load phase (reads, dma issue, waits, barrier)={s[b0+1]-s[b0]} mfma phase={s[b0+2]-s[b0+1]} barrier={s[b0+3]-s[b0+2]} iter={s[b0+3]-s[b0]}")
     if s[8]:
         print(f"   prologue wait (start of kt=0 - end of prologue issue) = {s[8]-s[1]}")
+    # per-workgroup begin / end on the 100 MHz real-time counter
+    import numpy as np
+    n = (M // 256) * (N // 192 if N % 192 == 0 else -(-N // 256))
+    w = s[256:256 + 2 * n].reshape(n, 2).astype(np.int64)
+    t0 = w[:, 0].min()
+    beg, end = (w[:, 0] - t0) / 100.0, (w[:, 1] - t0) / 100.0     # us
+    print(f"   {n} workgroups: begin min/median/max = {beg.min():.2f}/{np.median(beg):.2f}/{beg.max():.2f} us, "
+          f"end min/median/max = {end.min():.2f}/{np.median(end):.2f}/{end.max():.2f} us, "
+          f"duration min/median/max = {(end-beg).min():.2f}/{np.median(end-beg):.2f}/{(end-beg).max():.2f} us")
+    order = np.argsort(beg)
+    print("   begin times (sorted, every 16th):", " ".join(f"{beg[i]:.2f}" for i in order[::16]))
+    print("   end times of the same workgroups :", " ".join(f"{end[i]:.2f}" for i in order[::16]))
 
 
 run("in_proj", 8192, 1536, 512, True)

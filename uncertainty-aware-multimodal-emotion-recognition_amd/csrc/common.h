@@ -10,6 +10,25 @@ typedef unsigned short bf16_t;  // raw bf16 bits in memory
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Write-through, system-scope global stores (sc0 sc1).  The L2 of an XCD is write-back and not coherent with the other
+// seven, so a kernel's dirty lines are written back when it ends -- serial time after the last wave has retired
+// (measured on the in_proj GEMM, 24 MB of output: 23.45 us with plain stores, 21.4 us with these, consumer unchanged;
+// `nt` stores gave the same 21.6 us but slowed the consumer down by 0.7 us).  Only for stores that cover whole cache
+// lines: the lane-direct epilogues of the small GEMMs write 8-byte pieces of a row per instruction, and as
+// write-through those cost MORE (128x64 kernel 6.4 -> 7.0 us, step 0.323 -> 0.334 ms) -- they keep plain stores.
+template <typename V2>
+__device__ __forceinline__ void store_wt8(void* p, V2 v) {    // 8 bytes
+  static_assert(sizeof(V2) == 8, "store_wt8 writes 8 bytes");
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+template <typename V4>
+__device__ __forceinline__ void store_wt16(void* p, V4 v) {   // 16 bytes
+  static_assert(sizeof(V4) == 16, "store_wt16 writes 16 bytes");
+  // s_nop 1: a store of more than 8 bytes reads its data VGPRs up to two cycles after issue, and the compiler's hazard
+  // recogniser cannot see into the asm statement -- without it a following VALU write to the same registers lands first
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 enum { DT_BF16 = 0, DT_F32 = 1 };
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }

@@ -23,8 +23,18 @@ namespace {
       g.stamps[slot] = t_;                                                                 \
     }                                                                                      \
   } while (0)
+// per-workgroup begin / end on the 100 MHz real-time counter (comparable across XCDs): stamps[256 + 2 bid + {0, 1}]
+#define WGSTAMP(which)                                                                     \
+  do {                                                                                     \
+    if (g.stamps && threadIdx.x == 0) {                                                    \
+      unsigned long long t_;                                                               \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+      g.stamps[256 + 2 * blockIdx.x + (which)] = t_;                                       \
+    }                                                                                      \
+  } while (0)
 #else
 #define NSTAMP(slot) do {} while (0)
+#define WGSTAMP(which) do {} while (0)
 #endif
 
 template <int N>
@@ -71,6 +81,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* A0, const
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   NSTAMP(0);
+  WGSTAMP(0);
 
   int bid = blockIdx.x;
   if (nwg > 0) {
@@ -245,14 +256,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* A0, const
       if (m >= M || n >= N) continue;
       const u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * CROW + cchunk * 16);
       bf16_t* dst = Cb + (long long)m * ldc + n;
-      if (n + 8 <= N) *reinterpret_cast<u32x4*>(dst) = v;
-      else *reinterpret_cast<u32x2*>(dst) = u32x2{v.x, v.y};       // N % 4 == 0: the last chunk may be half valid
+      if (n + 8 <= N) store_wt16(dst, v);
+      else store_wt8(dst, u32x2{v.x, v.y});                        // N % 4 == 0: the last chunk may be half valid
     }
   }
 #ifdef MMDEER_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   NSTAMP(3);
+  WGSTAMP(1);
 }
 
 }  // namespace

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
       f32x4 v = acc[i][j];
       f32x4* cp = reinterpret_cast<f32x4*>(rowp + j * 16);
       if (accumulate) v += *cp;
-      *cp = v;
+      store_wt16(cp, v);
     }
   }
   TSTAMP(3);

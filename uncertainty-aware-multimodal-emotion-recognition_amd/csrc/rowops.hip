@@ -28,10 +28,11 @@ __device__ __forceinline__ f32x4 load4(const void* base, long long idx) {
 }
 template <bool F32>
 __device__ __forceinline__ void store4(void* base, long long idx, f32x4 v) {
+  // a wave stores whole rows contiguously: full cache lines, written through (common.h: store_wt*)
   if constexpr (F32) {
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+    store_wt16(reinterpret_cast<float*>(base) + idx, v);
   } else {
-    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(base) + idx) = u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+    store_wt8(reinterpret_cast<bf16_t*>(base) + idx, u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)});
   }
 }
 
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceTable 
   __syncthreads();
   if (pl == 0 && e < n) {
     const int c = threadIdx.x;
-    *reinterpret_cast<f32x4*>((float*)T.dst[sgm] + e) = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    store_wt16((float*)T.dst[sgm] + e, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
   }
 }
 
