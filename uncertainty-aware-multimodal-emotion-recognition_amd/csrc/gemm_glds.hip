@@ -30,8 +30,18 @@ namespace {
       g.stamps[slot] = t_;                                                                 \
     }                                                                                      \
   } while (0)
+// per-workgroup begin / end on the 100 MHz real-time counter (comparable across XCDs): stamps[256 + 2 bid + {0, 1}]
+#define KWGSTAMP(which)                                                                    \
+  do {                                                                                     \
+    if (g.stamps && threadIdx.x == 0 && blockIdx.x < 1024) {                               \
+      unsigned long long t_;                                                               \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+      g.stamps[256 + 2 * blockIdx.x + (which)] = t_;                                       \
+    }                                                                                      \
+  } while (0)
 #else
 #define KSTAMP(slot) do {} while (0)
+#define KWGSTAMP(which) do {} while (0)
 #endif
 
 int env_nt8() {   // MMDEER_NT8=0: never use the 8-wave 128x64 form
@@ -82,6 +92,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && BM * BN <= 128 * 64) ? 2 : 1) 
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   KSTAMP(0);
+  KWGSTAMP(0);
 
   int bid = blockIdx.x;
   if (nwg > 0) {   // XCD-contiguous renumbering (nwg = grid size; 0 switches it off)
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && BM * BN <= 128 * 64) ? 2 : 1) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   KSTAMP(5);
+  KWGSTAMP(1);
 }
 
 template <int BM, int BN, int NST, int NW>
