@@ -34,13 +34,14 @@ __device__ __forceinline__ f32x4 ld4(const void* base, long long idx) {
 
 template <bool F32>
 __device__ __forceinline__ void st4(void* base, long long idx, f32x4 v) {
+  // every caller has a wave write whole rows contiguously: full cache lines, written through (common.h: store_wt*)
   if constexpr (F32) {
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+    store_wt16(reinterpret_cast<float*>(base) + idx, v);
   } else {
     u32x2 p;
     p.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
     p.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
-    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(base) + idx) = p;
+    store_wt8(reinterpret_cast<bf16_t*>(base) + idx, p);
   }
 }
 
