@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 5
+#define MMDEER_ABI_VERSION 6
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -349,6 +349,19 @@ typedef struct mmdeer_stackb_forward_args {
 } mmdeer_stackb_forward_args;
 size_t mmdeer_stackb_workspace_bytes(int batch, int compute_f32, int audio_ld);
 int mmdeer_stackb_forward(const mmdeer_stackb_forward_args* a);
+
+/* ---- gradient exchange: the data-parallel step has ONE collective, an all-reduce of the flat gradient
+ * buffer.  These wrap an RCCL communicator for hosts without torch.distributed; RCCL is bound at run time (dlopen), so
+ * the library loads without it and these calls then fail with a message.  Rank 0 draws the id, the host distributes
+ * its MMDEER_COMM_ID_BYTES bytes to the other ranks by whatever side channel it has (file, socket, MPI, a
+ * torch.distributed broadcast), every rank calls mmdeer_comm_init with its HIP device current.  mmdeer_allreduce works
+ * in place on `count` elements of fp32 (dtype_f32 != 0) or bf16, sum or average, enqueued on `stream` (capturable). */
+#define MMDEER_COMM_ID_BYTES 128
+typedef struct mmdeer_comm mmdeer_comm;
+int mmdeer_comm_unique_id(void* id_out);
+int mmdeer_comm_init(mmdeer_comm** comm, int rank, int world_size, const void* id);
+int mmdeer_comm_destroy(mmdeer_comm* comm);
+int mmdeer_allreduce(void* buf, long long count, int dtype_f32, int average, mmdeer_comm* comm, void* stream);
 
 /* fp32 <-> bf16 conversion of a contiguous device buffer (n % 4 == 0) */
 int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream);

@@ -154,6 +154,10 @@ SYMBOLS = [
     ("mmdeer_stackb_head", c_int, [c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
     ("mmdeer_stackb_workspace_bytes", c_size_t, [c_int, c_int, c_int]),
     ("mmdeer_stackb_forward", c_int, [C.POINTER(StackBForwardArgs)]),
+    ("mmdeer_comm_unique_id", c_int, [c_void_p]),
+    ("mmdeer_comm_init", c_int, [C.POINTER(c_void_p), c_int, c_int, c_void_p]),
+    ("mmdeer_comm_destroy", c_int, [c_void_p]),
+    ("mmdeer_allreduce", c_int, [c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p]),
     ("mmdeer_convert", c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p]),
 ]
 
@@ -187,7 +191,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 5:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 6:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         _LIB = lib
     return _LIB

@@ -16,6 +16,53 @@ import torch
 import torch.distributed as dist
 
 
+class RcclCommunicator:
+    """An RCCL communicator behind the C ABI (``mmdeer_comm_*`` / ``mmdeer_allreduce``, include/mmdeer.h): the exchange
+    of the path without torch.distributed in the data path.  Rank 0 draws the 128-byte id (``unique_id()``), the host
+    distributes it, every rank constructs the communicator with its device current; ``from_torch_distributed`` does
+    the distribution with a broadcast over an existing process group (bootstrap only)."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        import ctypes as C
+        from . import _lib
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of mmdeer_comm_unique_id")
+        self._lib = _lib.load()
+        self.rank, self.world = rank, world
+        handle = C.c_void_p()
+        _lib.check(self._lib.mmdeer_comm_init(C.byref(handle), rank, world, unique_id))
+        self._handle = handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().mmdeer_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_distributed(cls, group: Optional["dist.ProcessGroup"] = None) -> "RcclCommunicator":
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    def all_reduce(self, t: torch.Tensor, average: bool = True) -> None:
+        """In place on the current stream (enqueue only; capturable into a HIP graph)."""
+        from . import _lib
+        if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("all_reduce: a contiguous fp32 / bf16 GPU tensor is required")
+        _lib.check(self._lib.mmdeer_allreduce(t.data_ptr(), t.numel(), int(t.dtype == torch.float32), int(average),
+                                              self._handle, _lib.current_stream()))
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            from . import _lib
+            _lib.check(self._lib.mmdeer_comm_destroy(self._handle))
+            self._handle = None
+
+
 class BucketedAllReduce:
     """Gradient all-reduce of the flat buffer (the name is kept from the bucketed design; ``events`` is None: the
     library needs no per-bucket events any more, ``train_step(events=None)``).
@@ -25,7 +72,13 @@ class BucketedAllReduce:
     all-reduce, cast back into the fp32 buffer; ``'fp32'`` exchanges the buffer as it is."""
 
     def __init__(self, group: Optional["dist.ProcessGroup"] = None, device: Optional[torch.device] = None,
-                 force: bool = False, payload: Optional[str] = None):
+                 force: bool = False, payload: Optional[str] = None, backend: Optional[str] = None):
+        import os
+        backend = backend or os.environ.get("MMDEER_COMM", "torch")
+        if backend not in ("torch", "rccl"):
+            raise ValueError("backend must be 'torch' (torch.distributed's communicator) or 'rccl' (mmdeer_comm_* of the C ABI)")
+        self.backend = backend
+        self._rccl: Optional[RcclCommunicator] = None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force and dist.is_initialized()    # run the collective even on a 1-rank group (rehearsal)
@@ -37,6 +90,8 @@ class BucketedAllReduce:
         if payload == "bf16" and not self.cuda:
             raise ValueError("the bf16 payload needs the GPU (RCCL) path")
         self.payload = payload
+        if backend == "rccl" and self.cuda and (self.world > 1 or self.force):
+            self._rccl = RcclCommunicator.from_torch_distributed(group)
         self.events = None
         self._work: List = []
         self._half: Optional[torch.Tensor] = None
@@ -57,12 +112,19 @@ class BucketedAllReduce:
                 if self._half is None or self._half.numel() != flat.numel() or self._half.device != flat.device:
                     self._half = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
                 self._convert(flat, self._half)
-                self._work = [dist.all_reduce(self._half, op=dist.ReduceOp.AVG, group=self.group, async_op=True)]
+                self._work = [self._reduce(self._half)]
             else:
-                self._work = [dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)]
+                self._work = [self._reduce(flat)]
         else:           # gloo (CPU tests): no AVG op
             self._work = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
         self._flat = flat
+
+    def _reduce(self, t: torch.Tensor):
+        """Averaged all-reduce of a GPU tensor behind the work already on the current stream; returns a waitable or None."""
+        if self._rccl is not None:
+            self._rccl.all_reduce(t, average=True)      # enqueued on the current stream: nothing to wait for
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
 
     # ---- overlapped form (GPU): the exchange of a slice of the flat buffer on a side stream, forked from / joined to
     #      the current stream by events -- capturable into a HIP graph together with the step (model.train_step(comm=...))
@@ -84,10 +146,14 @@ class BucketedAllReduce:
                     self._half = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
                 half = self._half[lo:hi]
                 self._convert(view, half)
-                dist.all_reduce(half, op=dist.ReduceOp.AVG, group=self.group)
+                w = self._reduce(half)
+                if w is not None:
+                    w.wait()
                 self._convert(half, view)
             else:
-                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+                w = self._reduce(view)
+                if w is not None:
+                    w.wait()
 
     def join(self) -> None:
         """The current stream waits for the exchanges launched with ``launch_range``."""
@@ -99,7 +165,8 @@ class BucketedAllReduce:
         if self.world == 1 and not self.force:
             return
         for w in self._work:
-            w.wait()
+            if w is not None:
+                w.wait()
         if self.cuda and self.payload == "bf16" and self._work:
             self._convert(self._half, self._flat)
         if not self.cuda and flat is not None:
