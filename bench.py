@@ -182,6 +182,12 @@ def main():
     if args.dtype == "bf16":
         a, v, t = a.bfloat16(), v.bfloat16(), t.bfloat16()         # BASELINE configs 3-5: bf16 feature blocks
     comm = BucketedAllReduce(device=dev, force=force_comm, payload=args.grad_comm) if (world > 1 or force_comm) else None
+    # MMDEER_EXACT_GLOBAL=1 (optional): the 106 loss statistics are summed across ranks between forward and
+    # backward, so every rank optimises the loss of the GLOBAL batch; default is DDP semantics (mean of per-shard losses)
+    exact = comm is not None and os.environ.get("MMDEER_EXACT_GLOBAL", "0") == "1"
+    if exact:
+        comm.exact_global = True
+    sc = dict(stats_comm=comm) if exact else {}
     K, W = args.steps, args.warmup
     prof = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     for e0, e1 in prof:
@@ -211,10 +217,10 @@ def main():
             plans.append(("in-graph", dict(after=exchange)))
             for name, kw in plans:
                 try:
-                    model.train_step(a, v, t, y)
+                    model.train_step(a, v, t, y, **sc)
                     exchange()                       # communicator set up outside the capture
                     torch.cuda.synchronize()
-                    replay = model.capture_train_step(a, v, t, y, events=ev, **kw)
+                    replay = model.capture_train_step(a, v, t, y, events=ev, **kw, **sc)
                     comm_in_graph, comm_mode = True, name
                     break
                 except Exception as e:               # noqa: BLE001
@@ -222,7 +228,7 @@ def main():
                     torch.cuda.synchronize()
                     replay = None
         if replay is None:
-            replay = model.capture_train_step(a, v, t, y, events=ev)
+            replay = model.capture_train_step(a, v, t, y, events=ev, **sc)
             comm_mode = "host-enqueued" if comm else "none"
     elif comm:
         comm_mode = "host-enqueued"
@@ -234,7 +240,7 @@ def main():
         if replay is not None:
             ld = replay()
         else:
-            ld = model.train_step(a, v, t, y, events=ev, prof_events=prof[i] if i is not None else None)
+            ld = model.train_step(a, v, t, y, events=ev, prof_events=prof[i] if i is not None else None, **sc)
         if comm and not (comm_in_graph and replay is not None):
             comm.launch(model.flat_grad())
             comm.wait()
@@ -300,7 +306,7 @@ def main():
                        "parallelism": (f"dp{world} (one process per GPU, gradient all-reduce over RCCL, {args.grad_comm} payload, "
                                         f"{comm_mode})" if world > 1 else "single")},
             "launch": "eager" if replay is None else "hip-graph replay",
-            "grad_exchange": comm_mode,
+            "grad_exchange": comm_mode + (", exact-global loss statistics" if exact else ""),
             "final_loss": round(loss, 6),
             "train_step_with_optimizer_ms": round(full_elapsed / K * 1e3, 4),     # fwd + bwd + clip + AdamW + weight pack
             "optimizer_ms": round((full_elapsed - elapsed) / K * 1e3, 4),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 6
+#define MMDEER_ABI_VERSION 7
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -138,10 +138,23 @@ typedef struct mmdeer_backward_args {
    * audio-visual remainder (bucket 2).  Lets a data-parallel caller start the all-reduce of buckets 0-1 (89 % of
    * the gradient) while part 2 runs.  Both calls take the same arguments; 1 must precede 2. */
   int32_t phase;
+  /* Exact-global loss for data parallelism (optional): MMDEER_GLOBAL_STATS floats = the loss statistics of
+   * ALL ranks' batches (every rank calls mmdeer_loss_stats after its forward and the host sums the vectors across
+   * ranks, e.g. mmdeer_allreduce with average = 0).  The ECE and cross-dimension terms are non-linear in these batch
+   * statistics; with them the loss written to loss_out is that of the global batch on every rank and the gradients are
+   * each rank's share of ITS gradient -- exchange them with a SUM, not a mean.  NULL: the statistics of this call's own
+   * batch (DDP semantics, the default).  Used with `targets` only. */
+  const float* global_stats;
   void* stream;
 } mmdeer_backward_args;
 
 int mmdeer_backward(const mmdeer_backward_args* a);
+
+/* Loss statistics of the batch whose forward (with targets) last ran on `workspace`: out[3][35] per-dimension sums
+ * (5 loss sums + 10 ECE bins x {sum confidence, sum error, count}) followed by out[105] = batch.  All entries are plain
+ * sums over samples, so adding the vectors of several ranks gives the statistics of the union of their batches. */
+#define MMDEER_GLOBAL_STATS 106
+int mmdeer_loss_stats(const void* workspace, size_t workspace_bytes, int batch, int compute_f32, float* out, void* stream);
 
 /* bucket boundaries used by bucket_events: elements [mmdeer_bucket_begin(i), mmdeer_bucket_end(i)) of the flat buffer */
 long long mmdeer_bucket_begin(int bucket);

@@ -33,6 +33,17 @@ def _worker(rank, world, port, q):
         comm.launch(flat)
         comm.wait(flat)
         ok = torch.allclose(flat, expect)
+        # exact-global mode (optional): loss statistics are SUMMED across ranks before the backward pass, and so
+        # are the gradients (each rank holds its share of the global-batch gradient)
+        stats = torch.arange(106, dtype=torch.float32) * (rank + 1)
+        comm.sum_small(stats)
+        ok = ok and torch.equal(stats, torch.arange(106, dtype=torch.float32) * sum(range(1, world + 1)))
+        comm.exact_global = True
+        share = torch.full((n,), float(rank + 1))
+        comm.launch(share)
+        comm.wait(share)
+        ok = ok and torch.equal(share, torch.full((n,), float(sum(range(1, world + 1)))))
+        comm.exact_global = False
         # weak-scaling data sharding: rank r draws rows [rB, (r+1)B) of one global stream
         B = 6
         mine = synth.make_batch(B, seed=42, row_offset=rank * B)["video"]

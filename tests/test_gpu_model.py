@@ -351,3 +351,57 @@ def test_two_phase_backward_equals_single_call():
     torch.cuda.synchronize()
     assert torch.equal(flat, flat0)
     assert torch.equal(loss, loss0)
+
+
+def test_exact_global_loss_over_two_shards_equals_the_global_batch():
+    """SURVEY 8e, optional exact-global mode: with the 106 loss statistics summed across ranks between forward and
+    backward, the loss every rank reports is the global batch's and the SUM of the ranks' gradients is its gradient
+    (the default -- mean of per-shard losses -- is not: ECE and cross-dimension terms are non-linear in batch statistics).
+    Two ranks are played by two shards of unequal size on the one GPU; the oracle runs on their union."""
+    sizes = (48, 80)                                   # unequal, and ragged against the 64-row blocks of the head kernels
+    b = batch(sum(sizes), seed=17)
+    shards, lo = [], 0
+    for n in sizes:
+        shards.append({k: v[lo:lo + n].to(DEV) for k, v in b.items()})
+        lo += n
+    models = [make_model(dropout=0.0).train() for _ in sizes]       # identical closed-form parameters
+
+    class Exchange:                                    # stands in for parallel.BucketedAllReduce on each "rank"
+        active = True
+
+        def __init__(self):
+            self.seen, self.total = None, None
+
+        def sum_small(self, t):
+            self.seen = t.clone()
+            if self.total is not None:
+                t.copy_(self.total)
+
+    ex = [Exchange() for _ in sizes]
+    step = lambda m, s, e: m.train_step(s["audio"], s["video"], s["text"], s["targets"], stats_comm=e)
+    local = [step(m, s, e) for m, s, e in zip(models, shards, ex)]          # pass 1: every rank's own statistics
+    total = ex[0].seen + ex[1].seen
+    assert float(total[105]) == sum(sizes) and float(ex[0].seen[105]) == sizes[0]
+    for e in ex:
+        e.total = total
+    glob = [step(m, s, e) for m, s, e in zip(models, shards, ex)]           # pass 2: backward on the summed statistics
+    torch.cuda.synchronize()
+
+    P = oracle_params(models[0], requires_grad=True)
+    fo, ho, ldo, grads = O.train_step(P, b["audio"], b["video"], b["text"], b["targets"])
+    want = float(ldo["total_loss"])
+    for d in glob:
+        assert float(d["total_loss"]) == pytest.approx(want, rel=2e-5, abs=2e-6)
+    assert float(glob[0]["total_loss"]) == float(glob[1]["total_loss"])
+    assert abs(float(local[0]["total_loss"]) - want) > 1e-3                  # the shard's own loss is a different number
+    assert torch.equal(glob[0]["ece_bin_counts"], glob[1]["ece_bin_counts"]) and int(glob[0]["ece_bin_counts"].sum()) == 3 * sum(sizes)
+    g0, g1 = (dict(m.named_parameters()) for m in models)               # .grad of a live parameter is a view of the flat buffer
+    checked = 0
+    for name, ref in grads.items():
+        if g0[name].grad is None:
+            continue
+        g = (g0[name].grad.double() + g1[name].grad.double()).cpu()
+        scale = max(ref.abs().max().item(), 1e-12)
+        assert (g - ref.double()).abs().max().item() / scale < 2e-3, name
+        checked += 1
+    assert checked >= 30

@@ -655,7 +655,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   if (phase != 2) {
   // ================= bucket 0: DEER head =================
   // B1: last head layer + NIG activations (+ loss gradient)
-  TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
+  TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->targets ? a->global_stats : nullptr, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
                      L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
   if (!f32 && env_chain()) {
     // the four dX GEMMs of the head (evidence_net layers 3 and 0, feature_processor) as one row-block chain launch
@@ -874,6 +874,15 @@ int mmdeer_trimodal_attn_bwd(const void* qkv, const void* dobar, const float* pr
                              int act_f32, int training, float dropout_p, uint64_t seed, uint64_t offset, void* stream) {
   const DropCtx dc = make_drop(dropout_p, seed, offset);
   return launch_tri_attn_bwd(qkv, dobar, probs, dqkv, B, act_f32, (training && dropout_p > 0.f) ? 1 : 0, dc, (hipStream_t)stream);
+}
+
+int mmdeer_loss_stats(const void* workspace, size_t workspace_bytes, int batch, int compute_f32, float* out, void* stream) {
+  static_assert(MMDEER_GLOBAL_STATS == NIG_GLOBAL_STATS, "public header out of sync with nig.h");
+  MMDEER_CHECK(workspace && out, "loss_stats: NULL argument");
+  MMDEER_CHECK(batch > 0, "loss_stats: batch must be > 0 (got %d)", batch);
+  const Layout L = make_layout(const_cast<void*>(workspace), batch, compute_f32 ? 1 : 0);
+  MMDEER_CHECK(workspace_bytes >= L.bytes, "loss_stats: workspace of %zu bytes is smaller than the %zu of this batch", workspace_bytes, L.bytes);
+  return launch_nig_stats_sum(L.stats, batch, out, (hipStream_t)stream);
 }
 
 long long mmdeer_nig_stats_elems(int B) { return (long long)nig_nblocks(B) * 3 * NIG_NSTAT; }

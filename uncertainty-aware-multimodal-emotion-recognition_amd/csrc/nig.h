@@ -6,6 +6,7 @@
 namespace mmdeer {
 
 constexpr int NIG_NSTAT = 35;      // per (block, dim): 5 sums + 10 bins x {sum conf, sum err, count}
+constexpr int NIG_GLOBAL_STATS = 3 * NIG_NSTAT + 1;   // summed block partials of the three dims + the batch size (exact-global loss)
 constexpr int NIG_LOSS_OUT = 20;   // per dim {total, nll, reg, kl, ece} x 3, cross, total, mean nll, mean reg, mean kl
 
 struct LossCfg {
@@ -30,10 +31,15 @@ int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_strid
 //   chain mode (targets == null): gmu/gnu/galpha/gbeta [B,3] fp32 (each may be null) are upstream gradients.
 // Outputs: devid [B,3,4] fp32 (may be null), dz2 [B,192] (activation dtype; already multiplied by the
 // ReLU/dropout mask of e2), partial_w [nblk][3][4][64], partial_b [nblk][3][4].
+// gstats (optional, loss mode): NIG_GLOBAL_STATS floats that REPLACE the block partials -- the statistics of the global
+// batch (sum over ranks of launch_nig_stats_sum's output); the loss and its gradient then are those of the global batch.
 int launch_nig_bwd(const void* e2, const void* w3, const float* evid, const float* targets, const float* stats,
-                   const float* gmu, const float* gnu, const float* galpha, const float* gbeta,
+                   const float* gstats, const float* gmu, const float* gnu, const float* galpha, const float* gbeta,
                    float* devid, void* dz2, float* partial_w, float* partial_b, float* loss_out, int* bin_counts,
                    int B, int act_f32, float mask_scale, const LossCfg& cfg, hipStream_t s);
+
+// out[d][k] = sum over the nblk block partials of stats, out[3 * NIG_NSTAT] = B
+int launch_nig_stats_sum(const float* stats, int B, float* out, hipStream_t s);
 
 // Standalone loss on given NIG parameters (the `nig_loss` op of the C-ABI): same statistics / gradient code,
 // inputs are gamma, nu, alpha, beta [B,3]; outputs loss_out[17], bin_counts[30] and (optional) d{gamma,nu,alpha,beta}.

@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) void nig_fwd_kernel(const void* e2, const void
 // ------------------------------------------------------------------ backward of the last head layer
 template <bool F32>
 __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void* w3, const float* evid, const float* targets,
-                                                      const float* stats, const float* gmu, const float* gnu,
-                                                      const float* galpha, const float* gbeta, float* devid, void* dz2,
+                                                      const float* stats, const float* gstats, const float* gmu,
+                                                      const float* gnu, const float* galpha, const float* gbeta, float* devid, void* dz2,
                                                       float* partial_w, float* partial_b, float* loss_out,
                                                       int* bin_counts, int B, float mask_scale, LossCfg cfg) {
   __shared__ float gs[3][NIG_NSTAT];
@@ -297,11 +297,13 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
   f32x4 g{0.f, 0.f, 0.f, 0.f};
   if (loss_mode) {
     const float y = targets[o];
-    compute_finals(stats, nblk, B, cfg, F, gs);
+    // exact-global mode: the statistics of all ranks' batches (already summed), N = the global batch size
+    const int stat_n = gstats ? (int)gstats[3 * NIG_NSTAT] : B;
+    compute_finals(gstats ? gstats : stats, gstats ? 1 : nblk, stat_n, cfg, F, gs);
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) write_loss(F, loss_out, bin_counts);
     const Nig n = nig_act(ev);
     const Terms t = loss_terms(n, y);
-    g = loss_grad(n, t, d, B, cfg, F);
+    g = loss_grad(n, t, d, stat_n, cfg, F);
   } else {
     if (gmu) g.x = gmu[o];
     if (gnu) g.y = gnu[o];
@@ -386,17 +388,35 @@ int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_strid
   return 0;
 }
 
+__global__ __launch_bounds__(128) void nig_stats_sum_kernel(const float* stats, int nblk, int B, float* out) {
+  const int i = threadIdx.x;
+  if (i < 3 * NIG_NSTAT) {
+    float acc = 0.f;
+    for (int p = 0; p < nblk; ++p) acc += stats[(long long)p * 3 * NIG_NSTAT + i];   // same order as compute_finals
+    out[i] = acc;
+  } else if (i == 3 * NIG_NSTAT) {
+    out[i] = (float)B;
+  }
+}
+
+int launch_nig_stats_sum(const float* stats, int B, float* out, hipStream_t s) {
+  MMDEER_CHECK(B > 0, "nig statistics need a non-empty batch");
+  hipLaunchKernelGGL(nig_stats_sum_kernel, dim3(1), dim3(128), 0, s, stats, nig_nblocks(B), B, out);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_nig_bwd(const void* e2, const void* w3, const float* evid, const float* targets, const float* stats,
-                   const float* gmu, const float* gnu, const float* galpha, const float* gbeta,
+                   const float* gstats, const float* gmu, const float* gnu, const float* galpha, const float* gbeta,
                    float* devid, void* dz2, float* partial_w, float* partial_b, float* loss_out, int* bin_counts,
                    int B, int act_f32, float mask_scale, const LossCfg& cfg, hipStream_t s) {
   MMDEER_CHECK(B > 0, "nig backward needs a non-empty batch");
   dim3 grid(nig_nblocks(B), 3);
   if (act_f32)
-    hipLaunchKernelGGL(nig_bwd_kernel<true>, grid, dim3(256), 0, s, e2, w3, evid, targets, stats, gmu, gnu, galpha, gbeta,
+    hipLaunchKernelGGL(nig_bwd_kernel<true>, grid, dim3(256), 0, s, e2, w3, evid, targets, stats, gstats, gmu, gnu, galpha, gbeta,
                        devid, dz2, partial_w, partial_b, loss_out, bin_counts, B, mask_scale, cfg);
   else
-    hipLaunchKernelGGL(nig_bwd_kernel<false>, grid, dim3(256), 0, s, e2, w3, evid, targets, stats, gmu, gnu, galpha, gbeta,
+    hipLaunchKernelGGL(nig_bwd_kernel<false>, grid, dim3(256), 0, s, e2, w3, evid, targets, stats, gstats, gmu, gnu, galpha, gbeta,
                        devid, dz2, partial_w, partial_b, loss_out, bin_counts, B, mask_scale, cfg);
   MMDEER_HIP(hipGetLastError());
   return 0;

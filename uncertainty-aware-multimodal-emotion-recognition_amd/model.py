@@ -312,7 +312,8 @@ class MultimodalDEER(nn.Module):
                 "trimodal_features": trif, "av_attention": avw, "trimodal_attention": triw}
 
     def _launch_backward(self, ctx_or_meta, targets, g_mu=None, g_nu=None, g_alpha=None, g_beta=None,
-                         loss_out=None, bin_counts=None, events=None, flat=None, want_views=True, phase=0):
+                         loss_out=None, bin_counts=None, events=None, flat=None, want_views=True, phase=0,
+                         global_stats=None):
         lib = _lib.load()
         if isinstance(ctx_or_meta, dict):
             meta = ctx_or_meta
@@ -351,6 +352,7 @@ class MultimodalDEER(nn.Module):
             for i, ev in enumerate(events):
                 a.bucket_events[i] = ev.cuda_event
         a.phase = int(phase)
+        a.global_stats = _lib.ptr(global_stats)
         a.stream = _lib.current_stream()
         _lib.check(lib.mmdeer_backward(C.byref(a)))
         self._flat_grad = flat
@@ -409,10 +411,15 @@ class MultimodalDEER(nn.Module):
         return multitask_deer_loss(predictions, targets, self.loss_cfg)
 
     def train_step(self, audio, video, text, targets, events=None, prof_events=None, _offset_dev=None,
-                   return_features: bool = False, _bump: bool = False, comm=None) -> Dict[str, torch.Tensor]:
+                   return_features: bool = False, _bump: bool = False, comm=None, stats_comm=None) -> Dict[str, torch.Tensor]:
         """Fused forward + MultiTaskDEERLoss + backward: two library calls, gradients land in one flat buffer
         (``.grad`` of every live parameter is a view of it).  Equivalent to
-        ``compute_loss(model(a, v, t), y)['total_loss'].backward()``."""
+        ``compute_loss(model(a, v, t), y)['total_loss'].backward()``.
+
+        ``stats_comm`` (data parallel, optional): a communicator with ``sum_small(tensor)`` (``parallel.BucketedAllReduce``).
+        The 106 loss statistics of this rank's batch are summed across ranks between forward and backward, so the loss
+        is the global batch's (its ECE and cross-dimension terms are non-linear in batch statistics) and the
+        gradients are this rank's share of its gradient: exchange them with a SUM (``comm.exact_global = True``)."""
         # the fused step returns losses and gradients; the fp32 feature copies of forward()'s output dict are written
         # only on request (24 MB of stores per step at B = 4096 that nothing in training reads)
         o = self._launch_forward(audio, video, text, targets, prof_events, offset_dev=_offset_dev,
@@ -427,21 +434,27 @@ class MultimodalDEER(nn.Module):
         if self._step_flat is None or self._step_flat.device != dev:
             self._step_flat = torch.zeros(self._flat_elems, dtype=torch.float32, device=dev)
             self._step_views = None
+        gstats = None
+        if stats_comm is not None and getattr(stats_comm, "active", False):
+            gstats = torch.empty(106, dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().mmdeer_loss_stats(meta["ws"].data_ptr(), meta["ws"].numel(), meta["B"], self.compute_f32,
+                                                     gstats.data_ptr(), _lib.current_stream()))
+            stats_comm.sum_small(gstats)
         if comm is not None and getattr(comm, "active", False):
             # data parallel, overlapped: the backward pass in two calls; the all-reduce of buckets 0-1 (head, output
             # projection, trimodal fusion: 89 % of the gradient) runs on the communicator's side stream while the
             # audio-visual part of the pass, its weight gradients and their reduction are computed
             lo = int(_lib.load().mmdeer_bucket_end(2))
             self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, flat=self._step_flat,
-                                  want_views=False, phase=1)
+                                  want_views=False, phase=1, global_stats=gstats)
             comm.launch_range(self._step_flat, lo, self._flat_elems)
             views = self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, flat=self._step_flat,
-                                          want_views=self._step_views is None, phase=2)
+                                          want_views=self._step_views is None, phase=2, global_stats=gstats)
             comm.launch_range(self._step_flat, 0, lo)
             comm.join()
         else:
             views = self._launch_backward(meta, meta["targets"], loss_out=loss_out, bin_counts=bins, events=events,
-                                          flat=self._step_flat, want_views=self._step_views is None)
+                                          flat=self._step_flat, want_views=self._step_views is None, global_stats=gstats)
         if self._step_views is None:
             self._step_views = views
             self._grads_bound = False
@@ -459,7 +472,7 @@ class MultimodalDEER(nn.Module):
     def flat_grad(self) -> Optional[torch.Tensor]:
         return self._flat_grad
 
-    def capture_train_step(self, audio, video, text, targets, events=None, after=None, comm=None):
+    def capture_train_step(self, audio, video, text, targets, events=None, after=None, comm=None, stats_comm=None):
         """Capture ``train_step`` on these (static) input tensors into a HIP graph and return ``replay()``.
 
         One step is ~45 kernel launches of 4-40 us each; enqueueing them from the host costs about as much as the GPU
@@ -478,7 +491,7 @@ class MultimodalDEER(nn.Module):
         dev = audio.device
         # eager warm-up: allocates the workspace and the persistent gradient buffer, packs the weights.  It is a real
         # step on the given batch: its loss dict is returned as ``replay.first`` and its gradients are in place
-        first = self.train_step(audio, video, text, targets, comm=comm)
+        first = self.train_step(audio, video, text, targets, comm=comm, stats_comm=stats_comm)
         self._graph_counter = torch.full((), int(self._step), dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
@@ -487,7 +500,7 @@ class MultimodalDEER(nn.Module):
             if not in_kernel:
                 self._graph_counter.add_(1)
             out = self.train_step(audio, video, text, targets, events=events, _offset_dev=self._graph_counter, _bump=in_kernel,
-                                  comm=comm)
+                                  comm=comm, stats_comm=stats_comm)
             if after is not None:
                 after()
         self._graph = graph

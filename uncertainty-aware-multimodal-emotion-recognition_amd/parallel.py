@@ -92,6 +92,9 @@ class BucketedAllReduce:
         self.payload = payload
         if backend == "rccl" and self.cuda and (self.world > 1 or self.force):
             self._rccl = RcclCommunicator.from_torch_distributed(group)
+        # exact-global loss (optional): ranks exchange the loss statistics between forward and backward
+        # (sum_small), each rank's gradient then is its SHARE of the global-batch gradient and the exchange is a SUM
+        self.exact_global = False
         self.events = None
         self._work: List = []
         self._half: Optional[torch.Tensor] = None
@@ -120,11 +123,22 @@ class BucketedAllReduce:
         self._flat = flat
 
     def _reduce(self, t: torch.Tensor):
-        """Averaged all-reduce of a GPU tensor behind the work already on the current stream; returns a waitable or None."""
+        """All-reduce of a GPU tensor (mean over ranks; SUM in exact-global mode) behind the work already on the current
+        stream; returns a waitable or None."""
+        avg = not self.exact_global
         if self._rccl is not None:
-            self._rccl.all_reduce(t, average=True)      # enqueued on the current stream: nothing to wait for
+            self._rccl.all_reduce(t, average=avg)       # enqueued on the current stream: nothing to wait for
             return None
-        return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def sum_small(self, t: torch.Tensor) -> None:
+        """In-place SUM all-reduce of a small fp32 tensor (the loss statistics), ordered on the current stream."""
+        if self.world == 1 and not self.force:
+            return
+        if self._rccl is not None:
+            self._rccl.all_reduce(t, average=False)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     # ---- overlapped form (GPU): the exchange of a slice of the flat buffer on a side stream, forked from / joined to
     #      the current stream by events -- capturable into a HIP graph together with the step (model.train_step(comm=...))
@@ -169,7 +183,7 @@ class BucketedAllReduce:
                 w.wait()
         if self.cuda and self.payload == "bf16" and self._work:
             self._convert(self._half, self._flat)
-        if not self.cuda and flat is not None:
+        if not self.cuda and flat is not None and not self.exact_global:
             flat.div_(self.world)
         self._work = []
 

@@ -136,7 +136,9 @@ class DEERTrainer:
                 # no zero_grad(): the fused step overwrites every live gradient slice of the flat buffer
                 ld = self._graph_step(a, v, t, y) if self._graph_ok(a) else None
                 if ld is None:
-                    ld = self.model.train_step(a, v, t, y, events=events)     # forward + loss + backward, fused
+                    # forward + loss + backward, fused; a communicator in exact-global mode also sums the loss statistics
+                    sc = self.comm if getattr(self.comm, "exact_global", False) else None
+                    ld = self.model.train_step(a, v, t, y, events=events, stats_comm=sc)
                 if self.comm is not None:
                     self.comm.launch(self.model.flat_grad())
                     self.comm.wait(self.model.flat_grad())
