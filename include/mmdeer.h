@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 7
+#define MMDEER_ABI_VERSION 8
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -202,6 +202,26 @@ long long mmdeer_nig_stats_elems(int B);
 int mmdeer_nig_loss(const float* gamma, const float* nu, const float* alpha, const float* beta, const float* targets,
                     float* stats, float* dgamma, float* dnu, float* dalpha, float* dbeta, float* loss_out,
                     int32_t* bin_counts, int B, const mmdeer_loss_cfg* cfg, void* stream);
+
+/* ---- the other loss classes of the path (a10, a13).  All tensors fp32, dense; gradient pointers are all
+ * NULL (values only) or all set (gradient of the total, scaled for a mean over the n elements).
+ *
+ * deer.DEERLoss.forward (reference src/models/deer.py:125-195, loss variant 1) on n elements (mu, nu, alpha, beta and
+ * targets of one shape): loss_out[5] = total, nll_loss, evidence_reg, kl_reg, mse with
+ * total = mean(nll) + evidence_weight * mean(reg) + kl_weight * mean(clamp(kl, 0)).
+ * scratch: mmdeer_deer_loss_v1_scratch(n) floats. */
+long long mmdeer_deer_loss_v1_scratch(long long n);
+int mmdeer_deer_loss_v1(const float* mu, const float* nu, const float* alpha, const float* beta, const float* targets,
+                        long long n, float evidence_weight, float kl_weight, float* loss_out, float* dmu, float* dnu,
+                        float* dalpha, float* dbeta, float* scratch, void* stream);
+/* losses.UncertaintyRegularizationLoss.forward with flat keys (src/utils/losses.py:363-416): alpha, beta [B][D], D <= 8;
+ * loss_out[3] = reg_loss (= dw * diversity + sw * sparsity), diversity_loss, sparsity_loss. */
+int mmdeer_uncertainty_reg_loss(const float* alpha, const float* beta, int B, int D, float diversity_weight,
+                                float sparsity_weight, float* loss_out, float* dalpha, float* dbeta, void* stream);
+/* losses.CalibrationLoss.forward, n_bins = 15, 'uniform' (src/utils/losses.py:431-497) on n flattened elements:
+ * loss_out[1]; bin_counts[15] (optional) are the exact bin populations. */
+int mmdeer_calibration_loss(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
+                            float* loss_out, int32_t* bin_counts, float* dgamma, float* dalpha, float* dbeta, void* stream);
 
 /* keep-mask of one dropout site, for test harnesses: out[r*cols + c] in {0,1} */
 int mmdeer_dropout_mask(int site, int rows, int cols, float dropout_p, uint64_t seed, uint64_t offset,

@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/mmdeer.h but not exported"
     bound = {n for n, _, _ in _lib.SYMBOLS}
     assert bound == set(declared), (bound ^ set(declared))
-    assert lib.mmdeer_abi_version() == 7
+    assert lib.mmdeer_abi_version() == 8
     assert b"gfx950" in lib.mmdeer_version()
 
 
@@ -173,3 +173,26 @@ def test_stackb_state_dict_matches_the_reference_names():
     assert float(w.abs().max()) <= (6.0 / (512 + 512)) ** 0.5 + 1e-6 and float(w.std()) > 0.02
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.eval()(torch.zeros(2, 84), torch.zeros(2, 256), torch.zeros(2, 768))
+
+
+def test_loss_classes_keep_the_reference_protocol_and_refuse_cpu_tensors():
+    """mmdeer.losses mirrors the constructor / call protocol of the reference's loss classes (deer.py:111-195,
+    losses.py:40-601); without a GPU every numeric call fails loudly, the key-lookup fallbacks behave as in the reference."""
+    import torch
+    from mmdeer import losses
+    assert isinstance(losses.create_deer_loss("basic", {"reg_weight": 0.2}), losses.DEERLoss)
+    assert isinstance(losses.create_deer_loss("MultiTask"), losses.MultiTaskDEERLoss)
+    comb = losses.create_deer_loss()
+    assert isinstance(comb, losses.CombinedDEERLoss) and comb.use_calibration_loss and comb.calibration_loss.n_bins == 15
+    with pytest.raises(ValueError, match="Unknown loss type"):
+        losses.create_deer_loss("focal")
+    with pytest.raises(NotImplementedError):
+        losses.MultiTaskDEERLoss(emotion_dims=["valence"])
+    pred = {k: torch.ones(4, 1) for k in ("mu", "nu", "alpha", "beta")}
+    for fn in (losses.DEERLossV1(), losses.DEERLoss(), losses.UncertaintyRegularizationLoss(), losses.CalibrationLoss()):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            fn(pred, torch.zeros(4))
+    # flat keys absent: the two extra terms return 0 exactly as the reference does (losses.py:379-380, 447-448)
+    per_dim = {"valence_alpha": torch.ones(4, 1)}
+    assert float(losses.UncertaintyRegularizationLoss()(per_dim, torch.zeros(4))["reg_loss"]) == 0.0
+    assert float(losses.CalibrationLoss()(per_dim, torch.zeros(4))) == 0.0

@@ -144,6 +144,10 @@ SYMBOLS = [
     ("mmdeer_trimodal_attn_bwd", c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p]),
     ("mmdeer_nig_stats_elems", c_ll, [c_int]),
     ("mmdeer_nig_loss", c_int, [c_void_p] * 12 + [c_int, C.POINTER(LossCfg), c_void_p]),
+    ("mmdeer_deer_loss_v1_scratch", c_ll, [c_ll]),
+    ("mmdeer_deer_loss_v1", c_int, [c_void_p] * 5 + [c_ll, c_float, c_float] + [c_void_p] * 6 + [c_void_p]),
+    ("mmdeer_uncertainty_reg_loss", c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("mmdeer_calibration_loss", c_int, [c_void_p] * 4 + [c_ll] + [c_void_p] * 5 + [c_void_p]),
     ("mmdeer_dropout_mask", c_int, [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p]),
     ("mmdeer_adamw_step", c_int, [C.POINTER(AdamWArgs)]),
     ("mmdeer_cross_modal_attn_fwd", c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
@@ -192,7 +196,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 7:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 8:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         _LIB = lib
     return _LIB

@@ -885,6 +885,32 @@ int mmdeer_loss_stats(const void* workspace, size_t workspace_bytes, int batch, 
   return launch_nig_stats_sum(L.stats, batch, out, (hipStream_t)stream);
 }
 
+long long mmdeer_deer_loss_v1_scratch(long long n) { return n > 0 ? 4ll * deer_v1_nblocks(n) : 0; }
+int mmdeer_deer_loss_v1(const float* mu, const float* nu, const float* alpha, const float* beta, const float* targets,
+                        long long n, float evidence_weight, float kl_weight, float* loss_out, float* dmu, float* dnu,
+                        float* dalpha, float* dbeta, float* scratch, void* stream) {
+  MMDEER_CHECK(mu && nu && alpha && beta && targets && loss_out && scratch, "deer_loss_v1: NULL argument");
+  MMDEER_CHECK(n > 0, "deer_loss_v1: n must be > 0 (got %lld)", n);
+  const int ng = (dmu != nullptr) + (dnu != nullptr) + (dalpha != nullptr) + (dbeta != nullptr);
+  MMDEER_CHECK(ng == 0 || ng == 4, "deer_loss_v1: pass all four gradient buffers or none");
+  return launch_deer_loss_v1(mu, nu, alpha, beta, targets, n, evidence_weight, kl_weight, loss_out, dmu, dnu, dalpha, dbeta, scratch,
+                             (hipStream_t)stream);
+}
+int mmdeer_uncertainty_reg_loss(const float* alpha, const float* beta, int B, int D, float diversity_weight,
+                                float sparsity_weight, float* loss_out, float* dalpha, float* dbeta, void* stream) {
+  MMDEER_CHECK(alpha && beta && loss_out, "uncertainty_reg_loss: NULL argument");
+  MMDEER_CHECK((dalpha != nullptr) == (dbeta != nullptr), "uncertainty_reg_loss: pass both gradient buffers or none");
+  return launch_unc_reg_loss(alpha, beta, B, D, diversity_weight, sparsity_weight, loss_out, dalpha, dbeta, (hipStream_t)stream);
+}
+int mmdeer_calibration_loss(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
+                            float* loss_out, int32_t* bin_counts, float* dgamma, float* dalpha, float* dbeta, void* stream) {
+  MMDEER_CHECK(gamma && alpha && beta && targets && loss_out, "calibration_loss: NULL argument");
+  MMDEER_CHECK(n > 0, "calibration_loss: n must be > 0 (got %lld)", n);
+  const int ng = (dgamma != nullptr) + (dalpha != nullptr) + (dbeta != nullptr);
+  MMDEER_CHECK(ng == 0 || ng == 3, "calibration_loss: pass all three gradient buffers or none");
+  return launch_calibration_loss(gamma, alpha, beta, targets, n, loss_out, bin_counts, dgamma, dalpha, dbeta, (hipStream_t)stream);
+}
+
 long long mmdeer_nig_stats_elems(int B) { return (long long)nig_nblocks(B) * 3 * NIG_NSTAT; }
 int mmdeer_nig_loss(const float* gamma, const float* nu, const float* alpha, const float* beta, const float* targets,
                     float* stats, float* dgamma, float* dnu, float* dalpha, float* dbeta, float* loss_out,

@@ -49,4 +49,17 @@ int launch_nig_loss_grad(const float* gamma, const float* nu, const float* alpha
                          const float* targets, const float* stats, float* dgamma, float* dnu, float* dalpha,
                          float* dbeta, float* loss_out, int* bin_counts, int B, const LossCfg& cfg, hipStream_t s);
 
+// deer.DEERLoss (loss variant 1, deer.py:111-195) on n elements: loss_out[5] = total, nll, evidence_reg, kl_reg, mse;
+// partial: deer_v1_nblocks(n) * 4 floats of scratch; the four gradient pointers are all null or all set.
+int deer_v1_nblocks(long long n);
+int launch_deer_loss_v1(const float* mu, const float* nu, const float* alpha, const float* beta, const float* targets, long long n,
+                        float ew, float kw, float* loss_out, float* dmu, float* dnu, float* dalpha, float* dbeta, float* partial,
+                        hipStream_t s);
+// losses.UncertaintyRegularizationLoss, flat keys (losses.py:351-416): loss_out[3] = reg_loss, diversity, sparsity
+int launch_unc_reg_loss(const float* alpha, const float* beta, int B, int D, float dw, float sw, float* loss_out, float* dalpha,
+                        float* dbeta, hipStream_t s);
+// losses.CalibrationLoss, 15 uniform bins (losses.py:419-497): loss_out[1], bin_counts[15] (optional)
+int launch_calibration_loss(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
+                            float* loss_out, int* bin_counts, float* dgamma, float* dalpha, float* dbeta, hipStream_t s);
+
 }  // namespace mmdeer

@@ -376,6 +376,176 @@ __global__ __launch_bounds__(256) void nig_loss_grad_kernel(const float* gamma, 
   dgamma[o] = g.x; dnu[o] = g.y; dalpha[o] = g.z; dbeta[o] = g.w;
 }
 
+// ------------------------------------------------------------------ the other loss classes of the path (a10, a13)
+// Small, HBM-trivial reductions: deterministic (fixed-order tree sums, no atomics), forward values and the gradient of
+// the total in one pass.
+
+// block sum of K values per thread (256 threads): wave DPP sum, then the four waves in a fixed order
+template <int K>
+__device__ __forceinline__ void block_sum(float (&v)[K], float (*sm)[K]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const float s = wave_sum(v[i]);
+    if (lane == 0) sm[wave][i] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < K; ++i) v[i] = (sm[0][i] + sm[1][i]) + (sm[2][i] + sm[3][i]);
+  __syncthreads();
+}
+
+// deer.DEERLoss (deer.py:111-195, loss variant 1) over n elements; partial: [gridDim.x][4] = sums of nll, reg, kl, se.
+// Gradients of  mean(nll) + ew mean(reg) + kw mean(kl)  are written when the pointers are non-null.
+__global__ __launch_bounds__(256) void deer_v1_kernel(const float* mu, const float* nu, const float* alpha, const float* beta,
+                                                      const float* targets, long long n, float ew, float kw, float* partial,
+                                                      float* dmu, float* dnu, float* dalpha, float* dbeta) {
+  __shared__ float sm[4][4];
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    const float m = mu[i], nv = nu[i], a = alpha[i], b = beta[i], y = targets[i];
+    const float d = y - m, se = d * d, ah = a + 0.5f;
+    const float om = b + nv * se / 2.f;
+    const float kPi = 3.14159265358979323846f;
+    const float nll = 0.5f * logf(kPi / nv) - a * logf(2.f * b) + lgammaf(a) - lgammaf(ah) + ah * logf(om);   // deer.py:150-158
+    const float reg = (nv * se + 2.f * b * (1.f + nv)) / (2.f * nv * (1.f + nv));                              // deer.py:161-163
+    const float klr = 0.5f * (nv - 1.f) + a * logf(b) - lgammaf(a) + lgammaf(ah) - 0.5f * logf(2.f * kPi * b);   // deer.py:188-194
+    v[0] = nll; v[1] = reg; v[2] = fmaxf(klr, 0.f); v[3] = se;
+    if (klr != klr) v[2] = klr;   // torch.clamp propagates NaN
+    if (dmu) {
+      const float inv = 1.f / (float)n, dpsi = digamma(a) - digamma(ah);
+      const float kg = (klr >= 0.f) ? kw : 0.f;          // clamp(min=0) passes the gradient where kl >= 0
+      const float g_mu = -ah * nv * d / om - ew * d / (1.f + nv);
+      const float g_nu = -0.5f / nv + ah * (se / 2.f) / om + ew * (-se / (2.f * (1.f + nv) * (1.f + nv)) - b / (nv * nv)) + kg * 0.5f;
+      const float g_al = -logf(2.f * b) + dpsi + logf(om) + kg * (logf(b) - dpsi);
+      const float g_be = -a / b + ah / om + ew / nv + kg * (a / b - 0.5f / b);
+      dmu[i] = g_mu * inv; dnu[i] = g_nu * inv; dalpha[i] = g_al * inv; dbeta[i] = g_be * inv;
+    }
+  }
+  block_sum<4>(v, sm);
+  if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = v[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void deer_v1_final_kernel(const float* partial, int nblk, long long n, float ew, float kw,
+                                                            float* loss_out) {
+  __shared__ float sm[4][4];
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += partial[b * 4 + k];
+  block_sum<4>(v, sm);
+  if (threadIdx.x == 0) {
+    const float inv = 1.f / (float)n;
+    const float nll = v[0] * inv, reg = v[1] * inv, kl = v[2] * inv;
+    loss_out[0] = nll + ew * reg + kw * kl; loss_out[1] = nll; loss_out[2] = reg; loss_out[3] = kl; loss_out[4] = v[3] * inv;
+  }
+}
+
+// losses.UncertaintyRegularizationLoss with flat keys (losses.py:351-416): u = beta / (alpha - 1 + 1e-8) on [B][D];
+// diversity = -log(mean_d var_B(u) + 1e-8) (unbiased variance), sparsity = mean(u).  One workgroup (B*D is a few thousand).
+constexpr int UREG_MAX_D = 8;
+__global__ __launch_bounds__(256) void unc_reg_kernel(const float* alpha, const float* beta, int B, int D, float dw, float sw,
+                                                      float* loss_out, float* dalpha, float* dbeta) {
+  __shared__ float sm[4][UREG_MAX_D];
+  __shared__ float mean[UREG_MAX_D], coef[UREG_MAX_D];
+  float v[UREG_MAX_D];
+#pragma unroll
+  for (int d = 0; d < UREG_MAX_D; ++d) v[d] = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256)
+#pragma unroll
+    for (int d = 0; d < UREG_MAX_D; ++d)
+      if (d < D) v[d] += beta[(long long)b * D + d] / (alpha[(long long)b * D + d] - 1.f + kEps);
+  block_sum<UREG_MAX_D>(v, sm);
+  float total = 0.f;
+#pragma unroll
+  for (int d = 0; d < UREG_MAX_D; ++d)
+    if (d < D) { total += v[d]; if (threadIdx.x == 0) mean[d] = v[d] / (float)B; }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < UREG_MAX_D; ++d) v[d] = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256)
+#pragma unroll
+    for (int d = 0; d < UREG_MAX_D; ++d)
+      if (d < D) {
+        const float c = beta[(long long)b * D + d] / (alpha[(long long)b * D + d] - 1.f + kEps) - mean[d];
+        v[d] += c * c;
+      }
+  block_sum<UREG_MAX_D>(v, sm);
+  float vm = 0.f;
+#pragma unroll
+  for (int d = 0; d < UREG_MAX_D; ++d)
+    if (d < D) vm += v[d] / (float)(B - 1);          // torch.var: unbiased (B = 1 gives NaN, as in the reference)
+  vm /= (float)D;
+  const float div = -logf(vm + kEps), spars = total / ((float)B * (float)D);
+  if (threadIdx.x == 0) { loss_out[0] = dw * div + sw * spars; loss_out[1] = div; loss_out[2] = spars; }
+  if (!dalpha) return;
+  // d div / d u_bd = -1/(vm + eps) * (1/D) * 2 (u_bd - mean_d) / (B - 1);  d spars / d u_bd = 1 / (B D)
+  const float cdiv = -dw / (vm + kEps) * 2.f / ((float)D * (float)(B - 1)), cs = sw / ((float)B * (float)D);
+  for (long long e = threadIdx.x; e < (long long)B * D; e += 256) {
+    const int d = (int)(e % D);
+    const float den = alpha[e] - 1.f + kEps, u = beta[e] / den;
+    const float gu = cdiv * (u - mean[d]) + cs;
+    dalpha[e] = gu * (-u / den);
+    dbeta[e] = gu / den;
+  }
+  (void)coef;
+}
+
+// losses.CalibrationLoss, 15 uniform bins (losses.py:419-497): torch.linspace(0, 1, 16) in fp32 is NOT float32(i)/15
+__device__ const float kCalEdges[16] = {0.0f, 0x1.111112p-4f, 0x1.111112p-3f, 0x1.99999cp-3f, 0x1.111112p-2f, 0x1.555556p-2f,
+                                        0x1.99999cp-2f, 0x1.dddde0p-2f, 0x1.111110p-1f, 0x1.333332p-1f, 0x1.555554p-1f,
+                                        0x1.777778p-1f, 0x1.99999ap-1f, 0x1.bbbbbcp-1f, 0x1.dddddep-1f, 1.0f};
+__device__ __forceinline__ int cal_bin(float conf) {
+  int bin = -1;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    const bool in = conf >= kCalEdges[k] && (k == 14 ? conf <= kCalEdges[k + 1] : conf < kCalEdges[k + 1]);   // [lo, hi), last [lo, hi]
+    if (in) bin = k;
+  }
+  return bin;
+}
+__global__ __launch_bounds__(256) void calibration_kernel(const float* gamma, const float* alpha, const float* beta,
+                                                          const float* targets, long long n, float* loss_out, int* bin_counts,
+                                                          float* dgamma, float* dalpha, float* dbeta) {
+  __shared__ float sm[4][3];
+  __shared__ float sgn[15];
+  float loss = 0.f;
+  for (int k = 0; k < 15; ++k) {     // 15 passes over a few thousand elements: each bin's three sums in a fixed order
+    float v[3] = {0.f, 0.f, 0.f};
+    for (long long i = threadIdx.x; i < n; i += 256) {
+      const float conf = 1.0f / (1.0f + beta[i] / (alpha[i] - 1.f + kEps));
+      if (cal_bin(conf) == k) {
+        const float err = fabsf(targets[i] - gamma[i]);
+        v[0] += 1.f; v[1] += conf; v[2] += 1.0f - fminf(fmaxf(err / 2.0f, 0.f), 1.f);
+      }
+    }
+    block_sum<3>(v, sm);
+    float sg = 0.f;
+    if (v[0] > 0.f) {
+      const float diff = v[1] / v[0] - v[2] / v[0];
+      loss += (v[0] / (float)n) * fabsf(diff);
+      sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+    }
+    if (threadIdx.x == 0) { sgn[k] = sg; if (bin_counts) bin_counts[k] = (int)v[0]; }
+  }
+  if (threadIdx.x == 0) loss_out[0] = loss;
+  __syncthreads();
+  if (!dgamma) return;
+  const float inv = 1.f / (float)n;
+  for (long long i = threadIdx.x; i < n; i += 256) {
+    const float den = alpha[i] - 1.f + kEps, u = beta[i] / den, conf = 1.0f / (1.0f + u);
+    const int b = cal_bin(conf);
+    const float s = b >= 0 ? sgn[b] * inv : 0.f;        // d loss / d conf_i = s, d loss / d acc_i = -s
+    const float d = targets[i] - gamma[i], h = fabsf(d) / 2.0f;
+    const float sd = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    dgamma[i] = (h >= 0.f && h <= 1.f) ? -s * 0.5f * sd : 0.f;    // acc = 1 - |y - gamma| / 2 inside the clamp
+    const float gu = -s * conf * conf;
+    dalpha[i] = gu * (-u / den);
+    dbeta[i] = gu / den;
+  }
+}
+
 }  // namespace
 
 int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_stride, float* evid, float* nig_out,
@@ -436,6 +606,35 @@ int launch_nig_loss_grad(const float* gamma, const float* nu, const float* alpha
   MMDEER_CHECK(B > 0, "nig loss needs a non-empty batch");
   hipLaunchKernelGGL(nig_loss_grad_kernel, dim3((B + 255) / 256, 3), dim3(256), 0, s, gamma, nu, alpha, beta, targets, stats,
                      dgamma, dnu, dalpha, dbeta, loss_out, bin_counts, B, cfg);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int deer_v1_nblocks(long long n) { return (int)((n + 255) / 256); }
+
+int launch_deer_loss_v1(const float* mu, const float* nu, const float* alpha, const float* beta, const float* targets, long long n,
+                        float ew, float kw, float* loss_out, float* dmu, float* dnu, float* dalpha, float* dbeta, float* partial,
+                        hipStream_t s) {
+  MMDEER_CHECK(n > 0, "deer loss needs a non-empty batch");
+  const int nblk = deer_v1_nblocks(n);
+  hipLaunchKernelGGL(deer_v1_kernel, dim3(nblk), dim3(256), 0, s, mu, nu, alpha, beta, targets, n, ew, kw, partial, dmu, dnu, dalpha, dbeta);
+  hipLaunchKernelGGL(deer_v1_final_kernel, dim3(1), dim3(256), 0, s, partial, nblk, n, ew, kw, loss_out);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_unc_reg_loss(const float* alpha, const float* beta, int B, int D, float dw, float sw, float* loss_out, float* dalpha,
+                        float* dbeta, hipStream_t s) {
+  MMDEER_CHECK(B > 0 && D >= 1 && D <= UREG_MAX_D, "uncertainty regularisation: B=%d must be > 0 and D=%d in 1..8", B, D);
+  hipLaunchKernelGGL(unc_reg_kernel, dim3(1), dim3(256), 0, s, alpha, beta, B, D, dw, sw, loss_out, dalpha, dbeta);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_calibration_loss(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
+                            float* loss_out, int* bin_counts, float* dgamma, float* dalpha, float* dbeta, hipStream_t s) {
+  MMDEER_CHECK(n > 0, "calibration loss needs a non-empty batch");
+  hipLaunchKernelGGL(calibration_kernel, dim3(1), dim3(256), 0, s, gamma, alpha, beta, targets, n, loss_out, bin_counts, dgamma, dalpha, dbeta);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
