@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 8
+#define MMDEER_ABI_VERSION 9
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -145,6 +145,9 @@ typedef struct mmdeer_backward_args {
    * each rank's share of ITS gradient -- exchange them with a SUM, not a mean.  NULL: the statistics of this call's own
    * batch (DDP semantics, the default).  Used with `targets` only. */
   const float* global_stats;
+  /* Optional upstream gradient wrt the fused_features output [B][512] fp32 (a consumer of that output other than the
+   * DEER head): added to the head's own gradient before the output_projection backward.  Either mode. */
+  const float* g_fused;
   void* stream;
 } mmdeer_backward_args;
 

@@ -405,3 +405,45 @@ def test_exact_global_loss_over_two_shards_equals_the_global_batch():
         assert (g - ref.double()).abs().max().item() / scale < 2e-3, name
         checked += 1
     assert checked >= 30
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gradient_through_fused_features_reaches_the_fusion_parameters(dtype):
+    """fused_features is a differentiable output (fusion.py:164-171 hands it to whatever head the caller builds): a loss
+    on it alone, and one on it plus the NIG outputs, give the oracle's gradients."""
+    b = batch(40, seed=23)
+    a, v, t = (b[k].to(DEV) for k in ("audio", "video", "text"))
+    w = torch.from_numpy(synth.normal(999, 40 * 512).reshape(40, 512).astype(np.float32))
+    for with_head in (False, True):
+        m = make_model(dtype=dtype, dropout=0.0).train()
+        out = m(a, v, t)
+        loss = (out["fused_features"] * w.to(DEV)).sum()
+        if with_head:
+            loss = loss + (out["mu_all"] * 0.5).sum() + out["valence_uncertainty"].sum()
+        loss.backward()
+        P = oracle_params(m, requires_grad=True)
+        fo, ho = O.model_forward(P, b["audio"], b["video"], b["text"])
+        ref = (fo["fused_features"] * w).sum()
+        if with_head:
+            ref = ref + (ho["mu_all"] * 0.5).sum() + ho["valence_uncertainty"].sum()
+        ref.backward()
+        tol = 2e-3 if dtype == "fp32" else 8e-2
+        close = abs(float(loss) - float(ref)) / max(abs(float(ref)), 1.0)
+        assert close < (1e-4 if dtype == "fp32" else 3e-2)
+        named = dict(m.named_parameters())
+        checked = 0
+        for name, p in P.items():
+            if p.grad is None or named[name].grad is None:
+                continue
+            head = name.startswith("head.")
+            if head and not with_head:
+                assert float(named[name].grad.abs().max()) == 0.0, name      # nothing flows into the head
+                continue
+            g, r = named[name].grad.cpu().double().flatten(), p.grad.double().flatten()
+            if dtype == "fp32":
+                assert (g - r).abs().max().item() / max(r.abs().max().item(), 1e-12) < tol, name
+            else:
+                cos = float((g @ r) / (g.norm() * r.norm() + 1e-30))
+                assert cos > 0.95, (name, cos)
+            checked += 1
+        assert checked >= (20 if with_head else 12)

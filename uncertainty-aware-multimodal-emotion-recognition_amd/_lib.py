@@ -55,7 +55,7 @@ class BackwardArgs(C.Structure):
         ("targets", c_void_p), ("g_mu", c_void_p), ("g_nu", c_void_p), ("g_alpha", c_void_p), ("g_beta", c_void_p),
         ("loss", LossCfg),
         ("grads", c_void_p), ("loss_out", c_void_p), ("bin_counts", c_void_p),
-        ("bucket_events", c_void_p * 3), ("phase", c_int), ("global_stats", c_void_p), ("stream", c_void_p),
+        ("bucket_events", c_void_p * 3), ("phase", c_int), ("global_stats", c_void_p), ("g_fused", c_void_p), ("stream", c_void_p),
     ]
 
 
@@ -196,7 +196,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 8:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 9:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         _LIB = lib
     return _LIB

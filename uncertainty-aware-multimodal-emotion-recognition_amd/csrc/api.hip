@@ -691,6 +691,8 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     TRY(X.run1(X.dx(L.dh2, HID, P_FP1_W, L.dh1, HID, B, L.h1, HID)));
     TRY(X.run1(X.dx(L.dh1, HID, P_FP0_W, L.dfused, FUS, B, nullptr, 0)));
   }
+  // a gradient that reaches fused_features from outside the head (a caller's own consumer of that output)
+  if (a->g_fused) TRY(launch_add_f32(L.dfused, f32, a->g_fused, (long long)B * FUS, s));
   {
     GemmProblem q = X.dw(L.dz2, 3 * EV2, L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, G, B);
     q.batch = 3; q.sA = EV2; q.sB = EV1; q.sC = (long long)EV2 * EV1; q.sBiasGrad = EV2;

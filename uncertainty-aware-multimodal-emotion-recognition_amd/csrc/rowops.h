@@ -91,6 +91,9 @@ int launch_tile_pack(TilePackTable& t, void* dst_bf16, hipStream_t s);
 // keep-mask dump for the test harness: out[r*cols + c] = keep(site, r, c) ? 1 : 0   (c already in site granularity)
 int launch_dropout_mask(const DropCtx& d, int site, int rows, int cols, unsigned char* out, hipStream_t s);
 
+// dst[i] += src[i]: dst in the activation dtype, src fp32 (n % 4 == 0) -- an upstream gradient joining the chain
+int launch_add_f32(void* dst, int dst_f32, const float* src, long long n, hipStream_t s);
+
 // plain dtype conversion of a contiguous buffer (n % 4 == 0)
 int launch_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, hipStream_t s);
 

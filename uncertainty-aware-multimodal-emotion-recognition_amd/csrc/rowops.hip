@@ -338,6 +338,13 @@ __global__ __launch_bounds__(256) void convert_kernel(const void* src, void* dst
     store4<DF32>(dst, c * 4, load4<SF32>(src, c * 4));
 }
 
+// dst (activation dtype) += src (fp32)
+template <bool DF32>
+__global__ __launch_bounds__(256) void add_f32_kernel(void* dst, const float* src, long long n4) {
+  for (long long c = blockIdx.x * 256ll + threadIdx.x; c < n4; c += gridDim.x * 256ll)
+    store4<DF32>(dst, c * 4, load4<DF32>(dst, c * 4) + *reinterpret_cast<const f32x4*>(src + c * 4));
+}
+
 inline int grid_for(long long work, int per_block = 256, int cap = 2048) {
   long long g = (work + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -457,6 +464,16 @@ int launch_pad_cols(PadTable& t, hipStream_t s) {
 int launch_dropout_mask(const DropCtx& d, int site, int rows, int cols, unsigned char* out, hipStream_t s) {
   if ((long long)rows * cols == 0) return 0;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((long long)rows * cols)), dim3(256), 0, s, d, site, rows, cols, out);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_add_f32(void* dst, int dst_f32, const float* src, long long n, hipStream_t s) {
+  MMDEER_CHECK(n % 4 == 0, "add: n=%lld must be a multiple of 4", n);
+  if (n == 0) return 0;
+  const int grid = grid_for(n / 4);
+  if (dst_f32) hipLaunchKernelGGL(add_f32_kernel<true>, dim3(grid), dim3(256), 0, s, dst, src, n / 4);
+  else hipLaunchKernelGGL(add_f32_kernel<false>, dim3(grid), dim3(256), 0, s, dst, src, n / 4);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

@@ -101,11 +101,11 @@ class _ForwardFn(torch.autograd.Function):
                                                  out["trimodal_features"], out["av_attention"],
                                                  out["trimodal_attention"])
         ctx.save_for_backward(nig)
-        ctx.mark_non_differentiable(*res[7:])
+        ctx.mark_non_differentiable(*res[8:])      # fused_features (res[7]) is differentiable: callers hang their own heads on it
         return res
 
     @staticmethod
-    def backward(ctx, g_mu, g_nu, g_alpha, g_beta, g_alea, g_epis, g_unc, *_unused):
+    def backward(ctx, g_mu, g_nu, g_alpha, g_beta, g_alea, g_epis, g_unc, g_fused=None, *_unused):
         model = ctx.model
         (nig,) = ctx.saved_tensors
         # fold gradients that arrive through the derived uncertainties (deer.py:96-98) into nu / alpha / beta
@@ -123,7 +123,7 @@ class _ForwardFn(torch.autograd.Function):
             g_beta = d_beta if g_beta is None else g_beta + d_beta
             g_alpha = d_alpha if g_alpha is None else g_alpha + d_alpha
             g_nu = d_nu if g_nu is None else g_nu + d_nu
-        grads = model._launch_backward(ctx, None, g_mu, g_nu, g_alpha, g_beta)
+        grads = model._launch_backward(ctx, None, g_mu, g_nu, g_alpha, g_beta, g_fused=g_fused)
         return (None, None, None, None, None) + tuple(grads)
 
 
@@ -313,7 +313,7 @@ class MultimodalDEER(nn.Module):
 
     def _launch_backward(self, ctx_or_meta, targets, g_mu=None, g_nu=None, g_alpha=None, g_beta=None,
                          loss_out=None, bin_counts=None, events=None, flat=None, want_views=True, phase=0,
-                         global_stats=None):
+                         global_stats=None, g_fused=None):
         lib = _lib.load()
         if isinstance(ctx_or_meta, dict):
             meta = ctx_or_meta
@@ -353,6 +353,10 @@ class MultimodalDEER(nn.Module):
                 a.bucket_events[i] = ev.cuda_event
         a.phase = int(phase)
         a.global_stats = _lib.ptr(global_stats)
+        if g_fused is not None:
+            g_fused = g_fused.contiguous().float()
+            keep.append(g_fused)
+            a.g_fused = g_fused.data_ptr()
         a.stream = _lib.current_stream()
         _lib.check(lib.mmdeer_backward(C.byref(a)))
         self._flat_grad = flat
