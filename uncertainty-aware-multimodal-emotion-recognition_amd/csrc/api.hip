@@ -772,6 +772,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
 
 #ifdef MMDEER_STAMPS
 // diagnostic library only (not part of the ABI): 32 uint64 slots, forward chain stamps at [0,16), backward at [16,32)
+int mmdeer_debug_nig_stamps(unsigned long long* out16) { return mmdeer::debug_nig_stamps(out16); }
 void mmdeer_debug_chain_stamps(void* p) { g_chain_stamps = reinterpret_cast<unsigned long long*>(p); }
 #endif
 

@@ -62,4 +62,9 @@ int launch_unc_reg_loss(const float* alpha, const float* beta, int B, int D, flo
 int launch_calibration_loss(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
                             float* loss_out, int* bin_counts, float* dgamma, float* dalpha, float* dbeta, hipStream_t s);
 
+#ifdef MMDEER_STAMPS
+// diagnostic library only: the 16 s_memtime slots nig_bwd_kernel's workgroup (0, 0) wrote (tools/nig_stamps.py)
+int debug_nig_stamps(unsigned long long* out16);
+#endif
+
 }  // namespace mmdeer

@@ -17,6 +17,20 @@ __device__ const float kEceEdges[11] = {0.0f, 0x1.99999ap-4f, 0x1.99999ap-3f, 0x
 constexpr float kEps = 1e-8f;                 // losses.py:53
 constexpr float kTwoPiEps = 6.28318530717958647692f;  // float32(2*pi + 1e-8) (losses.py:144)
 
+#ifdef MMDEER_STAMPS
+__device__ unsigned long long g_nig_stamps[16];   // diagnostic build: s_memtime of workgroup (0, 0) through nig_bwd_kernel
+#define GSTAMP(slot)                                                                        \
+  do {                                                                                     \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                          \
+      unsigned long long t_;                                                               \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+      g_nig_stamps[slot] = t_;                                                             \
+    }                                                                                      \
+  } while (0)
+#else
+#define GSTAMP(slot) do {} while (0)
+#endif
+
 struct Nig { float mu, nu, alpha, beta; };
 
 __device__ __forceinline__ float softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus, threshold 20
@@ -104,39 +118,71 @@ struct Finals {
 
 __device__ __forceinline__ void compute_finals(const float* stats, int nblk, int B, const LossCfg& cfg, Finals& F,
                                                float (*gs)[NIG_NSTAT]) {
-  for (int i = threadIdx.x; i < 3 * NIG_NSTAT; i += blockDim.x) {
-    const int d = i / NIG_NSTAT, k = i - d * NIG_NSTAT;
+  // Identical in every workgroup (blockDim.x == 256), and every wave of it waits here: the serial part is kept short.
+  // Measured on workgroup (0,0) at B = 4096 (tools/nig_stamps.py): one thread walking the 3 x 10 bins took 12.4k cycles
+  // and the chain of nblk dependent adds 5.9k, of 30k for the whole kernel.
+  constexpr int NV = 3 * NIG_NSTAT;
+  __shared__ float upper[NV], ece_c[30], dim_total[3], ubar_s[3];
+  {
+    // 105 sums over the nblk block partials: the two halves of the workgroup take the two halves of the range with
+    // 16 loads in flight per thread
+    const int i = threadIdx.x & 127, h = threadIdx.x >> 7;
     float acc = 0.f;
-#pragma unroll 8
-    for (int p = 0; p < nblk; ++p) acc += stats[((long long)p * 3 + d) * NIG_NSTAT + k];
-    gs[d][k] = acc;
+    if (i < NV) {
+      const int per = (nblk + 1) >> 1, p0 = h * per, p1 = (p0 + per < nblk) ? p0 + per : nblk;
+      // batches of 16 unconditional loads (index clamped, value masked): a load under a per-lane branch would be
+      // waited for on the spot, and a plain accumulation loop is a chain of dependent adds
+      for (int q = p0; q < p1; q += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int p = q + u < p1 ? q + u : p1 - 1;
+          v[u] = stats[(long long)p * NV + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = q + u < p1 ? v[u] : 0.f;
+        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+               (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+      }
+      if (h == 1) upper[i] = acc;
+    }
+    __syncthreads();
+    if (h == 0 && i < NV) gs[i / NIG_NSTAT][i % NIG_NSTAT] = acc + upper[i];
+  }
+  GSTAMP(8);
+  __syncthreads();
+  GSTAMP(9);
+  const float N = (float)B;
+  if (threadIdx.x < 30) {                     // one thread per (dimension, ECE bin)
+    const int d = threadIdx.x / 10, k = threadIdx.x - d * 10;
+    const float cnt = gs[d][25 + k];
+    F.counts[d][k] = (int)cnt;
+    float sg = 0.f, c = 0.f;
+    if (cnt > 0.f) {
+      const float diff = gs[d][5 + k] / cnt - (1.0f - gs[d][15 + k] / cnt);   // losses.py:219-224
+      c = (cnt / N) * fabsf(diff);
+      sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+    }
+    F.sign[d][k] = sg;
+    ece_c[threadIdx.x] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {                      // one thread per dimension
+    const int d = threadIdx.x;
+    float ece = 0.f;
+    for (int k = 0; k < 10; ++k) ece += ece_c[d * 10 + k];                      // bins in order, as the reference adds them
+    const float nll = -gs[d][0] / N, reg = gs[d][1] / N;
+    const float kl = gs[d][2] / N + 0.1f * (gs[d][3] / N);
+    const float total = nll + cfg.reg_w * reg + cfg.kl_w * kl + cfg.ece_w * ece;   // losses.py:121
+    F.out[d * 5 + 0] = total; F.out[d * 5 + 1] = nll; F.out[d * 5 + 2] = reg; F.out[d * 5 + 3] = kl; F.out[d * 5 + 4] = ece;
+    ubar_s[d] = gs[d][4] / N;
+    dim_total[d] = total;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float N = (float)B;
-    float ubar[3];
     float tot = 0.f;
-    for (int d = 0; d < 3; ++d) {
-      float ece = 0.f;
-      for (int k = 0; k < 10; ++k) {
-        const float cnt = gs[d][25 + k];
-        F.counts[d][k] = (int)cnt;
-        float sg = 0.f;
-        if (cnt > 0.f) {
-          const float diff = gs[d][5 + k] / cnt - (1.0f - gs[d][15 + k] / cnt);   // losses.py:219-224
-          ece += (cnt / N) * fabsf(diff);
-          sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-        }
-        F.sign[d][k] = sg;
-      }
-      const float nll = -gs[d][0] / N, reg = gs[d][1] / N;
-      const float kl = gs[d][2] / N + 0.1f * (gs[d][3] / N);
-      const float total = nll + cfg.reg_w * reg + cfg.kl_w * kl + cfg.ece_w * ece;   // losses.py:121
-      F.out[d * 5 + 0] = total; F.out[d * 5 + 1] = nll; F.out[d * 5 + 2] = reg; F.out[d * 5 + 3] = kl; F.out[d * 5 + 4] = ece;
-      ubar[d] = gs[d][4] / N;
-      tot += cfg.task_w[d] * total;
-    }
-    const float d01 = ubar[0] - ubar[1], d02 = ubar[0] - ubar[2], d12 = ubar[1] - ubar[2];
+    for (int d = 0; d < 3; ++d) tot += cfg.task_w[d] * dim_total[d];
+    const float d01 = ubar_s[0] - ubar_s[1], d02 = ubar_s[0] - ubar_s[2], d12 = ubar_s[1] - ubar_s[2];
     const float cross = (d01 * d01 + d02 * d02 + d12 * d12) / 3.f;                  // losses.py:339-346
     F.dcross[0] = (2.f / 3.f) * (d01 + d02);
     F.dcross[1] = (2.f / 3.f) * (-d01 + d12);
@@ -149,6 +195,7 @@ __device__ __forceinline__ void compute_finals(const float* stats, int nblk, int
     F.out[18] = (F.out[2] + F.out[7] + F.out[12]) / 3.f;
     F.out[19] = (F.out[3] + F.out[8] + F.out[13]) / 3.f;
   }
+  GSTAMP(10);
   __syncthreads();
 }
 
@@ -286,6 +333,7 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
   const bool active = b < B;
   const int bc = active ? b : B - 1;
   const long long o = (long long)bc * 3 + d;
+  GSTAMP(0);
   // loads that do not depend on the loss finals go first
   float w[4][16];
 #pragma unroll
@@ -297,13 +345,16 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
   f32x4 g{0.f, 0.f, 0.f, 0.f};
   if (loss_mode) {
     const float y = targets[o];
+    GSTAMP(1);
     // exact-global mode: the statistics of all ranks' batches (already summed), N = the global batch size
     const int stat_n = gstats ? (int)gstats[3 * NIG_NSTAT] : B;
     compute_finals(gstats ? gstats : stats, gstats ? 1 : nblk, stat_n, cfg, F, gs);
+    GSTAMP(2);
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) write_loss(F, loss_out, bin_counts);
     const Nig n = nig_act(ev);
     const Terms t = loss_terms(n, y);
     g = loss_grad(n, t, d, stat_n, cfg, F);
+    GSTAMP(3);
   } else {
     if (gmu) g.x = gmu[o];
     if (gnu) g.y = gnu[o];
@@ -323,6 +374,7 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
   }
   if (active) store_chunk16<F32>(dz2, (long long)b * 192 + d * 64 + q * 16, dz);
   if (q == 0) sdE[s] = dE;
+  GSTAMP(4);
   __syncthreads();
   // weight-gradient partial of this block: dW3[d][c][j] = sum_s dE[s][c] * e2[s][d*64 + j]
   {
@@ -341,6 +393,7 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
       partial_b[((long long)blockIdx.x * 3 + d) * 4 + c] = bs;
     }
   }
+  GSTAMP(5);
 }
 
 // ------------------------------------------------------------------ standalone loss on given NIG parameters
@@ -638,5 +691,12 @@ int launch_calibration_loss(const float* gamma, const float* alpha, const float*
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
+
+#ifdef MMDEER_STAMPS
+int debug_nig_stamps(unsigned long long* out16) {
+  MMDEER_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_nig_stamps), sizeof(unsigned long long) * 16));
+  return 0;
+}
+#endif
 
 }  // namespace mmdeer
