@@ -20,7 +20,7 @@ def run(tag, M, N, K, ta, tw, tile, dt=torch.bfloat16):
     A = torch.randn((K, M) if ta else (M, K), device=dev).to(dt)
     W = torch.randn((K, N) if tw else (N, K), device=dev).to(dt)
     Cm = torch.empty(M, N, device=dev, dtype=torch.float32 if ta else dt)
-    st = torch.zeros(17 * 8, dtype=torch.int64, device=dev)
+    st = torch.zeros(4096, dtype=torch.int64, device=dev)   # room for the per-workgroup slots [256, ...) of the LDS-DMA kernels
     a = _lib.GemmArgs()
     a.A, a.W, a.C = A.data_ptr(), W.data_ptr(), Cm.data_ptr()
     a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, A.shape[1], W.shape[1], N

@@ -22,7 +22,7 @@ def run(tag, M, N, K, tile, bias):
     W = torch.randn(N, K, device=dev).to(dt)
     b = torch.randn(N, device=dev) if bias else None
     Cm = torch.empty(M, N, device=dev, dtype=dt)
-    st = torch.zeros(16, dtype=torch.int64, device=dev)
+    st = torch.zeros(4096, dtype=torch.int64, device=dev)   # slots [0,16): workgroup 0 phases; [256, ...): per-workgroup begin / end
     a = _lib.GemmArgs()
     a.A, a.W, a.C = A.data_ptr(), W.data_ptr(), Cm.data_ptr()
     a.bias = b.data_ptr() if bias else None
