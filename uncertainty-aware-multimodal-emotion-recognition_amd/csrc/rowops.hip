@@ -167,18 +167,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dout, const voi
     dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // two rows per trip: both rows' loads are in flight before the first reduction (a wave owns 4+ rows; one row at a
-  // time the loop was a chain of load -> reduce -> store round trips)
+  // RPT rows per trip: all their loads are in flight before the first reduction.  A wave owns M / (4 gridDim.x) rows --
+  // four at B = 4096 -- and every trip is one full memory round trip (load -> reduce -> store): one row at a time the
+  // kernel was a chain of them, two at a time it still made two (6.0 us per launch against 4.8 us for the forward).
+  constexpr int RPT = 4;
   const int stride = gridDim.x * 4;
-  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += 2 * stride) {
-    f32x4 yv[2][NV], d[2][NV];
-    float mu[2], rs[2];
-    bool live[2];
+  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += RPT * stride) {
+    f32x4 yv[RPT][NV], d[RPT][NV];
+    float mu[RPT], rs[RPT];
+    bool live[RPT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < RPT; ++r) {
       const int row = row0 + r * stride;
       live[r] = row < M;
-      const int rr = live[r] ? row : row0;            // a dead second row re-reads the first (results discarded)
+      const int rr = live[r] ? row : row0;            // a dead row re-reads the first (results discarded)
       const long long base = (long long)rr * N;
       mu[r] = mean[rr]; rs[r] = rstd[rr];
 #pragma unroll
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dout, const voi
       }
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < RPT; ++r) {
       if (!live[r]) continue;                         // wave-uniform
       const long long base = (long long)(row0 + r * stride) * N;
       f32x4 xh[NV], gd[NV];
