@@ -501,7 +501,7 @@ constexpr int UREG_MAX_D = 8;
 __global__ __launch_bounds__(256) void unc_reg_kernel(const float* alpha, const float* beta, int B, int D, float dw, float sw,
                                                       float* loss_out, float* dalpha, float* dbeta) {
   __shared__ float sm[4][UREG_MAX_D];
-  __shared__ float mean[UREG_MAX_D], coef[UREG_MAX_D];
+  __shared__ float mean[UREG_MAX_D];
   float v[UREG_MAX_D];
 #pragma unroll
   for (int d = 0; d < UREG_MAX_D; ++d) v[d] = 0.f;
@@ -542,7 +542,6 @@ __global__ __launch_bounds__(256) void unc_reg_kernel(const float* alpha, const 
     dalpha[e] = gu * (-u / den);
     dbeta[e] = gu / den;
   }
-  (void)coef;
 }
 
 // losses.CalibrationLoss, 15 uniform bins (losses.py:419-497): torch.linspace(0, 1, 16) in fp32 is NOT float32(i)/15
