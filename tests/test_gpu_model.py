@@ -447,3 +447,65 @@ def test_gradient_through_fused_features_reaches_the_fusion_parameters(dtype):
                 assert cos > 0.95, (name, cos)
             checked += 1
         assert checked >= (20 if with_head else 12)
+
+
+def test_standalone_fusion_module_has_the_reference_protocol(golden_dir):
+    """model.HierarchicalMultimodalFusion: the reference class's constructor, state_dict keys, output dictionary, values
+    (golden eval forward) and a caller-owned head that trains the fusion through fused_features."""
+    from mmdeer.model import HierarchicalMultimodalFusion
+    f = HierarchicalMultimodalFusion(84, 256, 768, fusion_dim=512, intermediate_dim=256, num_attention_heads=8, dropout=0.0)
+    names = json.load(open(os.path.join(golden_dir, "state_dict_names.json")))
+    assert sorted(f.state_dict()) == sorted(names["fusion"])   # exactly the reference class's keys (no head.*, no prefix)
+    state = synth.closed_form_state(include_gate=True)
+    f.load_state_dict({k[len("fusion."):]: torch.from_numpy(v) for k, v in state.items() if k.startswith("fusion.")})
+    f = f.to(DEV).eval()
+    g = dict(np.load(os.path.join(golden_dir, "stackc_B7.npz")))
+    b = batch(7)
+    with torch.no_grad():
+        out = f(b["audio"].to(DEV), b["video"].to(DEV), b["text"].to(DEV))
+    assert set(out) == set(HierarchicalMultimodalFusion.KEYS) and out["uncertainty_weights"] is None
+    for k in ("fused_features", "audiovisual_features", "trimodal_features", "trimodal_attention_weights"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), g["eval." + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    with pytest.raises(NotImplementedError):
+        f(b["audio"].to(DEV), b["video"].to(DEV), b["text"].to(DEV), uncertainties={"audio": None})
+    # a caller's own head on fused_features: gradients reach the fusion parameters and match the oracle
+    f.train()
+    head = torch.nn.Linear(512, 2).to(DEV)
+    out = f(b["audio"].to(DEV), b["video"].to(DEV), b["text"].to(DEV))
+    head(out["fused_features"]).square().sum().backward()
+    P = O.to_params({k: torch.from_numpy(v) for k, v in state.items()}, requires_grad=True)
+    fo = O.fusion_forward(P, b["audio"], b["video"], b["text"])
+    w, bb = head.weight.detach().cpu(), head.bias.detach().cpu()
+    (fo["fused_features"] @ w.t() + bb).square().sum().backward()
+    got = dict(f.named_parameters())
+    checked = 0
+    for name, p in P.items():
+        key = name[len("fusion."):]
+        if not name.startswith("fusion.") or p.grad is None or got[key].grad is None:
+            continue
+        scale = max(p.grad.abs().max().item(), 1e-12)
+        assert (got[key].grad.cpu() - p.grad).abs().max().item() / scale < 2e-3, name
+        checked += 1
+    assert checked >= 12
+
+
+def test_training_after_an_inference_call_on_the_same_parameters():
+    """The W^T copies the backward GEMMs read are packed with every repack -- also when the call that triggers it is an
+    inference call; gradients after eval -> train equal those of a model that trained first."""
+    b = batch(7, seed=31)
+    a, v, t, y = (b[k].to(DEV) for k in ("audio", "video", "text", "targets"))
+    grads = []
+    for first_eval in (False, True):
+        junk = torch.full((64 << 20,), 7.0, device=DEV)      # dirty the allocator's free blocks: no lucky leftovers
+        del junk
+        m = make_model(dropout=0.0)
+        if first_eval:
+            m.eval()
+            with torch.no_grad():
+                m(a, v, t)
+        m.train()
+        m.compute_loss(m(a, v, t), y)["total_loss"].backward()
+        grads.append([p.grad.clone() for p in m.live_parameters()])
+    for g0, g1 in zip(*grads):
+        assert torch.equal(g0, g1)
+    assert float(grads[1][0].abs().sum()) > 0

@@ -448,9 +448,11 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
       t.is_vec[i] = kParams[i].is_matrix ? 0 : 1;
     }
     TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
-    // W^T copies for the backward dX GEMMs (only when this call trains: inference never reads them)
-    if (a->training || a->targets) TRY(pack_transposed_weights(a->params, L, f32, s));
-    if (!f32 && env_chain()) TRY(pack_chain_weights(a->params, L, (a->training || a->targets) ? 1 : 0, s));
+    // W^T copies for the backward dX GEMMs.  Always, not only when THIS call trains: the caller skips the repack while
+    // the parameters are unchanged, so an inference call followed by a training call on the same parameters would find
+    // them missing (the backward pass then multiplied by whatever the buffer held)
+    TRY(pack_transposed_weights(a->params, L, f32, s));
+    if (!f32 && env_chain()) TRY(pack_chain_weights(a->params, L, 1, s));
   }
   const bool wa_pending = a->repack && !f32;   // the padded bf16 copy of audio_projection.weight follows the parameters
   if (B == 0) {

@@ -553,6 +553,50 @@ def multitask_deer_loss(predictions: Dict[str, torch.Tensor], targets: torch.Ten
 CompleteDEERModel = MultimodalDEER
 
 
+class HierarchicalMultimodalFusion(nn.Module):
+    """``fusion.HierarchicalMultimodalFusion`` (src/models/fusion.py:35-185) for callers that use the fusion on its own:
+    same constructor arguments, ``forward(audio, video, text, uncertainties=None)`` and output dictionary
+    (fusion.py:164-171), and ``state_dict()`` has exactly the reference class's keys, so its checkpoints load.
+
+    The arithmetic is the fused fusion + head pass of ``MultimodalDEER`` (the head is a few launches and its outputs are
+    dropped); ``fused_features`` is differentiable -- a caller's own head trains the fusion through it
+    (``mmdeer_backward``'s ``g_fused``).  ``audiovisual_features`` / ``trimodal_features`` are returned as values only."""
+
+    KEYS = ("fused_features", "audiovisual_features", "trimodal_features", "av_attention_weights",
+            "trimodal_attention_weights", "uncertainty_weights")
+
+    def __init__(self, audio_dim: int, video_dim: int, text_dim: int, fusion_dim: int = 512, intermediate_dim: int = 256,
+                 num_attention_heads: int = 8, dropout: float = 0.3, use_uncertainty_weighting: bool = True,
+                 compute_dtype: str = "fp32", seed: int = 0):
+        super().__init__()
+        if intermediate_dim != DEFAULT_DIMS.inter:
+            raise NotImplementedError("libmmdeer_hip.so is specialised for intermediate_dim = 256")
+        core = MultimodalDEER(ModelConfig(audio_dim=audio_dim, video_dim=video_dim, text_dim=text_dim, fusion_dim=fusion_dim,
+                                          attention_heads=num_attention_heads, dropout=dropout, compute_dtype=compute_dtype,
+                                          seed=seed))
+        self.__dict__["_core"] = core             # not a registered child: the head's parameters stay out of state_dict()
+        for name, child in core.fusion.named_children():
+            self.add_module(name, child)          # the fusion's own parameter tree, shared with the core
+        self.use_uncertainty_weighting = use_uncertainty_weighting
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        self._core.head._apply(fn, *args, **kwargs)   # .to(device) / .float() reach the hidden head as well
+        return self
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        self._core.train(mode)
+        return self
+
+    def forward(self, audio_features, video_features, text_features, uncertainties=None) -> Dict[str, torch.Tensor]:
+        if uncertainties is not None:
+            # the reference's own path for this argument raises a TypeError (fusion.py:148-150 against :384; SURVEY 8a, a4)
+            raise NotImplementedError("uncertainty weighting is unreachable in the reference and not built")
+        out = self._core(audio_features, video_features, text_features)
+        return {k: out[k] for k in self.KEYS}
+
+
 def create_model(config: Optional[ModelConfig] = None, device: Optional[str] = None) -> MultimodalDEER:
     m = MultimodalDEER(config)
     return m.to(device) if device else m
