@@ -509,3 +509,8 @@ def test_training_after_an_inference_call_on_the_same_parameters():
     for g0, g1 in zip(*grads):
         assert torch.equal(g0, g1)
     assert float(grads[1][0].abs().sum()) > 0
+    # gradients asked for in eval mode (dropout is 0 here, so they are the same numbers)
+    m = make_model(dropout=0.0).eval()
+    m.compute_loss(m(a, v, t), y)["total_loss"].backward()
+    for g0, p in zip(grads[0], m.live_parameters()):
+        assert torch.equal(g0, p.grad)
