@@ -239,3 +239,43 @@ def test_evaluate_deer_model_accepts_stack_b():
     ref = validation_metrics(np.concatenate(preds), np.concatenate(tgts), np.concatenate(uncs))
     for k in ("ccc_valence", "ccc_overall", "mae_arousal", "rmse_dominance"):
         np.testing.assert_allclose(ev[k], ref[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_alternating_batch_sizes_keep_the_packed_weights_current(dtype):
+    """The packed weight copies live in the per-batch-size workspace and the fused optimiser refreshes only the one the
+    last step used: a ragged tail batch, a validation pass in between and the return to the full batch size must all
+    see current weights.  Reference run: the same sequence with a forced repack before every call."""
+    import copy
+
+    from mmdeer.model import ModelConfig, MultimodalDEER
+    from mmdeer.optim import FusedAdamW
+
+    m1 = MultimodalDEER(ModelConfig(compute_dtype=dtype, dropout=0.3, seed=4)).to("cuda:0").train()
+    m2 = copy.deepcopy(m1)
+    o1, o2 = FusedAdamW(m1, lr=1e-3, max_grad_norm=1.0), FusedAdamW(m2, lr=1e-3, max_grad_norm=1.0)
+
+    def data(B, seed):
+        b = synth.make_batch(B, seed=seed)
+        return [torch.from_numpy(b[k]).to("cuda:0") for k in ("audio", "video", "text", "targets")]
+
+    plan = [("train", 32, 1), ("train", 8, 2), ("eval", 20, 3), ("train", 32, 4), ("eval", 32, 5), ("train", 8, 6), ("train", 32, 7)]
+    for kind, B, seed in plan:
+        a, v, t, y = data(B, seed)
+        outs = []
+        for m, o, force in ((m1, o1, False), (m2, o2, True)):
+            if force:
+                m._st.packed_key = None                      # reference: repack from the fp32 parameters every time
+            if kind == "train":
+                m.train()
+                m._step = 100 + seed                         # identical dropout masks in both runs
+                ld = m.train_step(a, v, t, y)
+                o.step()
+                outs.append(ld["total_loss"].clone())
+            else:
+                m.eval()
+                with torch.no_grad():
+                    outs.append(m(a, v, t)["mu_all"].clone())
+        assert torch.equal(outs[0], outs[1]), (kind, B, seed)
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1, p2), n
