@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 9
+#define MMDEER_ABI_VERSION 10
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -255,6 +255,13 @@ typedef struct {
   void* stream;
 } mmdeer_adamw_args;
 int mmdeer_adamw_step(const mmdeer_adamw_args* a);
+
+/* Refresh every packed copy of the parameters in `workspace` (the compute-dtype matrices, their W^T copies, the padded
+ * audio weight) without running a pass -- what mmdeer_forward does when repack = 1.  For a caller that replays a
+ * captured graph (repack = 0 is frozen into it) after something else changed the parameters: a step on another batch
+ * size, whose optimiser call refreshed only that batch size's workspace. */
+int mmdeer_pack_weights(const void* const* params, void* workspace, size_t workspace_bytes, int batch, int compute_f32,
+                        void* stream);
 
 /* ---- side rows (a8, a9, a14), forward only --------------------------------------------------------
  * Their Linear(+ReLU) layers run on mmdeer_gemm and the LayerNorm on mmdeer_layernorm_fwd; the two entry points

@@ -131,14 +131,16 @@ def test_fused_adamw_matches_torch_adamw_with_clipping():
     assert torch.allclose(out1["mu_all"], out2["mu_all"], rtol=1e-4, atol=1e-5)
 
 
-def test_trainer_graph_mode_matches_eager_mode(tmp_path):
+@pytest.mark.parametrize("n", [96, 100])
+def test_trainer_graph_mode_matches_eager_mode(tmp_path, n):
     """DEERTrainer with use_graph=True (captured train_step + FusedAdamW) follows the same trajectory as the eager
-    trainer: same data, same seeds, same dropout counters."""
+    trainer: same data, same seeds, same dropout counters.  n = 100 leaves a ragged tail batch of 4 that runs eagerly
+    on its own workspace between the replays -- the graph's weight copies must be refreshed after it."""
     import copy
 
     from torch.utils.data import DataLoader, TensorDataset
 
-    b = synth.make_batch(96, seed=21)
+    b = synth.make_batch(n, seed=21)
     ds = TensorDataset(*(torch.from_numpy(b[k]) for k in ("audio", "video", "text", "targets")))
     m1 = MultimodalDEER(ModelConfig(compute_dtype="fp32", seed=4)).to("cuda:0")
     m2 = copy.deepcopy(m1)
@@ -148,7 +150,7 @@ def test_trainer_graph_mode_matches_eager_mode(tmp_path):
                              checkpoint_dir=str(tmp_path / f"c{graph}"), use_graph=graph)
         tr = DEERTrainer(m, cfg, device="cuda:0")
         loaders = {"iemocap": DataLoader(ds, batch_size=32, shuffle=False)}
-        hist.append([tr.train_epoch(loaders)["total_loss"] for _ in range(2)])
+        hist.append([tr.train_epoch(loaders)["total_loss"] for _ in range(3)])
     assert hist[0] == pytest.approx(hist[1], rel=1e-5)
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.allclose(p1, p2, rtol=1e-4, atol=1e-6), n

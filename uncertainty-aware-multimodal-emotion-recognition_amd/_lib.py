@@ -150,6 +150,7 @@ SYMBOLS = [
     ("mmdeer_calibration_loss", c_int, [c_void_p] * 4 + [c_ll] + [c_void_p] * 5 + [c_void_p]),
     ("mmdeer_dropout_mask", c_int, [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p]),
     ("mmdeer_adamw_step", c_int, [C.POINTER(AdamWArgs)]),
+    ("mmdeer_pack_weights", c_int, [C.POINTER(c_void_p), c_void_p, c_size_t, c_int, c_int, c_void_p]),
     ("mmdeer_cross_modal_attn_fwd", c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     ("mmdeer_lstm_cell_t1", c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_eval_accumulate", c_int, [c_void_p] * 6 + [c_int, c_void_p]),
@@ -196,7 +197,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 9:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 10:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         _LIB = lib
     return _LIB

@@ -814,6 +814,29 @@ int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
   return 0;
 }
 
+int mmdeer_pack_weights(const void* const* params, void* workspace, size_t workspace_bytes, int batch, int compute_f32,
+                        void* stream) {
+  const int f32 = compute_f32 ? 1 : 0;
+  MMDEER_CHECK(params != nullptr, "pack_weights: params is NULL");
+  TRY(check_common(batch, workspace, workspace_bytes, f32));
+  hipStream_t s = (hipStream_t)stream;
+  const Layout L = make_layout(workspace, batch, f32);
+  PackTable t{};
+  t.nseg = MMDEER_NUM_PARAMS;
+  for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
+    MMDEER_CHECK(params[i] != nullptr && ((uintptr_t)params[i] % 16) == 0, "pack_weights: params[%d] (%s) must be non-NULL and 16-byte aligned", i, kParams[i].name);
+    t.src[i] = reinterpret_cast<const float*>(params[i]);
+    t.dst_off[i] = kParams[i].off;
+    t.n[i] = kParams[i].rows * kParams[i].cols;
+    t.is_vec[i] = kParams[i].is_matrix ? 0 : 1;
+  }
+  TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
+  TRY(pack_transposed_weights(params, L, f32, s));
+  if (!f32) TRY(pad_audio_weight(params, L, s));
+  if (!f32 && env_chain()) TRY(pack_chain_weights(params, L, 1, s));
+  return 0;
+}
+
 // ------------------------------------------------------------------ single operators
 int mmdeer_gemm(const mmdeer_gemm_args* a) {
   MMDEER_CHECK(a != nullptr, "args is NULL");

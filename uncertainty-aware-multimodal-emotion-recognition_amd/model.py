@@ -509,9 +509,28 @@ class MultimodalDEER(nn.Module):
                 after()
         self._graph = graph
 
+        cap_ws, cap_B = self._st.last_train          # the workspace (and its packed weight copies) frozen into the graph
+        counter = self._graph_counter
+        shadow = [int(self._step)]                    # the value the device-side dropout counter holds
+
         def replay():
+            # eager steps in between (a ragged tail batch) advanced the host-side dropout counter only: bring the device
+            # counter in line, so a replay never reuses the offset of the step before it
+            if self._step != shadow[0]:
+                counter.fill_(int(self._step))
+            # repack = 0 is frozen into the graph.  If the parameters were last updated through ANOTHER workspace -- an
+            # eager step on a ragged tail batch, whose optimiser call refreshed only that batch size's copies -- the
+            # copies the graph reads are stale: refresh them first.
+            pk = self._st.packed_key
+            if pk is None or pk[0] != cap_ws.data_ptr() or pk[1] != self._st.param_gen:
+                lib = _lib.load()
+                _lib.check(lib.mmdeer_pack_weights(self._ptr_cache[1], cap_ws.data_ptr(), cap_ws.numel(), cap_B, self.compute_f32,
+                                                   _lib.current_stream()))
+                self._st.packed_key = self._param_key(cap_ws)
             graph.replay()
             self._step += 1          # keep the host-side step counter in line with the device-side one
+            shadow[0] = int(self._step)
+            self._st.last_train = (cap_ws, cap_B)        # the optimiser step that follows packs into THIS workspace
             return out
         replay.first = first
         return replay
