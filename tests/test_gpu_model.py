@@ -514,3 +514,15 @@ def test_training_after_an_inference_call_on_the_same_parameters():
     m.compute_loss(m(a, v, t), y)["total_loss"].backward()
     for g0, p in zip(grads[0], m.live_parameters()):
         assert torch.equal(g0, p.grad)
+
+
+def test_mark_parameters_changed_after_a_write_through_data():
+    m = make_model().eval()
+    b = batch(5)
+    a, v, t = (b[k].to(DEV) for k in ("audio", "video", "text"))
+    with torch.no_grad():
+        before = m(a, v, t)["mu_all"].clone()
+        dict(m.named_parameters())["head.deer_heads.0.evidence_net.6.bias"].data[0] += 1.0   # .data: no version bump
+        m.mark_parameters_changed()
+        after = m(a, v, t)["mu_all"]
+    np.testing.assert_allclose((after - before).cpu().numpy(), np.tile(np.float32([1, 0, 0]), (5, 1)), atol=1e-5)

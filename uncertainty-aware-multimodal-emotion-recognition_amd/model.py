@@ -225,6 +225,12 @@ class MultimodalDEER(nn.Module):
     def live_parameters(self):
         return list(self._live)
 
+    def mark_parameters_changed(self) -> None:
+        """Force the next call to re-derive the packed weight copies.  Edits through ``load_state_dict``, optimisers and
+        ordinary in-place ops are seen on their own (tensor version counters); writes through ``param.data`` are not."""
+        self._st.param_gen += 1
+        self._st.packed_key = None
+
     def load_reference_state_dicts(self, fusion_sd: Dict[str, torch.Tensor], head_sd: Dict[str, torch.Tensor]):
         """Load state_dicts saved from the reference's HierarchicalMultimodalFusion / MultiDimensionalDEER."""
         self.fusion.load_state_dict(fusion_sd)
