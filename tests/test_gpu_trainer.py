@@ -150,7 +150,11 @@ def test_trainer_graph_mode_matches_eager_mode(tmp_path, n):
                              checkpoint_dir=str(tmp_path / f"c{graph}"), use_graph=graph)
         tr = DEERTrainer(m, cfg, device="cuda:0")
         loaders = {"iemocap": DataLoader(ds, batch_size=32, shuffle=False)}
-        hist.append([tr.train_epoch(loaders)["total_loss"] for _ in range(3)])
+        h = []
+        for _ in range(3):                 # a validation pass on the training batch size (the graph's own workspace) in between
+            h.append(tr.train_epoch(loaders)["total_loss"])
+            h.append(tr.validate_epoch(loaders)["val_loss"])
+        hist.append(h)
     assert hist[0] == pytest.approx(hist[1], rel=1e-5)
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.allclose(p1, p2, rtol=1e-4, atol=1e-6), n
