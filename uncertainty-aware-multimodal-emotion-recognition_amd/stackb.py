@@ -153,6 +153,11 @@ class CompleteDEERModel(nn.Module):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
 
+    def mark_parameters_changed(self) -> None:
+        """Force the next forward to rebuild the operand image (needed only after writes through ``param.data``, which
+        bypass the version counters the cache is keyed on)."""
+        self._packed = None
+
     # ---- device-side operand image (include/mmdeer.h: mmdeer_stackb_weights), rebuilt when a parameter changes
     def _pack(self) -> dict:
         key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.compute_dtype,)
