@@ -285,3 +285,43 @@ def test_alternating_batch_sizes_keep_the_packed_weights_current(dtype):
         assert torch.equal(outs[0], outs[1]), (kind, B, seed)
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(p1, p2), n
+
+
+def test_fused_adamw_checkpoint_round_trip_resumes_bit_for_bit():
+    """FusedAdamW.state_dict() / load_state_dict() (flat moments, step count, group settings): a run resumed from a
+    checkpoint in a fresh model + optimiser continues exactly like the run that was never interrupted."""
+    import copy
+    import io
+
+    from mmdeer.model import ModelConfig, MultimodalDEER
+    from mmdeer.optim import FusedAdamW
+
+    def data(seed):
+        b = synth.make_batch(24, seed=seed)
+        return [torch.from_numpy(b[k]).to("cuda:0") for k in ("audio", "video", "text", "targets")]
+
+    def step(m, o, seed):
+        m._step = 50 + seed
+        ld = m.train_step(*data(seed))
+        o.step()
+        return float(ld["total_loss"])
+
+    m = MultimodalDEER(ModelConfig(compute_dtype="fp32", dropout=0.2, seed=6)).to("cuda:0").train()
+    o = FusedAdamW(m, lr=2e-3, weight_decay=0.01, max_grad_norm=1.0)
+    for s in (1, 2, 3):
+        step(m, o, s)
+    buf = io.BytesIO()
+    torch.save({"model": m.state_dict(), "optim": o.state_dict()}, buf)
+    want = [step(m, o, s) for s in (4, 5)]
+
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    m2 = MultimodalDEER(ModelConfig(compute_dtype="fp32", dropout=0.2, seed=99)).to("cuda:0").train()
+    m2.load_state_dict(ck["model"])
+    o2 = FusedAdamW(m2, lr=2e-3, weight_decay=0.01, max_grad_norm=1.0)
+    o2.load_state_dict(ck["optim"])
+    m2.config.seed = m.config.seed            # the dropout stream is keyed on (seed, step)
+    got = [step(m2, o2, s) for s in (4, 5)]
+    assert got == want
+    for (n, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1, p2), n
