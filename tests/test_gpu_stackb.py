@@ -152,3 +152,27 @@ def test_stackb_graph_replay_equals_eager():
         assert torch.equal(got[k], want[k]), k
     again = replay(*xs)
     assert torch.equal(again["mu_all"], m(*xs)["mu_all"])
+
+
+def test_stackb_bf16_agrees_with_fp32_by_ccc():
+    """bf16 operands through ~14 layers: per-dimension concordance (metrics.py:85-101 formula) of the bf16 outputs with the
+    fp32 outputs at B = 1024, reference-style (Xavier) weights."""
+    torch.manual_seed(11)
+    m32 = stackb.CompleteDEERModel(compute_dtype="fp32")
+    m16 = stackb.CompleteDEERModel(compute_dtype="bf16")
+    m16.load_state_dict(m32.state_dict())
+    m32, m16 = m32.to("cuda:0").eval(), m16.to("cuda:0").eval()
+    xs = [x.to("cuda:0") for x in _inputs(1024, 17)]
+    o32, o16 = m32(*xs), m16(*xs)
+
+    def ccc(x, y):
+        x, y = x.double(), y.double()
+        mx, my = x.mean(0), y.mean(0)
+        vx, vy = x.var(0, unbiased=False), y.var(0, unbiased=False)
+        cov = ((x - mx) * (y - my)).mean(0)
+        return 2 * cov / (vx + vy + (mx - my) ** 2)
+
+    for k, floor in (("mu_all", 0.999), ("uncertainty_all", 0.99), ("calibrated_uncertainty", 0.99), ("fused_features", 0.995)):
+        c = ccc(o16[k], o32[k])
+        assert float(c.min()) > floor, (k, c.cpu().numpy())
+    assert float((o16["attention_weights"] - o32["attention_weights"]).abs().max()) < 0.05
