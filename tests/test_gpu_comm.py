@@ -39,3 +39,54 @@ def test_rccl_communicator_single_rank_allreduce_and_capture():
         comm.close()
     with pytest.raises(ValueError, match="128 bytes"):
         RcclCommunicator(0, 1, b"short")
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bucketed_allreduce_gpu_paths_on_a_one_rank_group():
+    """parallel.BucketedAllReduce on the GPU (a forced 1-rank RCCL group): both communicator backends, both payloads,
+    the mean / SUM (exact-global) modes, the side-stream range form and the statistics exchange leave a 1-rank buffer
+    unchanged (up to the bf16 round trip of the payload)."""
+    import torch.distributed as dist
+
+    from mmdeer import _lib
+    from mmdeer.parallel import BucketedAllReduce
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n = int(_lib.load().mmdeer_flat_elems())
+        ref = torch.randn(n, device="cuda:0")
+        for backend in ("torch", "rccl"):
+            for payload in ("bf16", "fp32"):
+                comm = BucketedAllReduce(device=torch.device("cuda", 0), force=True, payload=payload, backend=backend)
+                assert comm.active and comm.world == 1 and comm.backend == backend
+                for exact in (False, True):
+                    comm.exact_global = exact
+                    flat = ref.clone()
+                    comm.launch(flat)
+                    comm.wait(flat)
+                    lo = n // 3 // 4 * 4
+                    comm.launch_range(flat, lo, n)
+                    comm.launch_range(flat, 0, lo)
+                    comm.join()
+                    torch.cuda.synchronize()
+                    if payload == "fp32":
+                        assert torch.equal(flat, ref)
+                    else:
+                        assert torch.allclose(flat, ref, rtol=2 ** -7, atol=0)        # two bf16 round trips
+                stats = torch.arange(106, dtype=torch.float32, device="cuda:0")
+                comm.sum_small(stats)
+                assert torch.equal(stats.cpu(), torch.arange(106, dtype=torch.float32))
+                if comm._rccl is not None:
+                    comm._rccl.close()
+        with pytest.raises(ValueError):
+            BucketedAllReduce(device=torch.device("cuda", 0), backend="mpi")
+    finally:
+        dist.destroy_process_group()
