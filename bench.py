@@ -12,6 +12,8 @@ reference by tests/test_oracle_golden.py) on the host cores, N = 1 only.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +26,31 @@ import torch.distributed as dist  # noqa: E402
 
 BF16_MFMA_PEAK = 2.5e15   # dense bf16 FLOP/s, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 F32_MFMA_PEAK = 157.3e12
+
+
+def kernel_sources_sha():
+    """sha256 over the kernel sources the library is built from: ties a PMC record to the code it was measured on."""
+    import hashlib
+    d = os.path.join(ROOT, "uncertainty-aware-multimodal-emotion-recognition_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(dtype, batch):
+    """HBM-side bytes per launch of the roofline kernel from the committed PMC record (separate rocprofv3 --pmc passes,
+    FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes the record).  null unless
+    the record was taken on exactly these kernel sources, dtype and batch."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if rec.get("src_sha") == kernel_sources_sha() and rec.get("dtype") == dtype and rec.get("batch") == batch:
+            return float(rec["traffic_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def usable_cores():
@@ -138,9 +165,52 @@ def bench_stackb(args, dev, world, rank):
     print(json.dumps(out))
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1, not under a launcher): start N rank processes -- one per GPU -- as CHILD
+    processes of this one, which has not touched the GPU, and return their exit code.  The same command line the driver
+    uses for its own N > 1 runs (torch.distributed.run, 127.0.0.1 rendezvous)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing(args, world, rank):
+    """--plumbing: the launch / rendezvous / timing protocol of the N-rank bench on the CPU (gloo), no GPU work: what
+    tests/test_cpu_bench_spawn.py runs.  Same barrier + MAX-over-ranks bracket, same single JSON line from rank 0."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: world size {dist.get_world_size()} != --gpus {args.gpus}")
+        dist.barrier()
+    t0 = time.perf_counter()
+    x = torch.full((4,), float(rank + 1))
+    for _ in range(args.steps):
+        if world > 1:
+            dist.all_reduce(x, op=dist.ReduceOp.SUM)
+            x /= world
+    if world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"plumbing": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(tt) / max(args.steps, 1) * 1e3, 4)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--plumbing", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="samples per GPU")
@@ -153,15 +223,30 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     args = ap.parse_args()
 
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and not under_launcher:
+        # N ranks as child processes, started BEFORE anything here touches the GPU (device_count does not initialise it)
+        if not args.plumbing and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a "
+                         f"{world}-rank number as n_gpus={args.gpus}")
+    if args.plumbing:
+        return plumbing(args, world, rank)
     force_comm = os.environ.get("MMDEER_FORCE_COMM") == "1" and "RANK" in os.environ   # 1-rank rehearsal of the DP path
     if world > 1 or force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {world}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -315,7 +400,7 @@ def main():
                          "frac": round(achieved / peak, 4),
                          # HBM-side bytes of one launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950
                          # + WRITE_SIZE, profiles/r01_pmc_gemm_kernels.txt); algorithmic bytes: A 8.39 + W 1.57 + C 25.17 MB
-                         "traffic": 44.3e6 if args.dtype == "bf16" and B == 4096 else None,   # profiles/r01_pmc_gemm_kernels_v2.txt
+                         "traffic": measured_traffic(args.dtype, B),
                          "algorithmic_bytes": 2 * B * 512 * 2 + 1536 * 512 * 2 + 2 * B * 1536 * 2,
                          "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(gemm_ms[len(gemm_ms) // 2] * 1e3, 2)},
         }

@@ -114,7 +114,11 @@ class DEERTrainer:
             if self._graphs and key[0] < max(k[0] for k in self._graphs):
                 return None                      # a smaller tail batch: not worth a capture
             static = tuple(x.clone() for x in (a, v, t, y.float()))
-            replay = self.model.capture_train_step(*static)
+            # exact-global mode: the statistics exchange sits between forward and backward INSIDE the captured step (the
+            # eager fallback below passes the same communicator); without it a replayed step would be a per-shard step
+            # whose gradients the SUM exchange then scales by the world size
+            sc = self.comm if getattr(self.comm, "exact_global", False) else None
+            replay = self.model.capture_train_step(*static, stats_comm=sc)
             entry = self._graphs[key] = (static, replay)
             return replay.first              # the capture's eager warm-up WAS this batch's step: gradients are in place
         static, replay = entry
