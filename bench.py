@@ -53,6 +53,41 @@ def measured_traffic(dtype, batch):
     return None
 
 
+def rocprof_record(batch, dtype, step_ms):
+    """Per-kernel figures from the COMMITTED rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/r02_bench_kernel_stats.csv + .json: which sources / batch it was taken on): average duration of the roofline
+    kernel -> frac_rocprof, and achieved GB/s of the HBM-bound row kernels against their algorithmic bytes.  null when the
+    summary is missing or was taken on other kernel sources."""
+    import csv
+    try:
+        meta = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.json")))
+        if meta.get("src_sha") != kernel_sources_sha() or meta.get("batch") != batch or meta.get("dtype") != dtype:
+            return None
+        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", meta["csv"]))))
+    except (OSError, ValueError, KeyError):
+        return None
+    avg = {}
+    for r in rows:
+        n = r["Name"].replace("void ", "").replace("mmdeer::(anonymous namespace)::", "").split("(")[0]
+        avg[n] = float(r["AverageNs"]) * 1e-9
+    B, s = batch, 2     # bf16 activations
+    # algorithmic bytes per launch of the HBM-bound kernels (activations in + out; statistics / parameters are noise)
+    hbm = {"ln_fwd_kernel<false, 2, true>": 2 * B * 512 * s, "ln_fwd_kernel<false, 1, true>": 2 * B * 256 * s,
+           "ln_bwd_kernel<false, 2, true>": 3 * B * 512 * s, "ln_bwd_kernel<false, 1, true>": 3 * B * 256 * s,
+           "nig_fwd_kernel<false>": B * 192 * s + B * 12 * 4 + 7 * B * 3 * 4, "nig_bwd_kernel<false>": 2 * B * 192 * s + B * 12 * 4 + B * 3 * 4,
+           "tri_fused_kernel<1>": 2 * B * 512 * s + 1536 * 512 * s + B * 512 * s + B * 32 * 4 + 2 * B * 1536 * s}
+    out = {"file": "profiles/" + meta["csv"], "hbm_gbps": {}}
+    k = "tri_fused_kernel<0>"
+    if k in avg:
+        out["roofline_kernel_avg_us"] = round(avg[k] * 1e6, 2)
+        out["frac_rocprof"] = round(2.0 * (2 * B) * 512 * 1536 / avg[k] / BF16_MFMA_PEAK, 4)
+    for name, nbytes in hbm.items():
+        if name in avg:
+            out["hbm_gbps"][name] = {"gbps": round(nbytes / avg[name] / 1e9, 1), "frac_of_8TBps": round(nbytes / avg[name] / 8e12, 3),
+                                     "avg_us": round(avg[name] * 1e6, 2), "algorithmic_bytes": nbytes}
+    return out
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -369,6 +404,8 @@ def main():
         gemm_ms = sorted(e0.elapsed_time(e1) for e0, e1 in prof)
         avg_ms = sum(gemm_ms) / len(gemm_ms)
         flops = 2.0 * (2 * B) * 512 * 1536                      # algorithmic: SURVEY 8d, 3.146 MFLOP/sample forward
+        fused = args.dtype == "bf16" and os.environ.get("MMDEER_FUSED_ATTN", "1") != "0"
+        step_flops = 3 * 2.0 * 3950336 * B                       # 7.90 MFLOP/sample forward, x3 for the train step
         peak = BF16_MFMA_PEAK if args.dtype == "bf16" else F32_MFMA_PEAK
         achieved = flops / (avg_ms * 1e-3)
         out = {
@@ -395,15 +432,27 @@ def main():
             "final_loss": round(loss, 6),
             "train_step_with_optimizer_ms": round(full_elapsed / K * 1e3, 4),     # fwd + bwd + clip + AdamW + weight pack
             "optimizer_ms": round((full_elapsed - elapsed) / K * 1e3, 4),
-            "roofline": {"bound": "mfma", "kernel": ("gemm_nt256_kernel<192>" if args.dtype == "bf16" else "gemm_group_kernel") + " (trimodal in_proj, M=2B K=512 N=1536)",
+            "roofline": {"bound": "mfma",
+                         "kernel": ("tri_fused_kernel<0> (trimodal in_proj M=2B K=512 N=1536 + 2-token attention fused: q|k|v stay on chip)" if fused
+                                    else ("gemm_nt256_kernel<192>" if args.dtype == "bf16" else "gemm_group_kernel") + " (trimodal in_proj, M=2B K=512 N=1536)"),
                          "achieved": round(achieved / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
-                         # HBM-side bytes of one launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950
-                         # + WRITE_SIZE, profiles/r01_pmc_gemm_kernels.txt); algorithmic bytes: A 8.39 + W 1.57 + C 25.17 MB
+                         # HBM-side bytes of one launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE,
+                         # tools/gpu_pmc_fused.sh -> profiles/pmc_traffic.json); null unless taken on exactly these kernel sources
                          "traffic": measured_traffic(args.dtype, B),
-                         "algorithmic_bytes": 2 * B * 512 * 2 + 1536 * 512 * 2 + 2 * B * 1536 * 2,
-                         "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(gemm_ms[len(gemm_ms) // 2] * 1e3, 2)},
+                         # fused: X 8.39 + W 1.57 + obar 4.19 + probs 0.52 MB; unfused GEMM: A 8.39 + W 1.57 + C 25.17 MB
+                         "algorithmic_bytes": (2 * B * 512 * 2 + 1536 * 512 * 2 + B * 512 * 2 + B * 32 * 4) if fused
+                                              else (2 * B * 512 * 2 + 1536 * 512 * 2 + 2 * B * 1536 * 2),
+                         "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(gemm_ms[len(gemm_ms) // 2] * 1e3, 2),
+                         "timing": "HIP events around the kernel's launch inside K eager steps on the launch stream (includes the ~3 us the "
+                                   "event pair and the launch gap cost); the rocprofv3 average of the same launches is in `rocprof`",
+                         # the whole step against the same peak: 97.1 GFLOP (algorithmic) / step time
+                         "step_frac": round(step_flops / (elapsed / K) / peak, 4)},
         }
+        rp = rocprof_record(B, args.dtype, elapsed / K * 1e3)
+        if rp is not None:
+            out["roofline"]["frac_rocprof"] = rp.pop("frac_rocprof", None)
+            out["rocprof"] = rp
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out), flush=True)

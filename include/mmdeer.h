@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 10
+#define MMDEER_ABI_VERSION 11
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -198,6 +198,23 @@ int mmdeer_trimodal_attn_fwd(const void* qkv, void* obar, float* probs, float* a
                              int act_f32, int training, float dropout_p, uint64_t seed, uint64_t offset, void* stream);
 int mmdeer_trimodal_attn_bwd(const void* qkv, const void* dobar, const float* probs, void* dqkv, int B,
                              int act_f32, int training, float dropout_p, uint64_t seed, uint64_t offset, void* stream);
+
+/* The same attention with the packed in_proj FUSED in (bf16 compute; reference fusion.py:328-335, i.e. the
+ * F.multi_head_attention_forward call behind nn.MultiheadAttention: in_proj -> scaled 2x2 scores -> softmax -> dropout -> P V,
+ * followed by the mean over the two tokens that fusion.py:335 applies after out_proj and that commutes with it).
+ *   mmdeer_pack_qkv_headmajor: in_proj_weight fp32 [1536][512] -> the head-major bf16 operand image (1536*512 bf16) the
+ *                              fused kernels read; redo after every parameter update.
+ *   mmdeer_trimodal_fused_fwd: xtok bf16 [2B][512] (row 2b + t) -> obar bf16 [B][512], probs fp32 [B][8][4]; q|k|v stay
+ *                              on chip unless qkv_out (bf16 [2B][1536], optional) is given.  attn_w / av_w as above, optional.
+ *   mmdeer_trimodal_fused_bwd: recomputes q|k|v per head tile and writes dqkv bf16 [2B][1536] from dobar bf16 [B][512]
+ *                              and the saved probs. */
+int mmdeer_pack_qkv_headmajor(const float* in_proj_weight, void* whm_bf16, void* stream);
+int mmdeer_trimodal_fused_fwd(const void* xtok, const void* whm_bf16, const float* in_proj_bias, void* obar, float* probs,
+                              void* qkv_out, float* attn_w, float* av_w, int B, int training, float dropout_p, uint64_t seed,
+                              uint64_t offset, void* stream);
+int mmdeer_trimodal_fused_bwd(const void* xtok, const void* whm_bf16, const float* in_proj_bias, const void* dobar,
+                              const float* probs, void* dqkv, int B, int training, float dropout_p, uint64_t seed,
+                              uint64_t offset, void* stream);
 
 /* MultiTaskDEERLoss on given NIG parameters [B,3] (losses.py:268-348); gradients optional (all four or none).
  * stats: scratch of mmdeer_nig_stats_elems(B) floats. */

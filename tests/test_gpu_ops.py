@@ -295,6 +295,70 @@ def test_trimodal_attention(act_f32, training, B):
     assert (dqkv.double() - qr.grad).abs().max().item() < (5e-5 if act_f32 else 5e-2)
 
 
+@pytest.mark.parametrize("training", [0, 1])
+@pytest.mark.parametrize("B", [1, 37, 128, 300, 1024])
+def test_fused_projection_attention(training, B):
+    """tri_fused.hip (in_proj + 2-token attention in one kernel, q|k|v on chip) against fp64 math on the same bf16
+    operands: obar, probabilities, returned weights, the optional q|k|v tile; backward (recompute) dqkv against autograd.
+    B = 1 / 37 / 300: ragged row tiles (rows beyond 2B are never stored); 1024: several row tiles per XCD group."""
+    lib = _lib.load()
+    x = rnd(2 * B, 512, seed=50, scale=1.0).bfloat16()
+    w = rnd(1536, 512, seed=51, scale=0.06)                      # fp32 master in_proj_weight
+    bias = rnd(1536, seed=52, scale=0.2)
+    whm = torch.empty(1536 * 512, dtype=torch.bfloat16, device=dev())
+    _lib.check(lib.mmdeer_pack_qkv_headmajor(w.data_ptr(), whm.data_ptr(), stream()))
+    obar = torch.full((B, 512), float("nan"), dtype=torch.bfloat16, device=dev())
+    probs = torch.full((B, 8, 4), float("nan"), device=dev())
+    attn_w = torch.empty(B, 2, 2, device=dev())
+    avw = torch.empty(B, 2, device=dev())
+    qkv = torch.full((2 * B, 1536), float("nan"), dtype=torch.bfloat16, device=dev())
+    p, seed, off = 0.3, 91, 5
+    _lib.check(lib.mmdeer_trimodal_fused_fwd(x.data_ptr(), whm.data_ptr(), bias.data_ptr(), obar.data_ptr(), probs.data_ptr(),
+                                             qkv.data_ptr(), attn_w.data_ptr(), avw.data_ptr(), B, training, p, seed, off, stream()))
+    drop = None
+    if training:
+        m = torch.empty(B, 32, dtype=torch.uint8, device=dev())
+        _lib.check(lib.mmdeer_dropout_mask(3, B, 32, p, seed, off, m.data_ptr(), stream()))
+        drop = m.double().view(B, 8, 2, 2) / (1 - p)
+    torch.cuda.synchronize()
+    # head-major image: row 96 wn + 32 part + dd of head h  <-  in_proj_weight[part * 512 + 64 h + 32 wn + dd]
+    img = whm.view(8, 2, 3, 32, 512)
+    want = w.bfloat16().view(3, 8, 2, 32, 512).permute(1, 2, 0, 3, 4)
+    assert torch.equal(img, want)
+    xr = x.double().requires_grad_(True)
+    wr = w.bfloat16().double()
+    qkv_ref = xr @ wr.t() + bias.double()
+    obar_ref, p_ref, w_ref = _attn_ref(qkv_ref, drop)
+    assert torch.isfinite(obar.float()).all() and torch.isfinite(probs).all() and torch.isfinite(qkv.float()).all()
+    assert (qkv.double() - qkv_ref).abs().max().item() < 3e-2            # bf16 rounding of O(1) values
+    assert (probs.double().view(B, 8, 2, 2) - p_ref).abs().max().item() < 6e-3   # scores on the matrix pipe: q, k rounded to bf16
+    assert (obar.double() - obar_ref).abs().max().item() < 1.2e-2 * max(1.0, obar_ref.abs().max().item())   # bf16 output
+    assert (attn_w.double() - w_ref).abs().max().item() < 6e-3
+    # without the optional q|k|v tile the results are the same bits
+    obar2 = torch.empty_like(obar); probs2 = torch.empty_like(probs)
+    _lib.check(lib.mmdeer_trimodal_fused_fwd(x.data_ptr(), whm.data_ptr(), bias.data_ptr(), obar2.data_ptr(), probs2.data_ptr(),
+                                             None, None, None, B, training, p, seed, off, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(obar.view(torch.int16), obar2.view(torch.int16)) and torch.equal(probs, probs2)
+    # backward: recomputed q|k|v, d(obar) -> dqkv
+    dob = rnd(B, 512, seed=53).bfloat16()
+    dqkv = torch.full((2 * B, 1536), float("nan"), dtype=torch.bfloat16, device=dev())
+    _lib.check(lib.mmdeer_trimodal_fused_bwd(x.data_ptr(), whm.data_ptr(), bias.data_ptr(), dob.data_ptr(), probs.data_ptr(),
+                                             dqkv.data_ptr(), B, training, p, seed, off, stream()))
+    torch.cuda.synchronize()
+    qr = qkv_ref.detach().requires_grad_(True)
+    o2, _, _ = _attn_ref(qr, drop)
+    o2.backward(dob.double())
+    assert torch.isfinite(dqkv.float()).all()
+    assert (dqkv.double() - qr.grad).abs().max().item() < 3e-2 * max(1.0, qr.grad.abs().max().item())
+    # and it agrees with the unfused attention-backward kernel run on the stored q|k|v tile (bf16 rounding of q, k, v apart)
+    dq2 = torch.empty_like(dqkv)
+    _lib.check(lib.mmdeer_trimodal_attn_bwd(qkv.data_ptr(), dob.data_ptr(), probs.data_ptr(), dq2.data_ptr(), B, 0, training,
+                                            p, seed, off, stream()))
+    torch.cuda.synchronize()
+    assert (dqkv.double() - dq2.double()).abs().max().item() < 3e-2 * max(1.0, qr.grad.abs().max().item())
+
+
 def test_nig_loss_vs_oracle(golden_dir):
     import os
     from oracle import deer_oracle as O

@@ -142,6 +142,9 @@ SYMBOLS = [
     ("mmdeer_layernorm_bwd", c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_void_p]),
     ("mmdeer_trimodal_attn_fwd", c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p]),
     ("mmdeer_trimodal_attn_bwd", c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p]),
+    ("mmdeer_pack_qkv_headmajor", c_int, [c_void_p] * 3),
+    ("mmdeer_trimodal_fused_fwd", c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_u64, c_u64, c_void_p]),
+    ("mmdeer_trimodal_fused_bwd", c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_u64, c_u64, c_void_p]),
     ("mmdeer_nig_stats_elems", c_ll, [c_int]),
     ("mmdeer_nig_loss", c_int, [c_void_p] * 12 + [c_int, C.POINTER(LossCfg), c_void_p]),
     ("mmdeer_deer_loss_v1_scratch", c_ll, [c_ll]),
@@ -197,7 +200,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 10:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 11:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         _LIB = lib
     return _LIB

@@ -16,7 +16,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(PKG_DIR, "libmmdeer_hip.so")
-SOURCES = ["gemm_nt.hip", "gemm_nx.hip", "gemm_tt.hip", "gemm_glds.hip", "gemm_tt256.hip", "gemm_nt256.hip", "gemm.hip", "rowops.hip", "attention.hip", "chain.hip", "nig.hip", "optim.hip", "side.hip", "stackb.hip", "comm.hip", "api.hip"]
+SOURCES = ["gemm_nt.hip", "gemm_nx.hip", "gemm_tt.hip", "gemm_glds.hip", "gemm_tt256.hip", "gemm_nt256.hip", "gemm.hip", "rowops.hip", "attention.hip", "tri_fused.hip", "chain.hip", "nig.hip", "optim.hip", "side.hip", "stackb.hip", "comm.hip", "api.hip"]
 ARCH = "gfx950"
 # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs at wave start (gemm_glds.hip)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -46,6 +46,17 @@ def build_stamps() -> str:
     out = os.path.join(PKG_DIR, "libmmdeer_stamps.so")
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     r = subprocess.run([hipcc, *FLAGS, "-DMMDEER_STAMPS", "-shared", "-o", out, *srcs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return out
+
+
+def build_variant(name: str, defines=()) -> str:
+    """A/B library libmmdeer_var_<name>.so built with extra -D flags (tools/ab_fused.py); never loaded by the product."""
+    hipcc = _hipcc()
+    out = os.path.join(PKG_DIR, f"libmmdeer_var_{name}.so")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    r = subprocess.run([hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-shared", "-o", out, *srcs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr)
     return out

@@ -17,6 +17,9 @@
 
 namespace mmdeer {
 
+#ifdef MMDEER_STAMPS
+void tf_set_stamps(unsigned long long* p);   // tri_fused.hip
+#endif
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -76,6 +79,7 @@ struct Layout {
   char* wtpack;  // transposed weight matrices (W^T, compute dtype) at the same flat offsets: dX runs as an NT GEMM
   char* wa_pad;  // bf16 mode: audio_projection.weight as [256][AUD_PAD] (zero-padded rows, 16-byte aligned)
   char* audio_pad;  // bf16 mode: the audio feature block as [B][AUD_PAD]
+  char* wqkv_hm; // bf16 mode: head-major image of the trimodal in_proj weight for the fused projection + attention kernels
   char* wchain;  // bf16 mode: fragment-major images of the head weights for the row-block chain kernel (CHAIN_* offsets)
   float* vpack;  // fp32 vectors, MMDEER_FLAT_ELEMS
   // saved activations (activation dtype unless noted)
@@ -103,6 +107,7 @@ Layout make_layout(void* base, int B, int f32) {
   L.vpack = reinterpret_cast<float*>(take((size_t)MMDEER_FLAT_ELEMS * 4));
   L.wa_pad = take((size_t)INTER * AUD_PAD * 2);
   L.audio_pad = take(Bz * AUD_PAD * 2);
+  L.wqkv_hm = take((size_t)3 * FUS * FUS * 2);
   L.wchain = take((size_t)CH_TOTAL * 2);
   auto act = [&](size_t rows, size_t cols) { return take(rows * cols * es); };
   auto f32buf = [&](size_t n) { return reinterpret_cast<float*>(take(n * 4)); };
@@ -172,6 +177,19 @@ int env_chain() {
 int env_side() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MMDEER_SIDE"); v = e ? atoi(e) : 0; }
+  return v;
+}
+// MMDEER_FUSED_ATTN=0: the unfused pair (in_proj GEMM writing q|k|v + one-wave-per-sample attention kernels) also in bf16
+// mode.  Default 1: tri_fused.hip.  MMDEER_QKV_RECOMPUTE=0 (with the fused forward): the forward also stores q|k|v and
+// the backward runs the unfused attention-backward kernel on it instead of recomputing the head tiles.
+int env_fused_attn() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_FUSED_ATTN"); v = e ? atoi(e) : 1; }
+  return v;
+}
+int env_qkv_recompute() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_QKV_RECOMPUTE"); v = e ? atoi(e) : 1; }
   return v;
 }
 struct SideCtx {
@@ -397,7 +415,9 @@ int pad_audio_weight(const void* const* params, const Layout& L, hipStream_t s) 
   PadTable pt{};
   pt.src[0] = params[P_AUD_W]; pt.dst[0] = L.wa_pad; pt.src_f32[0] = 1; pt.rows[0] = INTER; pt.cols[0] = AUD; pt.ld_dst[0] = AUD_PAD;
   pt.nseg = 1;
-  return launch_pad_cols(pt, s);
+  if (launch_pad_cols(pt, s) != 0) return -1;
+  // ... and the head-major image of the trimodal in_proj weight (tri_fused.hip)
+  return launch_pack_qkv_headmajor(reinterpret_cast<const float*>(params[P_TIN_W]), L.wqkv_hm, s);
 }
 
 }  // namespace
@@ -482,6 +502,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
       pt.nseg = 2;
     }
     TRY(launch_pad_cols(pt, s));
+    if (wa_pending) TRY(launch_pack_qkv_headmajor(reinterpret_cast<const float*>(a->params[P_TIN_W]), L.wqkv_hm, s));
   }
   // F1: the three input projections (fusion.py:236-237, 322) in one launch
   {
@@ -518,11 +539,18 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   // F6: audiovisual_projection -> token 0 (fusion.py:321, 325)
   TRY(X.run1(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1)));
   // F7: packed q|k|v in_proj of the 2-token self-attention (fusion.py:328)
+  //     + F8: 2x2 softmax attention, token-pooled context.  bf16: ONE kernel, q|k|v stay in its accumulators
   if (a->prof_events[0]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[0], s));
-  TRY(X.run1(X.fwd(L.xtok, f32, FUS, P_TIN_W, P_TIN_B, L.qkv, 3 * FUS, 2 * B, 0, -1)));
-  if (a->prof_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[1], s));
-  // F8: 2x2 softmax attention, token-pooled context
-  TRY(launch_tri_attn_fwd(L.qkv, L.obar, L.probs, a->trimodal_attention, a->av_attention, B, f32, X.drop_on ? 1 : 0, X.dc, s));
+  if (!f32 && env_fused_attn()) {
+    void* qkv_out = (a->training && !env_qkv_recompute()) ? L.qkv : nullptr;
+    TRY(launch_tri_fused_fwd(L.xtok, L.wqkv_hm, X.V(P_TIN_B), L.obar, L.probs, qkv_out, B, X.drop_on ? 1 : 0, X.dc, s));
+    if (a->prof_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[1], s));
+    TRY(launch_tri_attn_weights(L.probs, a->trimodal_attention, a->av_attention, B, X.drop_on ? 1 : 0, X.dc, s));
+  } else {
+    TRY(X.run1(X.fwd(L.xtok, f32, FUS, P_TIN_W, P_TIN_B, L.qkv, 3 * FUS, 2 * B, 0, -1)));
+    if (a->prof_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[1], s));
+    TRY(launch_tri_attn_fwd(L.qkv, L.obar, L.probs, a->trimodal_attention, a->av_attention, B, f32, X.drop_on ? 1 : 0, X.dc, s));
+  }
   // F9: out_proj on the pooled context (mean over tokens commutes with the linear map; fusion.py:335)
   TRY(X.run1(X.fwd(L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, L.pool, FUS, B, 0, -1)));
   // F10-F11: final_fusion (fusion.py:338)
@@ -714,7 +742,10 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   TRY(launch_ln_bwd(L.dtri, L.y_t3, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), L.dz_t3, L.part_ln_t3, B, FUS, f32, X.mask_scale, s));
   TRY(X.run1(X.dx(L.dz_t3, FUS, P_TFF_W, L.dpool, FUS, B, nullptr, 0)));
   TRY(X.run1(X.dx(L.dpool, FUS, P_TOUT_W, L.dobar, FUS, B, nullptr, 0)));      // attention out_proj (pooled context)
-  TRY(launch_tri_attn_bwd(L.qkv, L.dobar, L.probs, L.dqkv, B, f32, X.drop_on ? 1 : 0, X.dc, s));
+  if (!f32 && env_fused_attn() && env_qkv_recompute())    // the forward kept q|k|v on chip: recompute the head tiles
+    TRY(launch_tri_fused_bwd(L.xtok, L.wqkv_hm, X.V(P_TIN_B), L.dobar, L.probs, L.dqkv, B, X.drop_on ? 1 : 0, X.dc, s));
+  else
+    TRY(launch_tri_attn_bwd(L.qkv, L.dobar, L.probs, L.dqkv, B, f32, X.drop_on ? 1 : 0, X.dc, s));
   TRY(X.run1(X.dx(L.dqkv, 3 * FUS, P_TIN_W, L.dxtok, FUS, 2 * B, nullptr, 0)));  // in_proj
   TRY(X.run1(X.dx(L.dxtok, 2 * FUS, P_AVP_W, L.dav, INTER, B, nullptr, 0)));     // token 0 -> audiovisual features
   {
@@ -776,6 +807,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
 // diagnostic library only (not part of the ABI): 32 uint64 slots, forward chain stamps at [0,16), backward at [16,32)
 int mmdeer_debug_nig_stamps(unsigned long long* out16) { return mmdeer::debug_nig_stamps(out16); }
 void mmdeer_debug_chain_stamps(void* p) { g_chain_stamps = reinterpret_cast<unsigned long long*>(p); }
+void mmdeer_debug_tf_stamps(void* p) { mmdeer::tf_set_stamps(reinterpret_cast<unsigned long long*>(p)); }
 #endif
 
 // ------------------------------------------------------------------ optimiser step
@@ -902,6 +934,31 @@ int mmdeer_trimodal_attn_bwd(const void* qkv, const void* dobar, const float* pr
                              int act_f32, int training, float dropout_p, uint64_t seed, uint64_t offset, void* stream) {
   const DropCtx dc = make_drop(dropout_p, seed, offset);
   return launch_tri_attn_bwd(qkv, dobar, probs, dqkv, B, act_f32, (training && dropout_p > 0.f) ? 1 : 0, dc, (hipStream_t)stream);
+}
+
+int mmdeer_pack_qkv_headmajor(const float* in_proj_weight, void* whm_bf16, void* stream) {
+  MMDEER_CHECK(in_proj_weight && whm_bf16, "pack_qkv_headmajor: NULL argument");
+  MMDEER_CHECK(((uintptr_t)in_proj_weight % 16) == 0 && ((uintptr_t)whm_bf16 % 16) == 0, "pack_qkv_headmajor: buffers must be 16-byte aligned");
+  return launch_pack_qkv_headmajor(in_proj_weight, whm_bf16, (hipStream_t)stream);
+}
+int mmdeer_trimodal_fused_fwd(const void* xtok, const void* whm_bf16, const float* in_proj_bias, void* obar, float* probs,
+                              void* qkv_out, float* attn_w, float* av_w, int B, int training, float dropout_p, uint64_t seed,
+                              uint64_t offset, void* stream) {
+  MMDEER_CHECK(B >= 0, "trimodal_fused_fwd: batch must be >= 0 (got %d)", B);
+  MMDEER_CHECK(B == 0 || (xtok && whm_bf16 && in_proj_bias && obar && probs), "trimodal_fused_fwd: NULL argument");
+  const DropCtx dc = make_drop(dropout_p, seed, offset);
+  const int train = (training && dropout_p > 0.f) ? 1 : 0;
+  TRY(launch_tri_fused_fwd(xtok, whm_bf16, in_proj_bias, obar, probs, qkv_out, B, train, dc, (hipStream_t)stream));
+  return launch_tri_attn_weights(probs, attn_w, av_w, B, train, dc, (hipStream_t)stream);
+}
+int mmdeer_trimodal_fused_bwd(const void* xtok, const void* whm_bf16, const float* in_proj_bias, const void* dobar,
+                              const float* probs, void* dqkv, int B, int training, float dropout_p, uint64_t seed,
+                              uint64_t offset, void* stream) {
+  MMDEER_CHECK(B >= 0, "trimodal_fused_bwd: batch must be >= 0 (got %d)", B);
+  MMDEER_CHECK(B == 0 || (xtok && whm_bf16 && in_proj_bias && dobar && probs && dqkv), "trimodal_fused_bwd: NULL argument");
+  const DropCtx dc = make_drop(dropout_p, seed, offset);
+  return launch_tri_fused_bwd(xtok, whm_bf16, in_proj_bias, dobar, probs, dqkv, B, (training && dropout_p > 0.f) ? 1 : 0, dc,
+                              (hipStream_t)stream);
 }
 
 int mmdeer_loss_stats(const void* workspace, size_t workspace_bytes, int batch, int compute_f32, float* out, void* stream) {

@@ -34,8 +34,12 @@ enum { DT_BF16 = 0, DT_F32 = 1 };
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 // round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+// two floats -> one dword of two bf16: a vector conversion lowers to ONE v_cvt_pk_bf16_f32 (the scalar form above, twice,
+// plus shift / or cost 4 instructions per pair in every bf16 epilogue)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 template <typename T> struct Elem;
