@@ -52,8 +52,12 @@ int mmdeer_param_cols(int i);                  /* 1 for vectors */
 long long mmdeer_param_offset(int i);          /* element offset in the flat buffers */
 long long mmdeer_flat_elems(void);             /* elements of the flat gradient buffer */
 
-/* bytes of `workspace` needed for a batch of B samples (holds packed weights, saved activations, scratch) */
+/* bytes of `workspace` needed for a batch of B samples (saved activations, backward scratch, split-K slabs) */
 size_t mmdeer_workspace_bytes(int batch, int compute_f32);
+/* bytes of `weights`: the packed copies of the parameters the kernels read (compute-dtype matrices, their W^T copies,
+ * fp32 vectors, the padded audio weight, the head-major in_proj image).  ONE buffer per model and compute dtype, shared
+ * by the workspaces of every batch size; written by mmdeer_forward(repack = 1), mmdeer_pack_weights and mmdeer_adamw_step. */
+size_t mmdeer_weights_bytes(int compute_f32);
 
 typedef struct mmdeer_loss_cfg {
   float reg_weight;    /* losses.py:52  0.1  */
@@ -71,7 +75,7 @@ typedef struct mmdeer_forward_args {
   int32_t compute_f32;      /* 1: exact-fp32 MFMA path (parity config); 0: bf16 MFMA, fp32 accumulate */
   int32_t training;         /* 1: dropout active (counter-based hash keyed by seed/offset) */
   int32_t inputs_bf16;      /* 0: audio/video/text are fp32; 1: bf16 */
-  int32_t repack;           /* 1: parameters changed since the last call with this workspace */
+  int32_t repack;           /* 1: parameters changed since `weights` was last written */
   float dropout_p;
   uint64_t seed, offset;
   const uint64_t* offset_dev; /* optional device counter added to `offset` when the kernels run: lets a captured HIP
@@ -84,6 +88,8 @@ typedef struct mmdeer_forward_args {
   const void* const* params;/* MMDEER_NUM_PARAMS_ABI fp32 device pointers, canonical order */
   void* workspace;
   size_t workspace_bytes;
+  void* weights;            /* mmdeer_weights_bytes(compute_f32) bytes, 256-byte aligned */
+  size_t weights_bytes;
   /* fp32 outputs; any may be NULL */
   float* nig_out;           /* [7][B][3]: mu, nu, alpha, beta, aleatoric, epistemic, uncertainty (deer.py:100-108) */
   float* fused_features;    /* [B, 512]  fusion.py:165 */
@@ -119,6 +125,8 @@ typedef struct mmdeer_backward_args {
   const void* text;
   void* workspace;
   size_t workspace_bytes;
+  void* weights;            /* the buffer the matching mmdeer_forward read */
+  size_t weights_bytes;
   const float* targets;
   const float* g_mu;
   const float* g_nu;
@@ -130,8 +138,8 @@ typedef struct mmdeer_backward_args {
   int32_t* bin_counts;      /* [3][10] ECE bin populations or NULL */
   /* optional: hipEvent_t handles recorded when a gradient bucket of the flat buffer is final:
    * bucket 0 = head (params 28..49), 1 = output_projection + trimodal (12..27), 2 = audio-visual (0..11).
-   * In the default launch plan all weight gradients are produced by one grouped launch at the end of the pass, so
-   * the three events are recorded together; with MMDEER_SIDE=1 each one follows its own bucket. */
+   * All weight gradients are produced by one grouped launch at the end of the pass (or of phase 1), so the events of
+   * the buckets it covers are recorded together. */
   void* bucket_events[3];
   /* 0: the whole backward pass.  1 / 2: the pass in two calls -- 1 = head + output_projection + trimodal fusion
    * including their weight gradients (buckets 0 and 1 of the flat buffer are final when it returns), 2 = the
@@ -249,12 +257,11 @@ int mmdeer_dropout_mask(int site, int rows, int cols, float dropout_p, uint64_t 
 
 /* ---- optimiser step on the device (reference src/training/training.py:121-150, 219-224) ------------
  * clip_grad_norm_(max_grad_norm) + torch.optim.AdamW (decoupled weight decay, eps 1e-8 in the reference) on the flat
- * gradient buffer of mmdeer_backward.  Updates the fp32 master parameters in place and refreshes, in `workspace`,
+ * gradient buffer of mmdeer_backward.  Updates the fp32 master parameters in place and refreshes, in `weights`,
  * the packed copies mmdeer_forward / mmdeer_backward read -- so the next mmdeer_forward may pass repack = 0.
  * `lr` is a HOST array with one learning rate per live parameter (ABI order): the reference's three parameter
  * groups (0.5 lr for names containing "encoder", lr otherwise) reduce to that.  No host synchronisation. */
 typedef struct {
-  int32_t batch;              /* batch size the workspace was sized for */
   int32_t compute_f32;        /* dtype of the packed matrices, as in mmdeer_forward */
   int32_t pack_transposed;    /* 1: also refresh the W^T copies used by mmdeer_backward */
   int32_t step;               /* 1-based step count t (bias corrections 1 - beta^t) */
@@ -267,18 +274,17 @@ typedef struct {
   float* exp_avg;             /* flat first moments  (mmdeer_flat_elems() floats, zero before the first step) */
   float* exp_avg_sq;          /* flat second moments */
   float* grad_norm;           /* device scalar out (may be NULL): global gradient norm before clipping */
-  void* workspace;
-  size_t workspace_bytes;
+  void* weights;              /* mmdeer_weights_bytes(compute_f32) bytes */
+  size_t weights_bytes;
   void* stream;
 } mmdeer_adamw_args;
 int mmdeer_adamw_step(const mmdeer_adamw_args* a);
 
-/* Refresh every packed copy of the parameters in `workspace` (the compute-dtype matrices, their W^T copies, the padded
- * audio weight) without running a pass -- what mmdeer_forward does when repack = 1.  For a caller that replays a
- * captured graph (repack = 0 is frozen into it) after something else changed the parameters: a step on another batch
- * size, whose optimiser call refreshed only that batch size's workspace. */
-int mmdeer_pack_weights(const void* const* params, void* workspace, size_t workspace_bytes, int batch, int compute_f32,
-                        void* stream);
+/* Refresh every packed copy of the parameters in `weights` (the compute-dtype matrices, their W^T copies, the padded
+ * audio weight, the head-major in_proj image) without running a pass -- what mmdeer_forward does when repack = 1.  For a
+ * caller that replays a captured graph (repack = 0 is frozen into it) after something other than mmdeer_adamw_step
+ * changed the parameters. */
+int mmdeer_pack_weights(const void* const* params, void* weights, size_t weights_bytes, int compute_f32, void* stream);
 
 /* ---- side rows (a8, a9, a14), forward only --------------------------------------------------------
  * Their Linear(+ReLU) layers run on mmdeer_gemm and the LayerNorm on mmdeer_layernorm_fwd; the two entry points

@@ -292,10 +292,11 @@ def test_graph_captured_train_step_matches_eager():
     assert float(d1["total_loss"]) == float(d2["total_loss"])
 
 
-def test_alternative_launch_plans_match_the_default():
-    """MMDEER_CHAIN=1 (head layers as one row-block chain launch, csrc/chain.hip) and MMDEER_SIDE=1 (weight-gradient
-    buckets on a side stream) reproduce the default plan: the switches are read once per process, so each mode runs in
-    its own interpreter."""
+def test_attention_launch_plans_match_each_other():
+    """The three plans of the trimodal attention block -- fused projection + attention with the backward recomputing q|k|v
+    (default), fused forward that also stores q|k|v for the unfused backward kernel (MMDEER_QKV_RECOMPUTE=0), and the
+    unfused pair (MMDEER_FUSED_ATTN=0) -- give the same training step up to the bf16 rounding of q, k, v: the switches
+    are read once per process, so each plan runs in its own interpreter."""
     import subprocess
     import sys
 
@@ -311,16 +312,14 @@ def test_alternative_launch_plans_match_the_default():
         "print(json.dumps({'loss': float(d['total_loss']), 'gsum': float(g.double().sum()), 'gabs': float(g.double().abs().sum())}))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    # default | head layers as row-block chains | weight-gradient buckets on the library's side stream
-    for mode, extra in (("default", {}), ("chain", {"MMDEER_CHAIN": "1"}), ("side", {"MMDEER_SIDE": "1"})):
+    for mode, extra in (("default", {}), ("store_qkv", {"MMDEER_QKV_RECOMPUTE": "0"}), ("unfused", {"MMDEER_FUSED_ATTN": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[mode] = json.loads(r.stdout.strip().splitlines()[-1])
-    for mode in ("chain", "side"):
-        assert outs["default"]["loss"] == pytest.approx(outs[mode]["loss"], rel=1e-6), mode
-        assert outs["default"]["gabs"] == pytest.approx(outs[mode]["gabs"], rel=1e-4), mode
-        assert outs["default"]["gsum"] == pytest.approx(outs[mode]["gsum"], rel=1e-3, abs=1e-6), mode
+    for mode in ("store_qkv", "unfused"):
+        assert outs["default"]["loss"] == pytest.approx(outs[mode]["loss"], rel=2e-3), mode
+        assert outs["default"]["gabs"] == pytest.approx(outs[mode]["gabs"], rel=2e-2), mode
 
 
 def test_two_phase_backward_equals_single_call():

@@ -39,7 +39,7 @@ class ForwardArgs(C.Structure):
         ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("offset_dev", c_void_p), ("bump_offset_dev", c_int),
         ("audio", c_void_p), ("video", c_void_p), ("text", c_void_p),
         ("params", C.POINTER(c_void_p)),
-        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("weights", c_void_p), ("weights_bytes", c_size_t),
         ("nig_out", c_void_p), ("fused_features", c_void_p), ("audiovisual_features", c_void_p),
         ("trimodal_features", c_void_p), ("av_attention", c_void_p), ("trimodal_attention", c_void_p),
         ("targets", c_void_p), ("prof_events", c_void_p * 2), ("stream", c_void_p),
@@ -51,7 +51,7 @@ class BackwardArgs(C.Structure):
         ("batch", c_int), ("compute_f32", c_int), ("training", c_int), ("inputs_bf16", c_int),
         ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("offset_dev", c_void_p),
         ("audio", c_void_p), ("video", c_void_p), ("text", c_void_p),
-        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("weights", c_void_p), ("weights_bytes", c_size_t),
         ("targets", c_void_p), ("g_mu", c_void_p), ("g_nu", c_void_p), ("g_alpha", c_void_p), ("g_beta", c_void_p),
         ("loss", LossCfg),
         ("grads", c_void_p), ("loss_out", c_void_p), ("bin_counts", c_void_p),
@@ -61,12 +61,12 @@ class BackwardArgs(C.Structure):
 
 class AdamWArgs(C.Structure):
     _fields_ = [
-        ("batch", c_int), ("compute_f32", c_int), ("pack_transposed", c_int), ("step", c_int),
+        ("compute_f32", c_int), ("pack_transposed", c_int), ("step", c_int),
         ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
         ("max_grad_norm", c_float), ("grad_scale", c_float),
         ("lr", C.POINTER(c_float)), ("params", C.POINTER(c_void_p)), ("grads", c_void_p),
         ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("grad_norm", c_void_p),
-        ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("stream", c_void_p),
+        ("weights", c_void_p), ("weights_bytes", c_size_t), ("stream", c_void_p),
     ]
 
 
@@ -131,6 +131,7 @@ SYMBOLS = [
     ("mmdeer_param_offset", c_ll, [c_int]),
     ("mmdeer_flat_elems", c_ll, []),
     ("mmdeer_workspace_bytes", c_size_t, [c_int, c_int]),
+    ("mmdeer_weights_bytes", c_size_t, [c_int]),
     ("mmdeer_forward", c_int, [C.POINTER(ForwardArgs)]),
     ("mmdeer_backward", c_int, [C.POINTER(BackwardArgs)]),
     ("mmdeer_loss_stats", c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
@@ -153,7 +154,7 @@ SYMBOLS = [
     ("mmdeer_calibration_loss", c_int, [c_void_p] * 4 + [c_ll] + [c_void_p] * 5 + [c_void_p]),
     ("mmdeer_dropout_mask", c_int, [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p]),
     ("mmdeer_adamw_step", c_int, [C.POINTER(AdamWArgs)]),
-    ("mmdeer_pack_weights", c_int, [C.POINTER(c_void_p), c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    ("mmdeer_pack_weights", c_int, [C.POINTER(c_void_p), c_void_p, c_size_t, c_int, c_void_p]),
     ("mmdeer_cross_modal_attn_fwd", c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     ("mmdeer_lstm_cell_t1", c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_eval_accumulate", c_int, [c_void_p] * 6 + [c_int, c_void_p]),

@@ -8,7 +8,6 @@
 
 #include "../../include/mmdeer.h"
 #include "attention.h"
-#include "chain.h"
 #include "common.h"
 #include "gemm.h"
 #include "nig.h"
@@ -66,22 +65,21 @@ constexpr int P_EV2_W = MMDEER_P_HEAD0_EV6_WEIGHT, P_EV2_B = MMDEER_P_HEAD0_EV6_
 constexpr int AUD = MMDEER_AUDIO_DIM, VID = MMDEER_VIDEO_DIM, TXT = MMDEER_TEXT_DIM, INTER = MMDEER_INTER_DIM;
 constexpr int FUS = MMDEER_FUSION_DIM, HID = MMDEER_HIDDEN_DIM, EV1 = 128, EV2 = 64;
 constexpr int SPLITK_MAX = 8;
-// fragment-major images of the DEER-head weights (chain.hip): forward layers use W, backward layers W^T
-constexpr long long CH_FP0 = 0, CH_FP1 = CH_FP0 + 256LL * 512, CH_EV0 = CH_FP1 + 256LL * 256, CH_EV1 = CH_EV0 + 384LL * 256,
-                    CH_EV1T = CH_EV1 + 192LL * 128, CH_EV0T = CH_EV1T + 384LL * 64, CH_FP1T = CH_EV0T + 256LL * 384,
-                    CH_FP0T = CH_FP1T + 256LL * 256, CH_TOTAL = CH_FP0T + 512LL * 256;
 constexpr int AUD_PAD = 128;   // the 84 audio features padded to a K-tile multiple for the LDS-DMA kernels
 
 // ------------------------------------------------------------------ workspace layout
 struct Layout {
-  // packed parameters
+  // packed parameters: ONE set per model, in the caller's `weights` buffer (mmdeer_weights_bytes), shared by the workspaces
+  // of every batch size -- written by mmdeer_forward(repack = 1), mmdeer_pack_weights and mmdeer_adamw_step
   char* wpack;   // compute dtype, MMDEER_FLAT_ELEMS
   char* wtpack;  // transposed weight matrices (W^T, compute dtype) at the same flat offsets: dX runs as an NT GEMM
   char* wa_pad;  // bf16 mode: audio_projection.weight as [256][AUD_PAD] (zero-padded rows, 16-byte aligned)
-  char* audio_pad;  // bf16 mode: the audio feature block as [B][AUD_PAD]
   char* wqkv_hm; // bf16 mode: head-major image of the trimodal in_proj weight for the fused projection + attention kernels
-  char* wchain;  // bf16 mode: fragment-major images of the head weights for the row-block chain kernel (CHAIN_* offsets)
   float* vpack;  // fp32 vectors, MMDEER_FLAT_ELEMS
+  float* wscratch;   // ADAM_NPART floats: sum-of-squares partials of the optimiser step
+  size_t wbytes;     // size of the weights buffer
+  // ---- per-batch workspace
+  char* audio_pad;   // bf16 mode: the audio feature block as [B][AUD_PAD]
   // saved activations (activation dtype unless noted)
   char *avin, *avv, *cat, *y_a2, *av, *xtok, *qkv, *obar, *pool, *y_t3, *tri, *y_o1, *fused, *h1, *h2, *e1, *e2;
   float *probs, *evid, *stats;
@@ -95,20 +93,23 @@ struct Layout {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-Layout make_layout(void* base, int B, int f32) {
+Layout make_layout(void* base, void* wbase, int B, int f32) {
   Layout L{};
   const size_t es = f32 ? 4 : 2;
   size_t off = 0;
-  char* b = reinterpret_cast<char*>(base);
+  char* b = reinterpret_cast<char*>(wbase);
   auto take = [&](size_t bytes) { char* p = b ? b + off : nullptr; off += align_up(bytes); return p; };
   const size_t Bz = (size_t)(B > 0 ? B : 1);
   L.wpack = take((size_t)MMDEER_FLAT_ELEMS * es);
   L.wtpack = take((size_t)MMDEER_FLAT_ELEMS * es);
   L.vpack = reinterpret_cast<float*>(take((size_t)MMDEER_FLAT_ELEMS * 4));
   L.wa_pad = take((size_t)INTER * AUD_PAD * 2);
-  L.audio_pad = take(Bz * AUD_PAD * 2);
   L.wqkv_hm = take((size_t)3 * FUS * FUS * 2);
-  L.wchain = take((size_t)CH_TOTAL * 2);
+  L.wscratch = reinterpret_cast<float*>(take((size_t)ADAM_NPART * 4));
+  L.wbytes = off;
+  off = 0;
+  b = reinterpret_cast<char*>(base);
+  L.audio_pad = take(Bz * AUD_PAD * 2);
   auto act = [&](size_t rows, size_t cols) { return take(rows * cols * es); };
   auto f32buf = [&](size_t n) { return reinterpret_cast<float*>(take(n * 4)); };
   L.avin = act(2 * Bz, INTER); L.avv = act(2 * Bz, INTER); L.cat = act(Bz, 2 * INTER); L.y_a2 = act(Bz, INTER);
@@ -159,26 +160,7 @@ int ksteps_target(int f32) {
   return v > 0 ? v : (f32 ? 8 : 16);
 }
 
-unsigned long long* g_chain_stamps = nullptr;   // diagnostic builds: set through mmdeer_debug_chain_stamps()
 
-// MMDEER_CHAIN=1: run the four head layers (forward) / their four dX products (backward) as one row-block chain
-// launch each (csrc/chain.hip) instead of four GEMM launches.  OFF by default: measured at B = 4096 the chain takes
-// 28.7 us against 4 x 6.3 us -- every 32-row workgroup re-streams all 626 KB of weights and each layer still pays a
-// cold first weight fetch, an epilogue store and a barrier, on 128 workgroups instead of 512.  Results are identical
-// (same MFMA order); kept as a measured alternative and covered by tests/test_gpu_model.py.
-int env_chain() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_CHAIN"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
-// MMDEER_SIDE=1: weight-gradient buckets run on a library-owned side stream, concurrently with the rest of the
-// backward chain (fork / join by events, capturable into a HIP graph)
-int env_side() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_SIDE"); v = e ? atoi(e) : 0; }
-  return v;
-}
 // MMDEER_FUSED_ATTN=0: the unfused pair (in_proj GEMM writing q|k|v + one-wave-per-sample attention kernels) also in bf16
 // mode.  Default 1: tri_fused.hip.  MMDEER_QKV_RECOMPUTE=0 (with the fused forward): the forward also stores q|k|v and
 // the backward runs the unfused attention-backward kernel on it instead of recomputing the head tiles.
@@ -192,23 +174,6 @@ int env_qkv_recompute() {
   if (v < 0) { const char* e = getenv("MMDEER_QKV_RECOMPUTE"); v = e ? atoi(e) : 1; }
   return v;
 }
-struct SideCtx {
-  hipStream_t s2 = nullptr;
-  hipEvent_t fork[3] = {nullptr, nullptr, nullptr}, join = nullptr;
-};
-SideCtx* get_side_ctx() {
-  static SideCtx ctx[16];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  SideCtx& c = ctx[dev];
-  if (!c.s2) {
-    if (hipStreamCreateWithFlags(&c.s2, hipStreamNonBlocking) != hipSuccess) { c.s2 = nullptr; return nullptr; }
-    for (int i = 0; i < 3; ++i) (void)hipEventCreateWithFlags(&c.fork[i], hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c.join, hipEventDisableTiming);
-  }
-  return &c;
-}
-
 }  // namespace
 
 namespace {
@@ -358,13 +323,20 @@ struct Exec {
 
 #define TRY(x) do { if ((x) != 0) return -1; } while (0)
 
-int check_common(int batch, const void* ws, size_t ws_bytes, int f32) {
+int check_weights(const void* w, size_t w_bytes, int f32) {
+  MMDEER_CHECK(w != nullptr, "weights buffer is NULL");
+  MMDEER_CHECK(((uintptr_t)w % 256) == 0, "weights buffer must be 256-byte aligned");
+  const size_t need = mmdeer_weights_bytes(f32);
+  MMDEER_CHECK(w_bytes >= need, "weights buffer too small: %zu bytes given, %zu needed", w_bytes, need);
+  return 0;
+}
+int check_common(int batch, const void* ws, size_t ws_bytes, const void* w, size_t w_bytes, int f32) {
   MMDEER_CHECK(batch >= 0, "batch must be >= 0 (got %d)", batch);
   MMDEER_CHECK(ws != nullptr, "workspace is NULL");
   MMDEER_CHECK(((uintptr_t)ws % 256) == 0, "workspace must be 256-byte aligned");
   const size_t need = mmdeer_workspace_bytes(batch, f32);
   MMDEER_CHECK(ws_bytes >= need, "workspace too small: %zu bytes given, %zu needed for batch %d", ws_bytes, need, batch);
-  return 0;
+  return check_weights(w, w_bytes, f32);
 }
 
 // W^T copies (compute dtype) of the matrices whose dX the backward chain needs, at their flat offsets in L.wtpack
@@ -383,31 +355,6 @@ int pack_transposed_weights(const void* const* params, const Layout& L, int f32,
     }
   }
   return launch_pack_transposed(tt, L.wtpack, f32, s);
-}
-
-// bf16 mode: fragment-major images of the head weights for the chain kernel (forward: W, backward: W^T)
-int pack_chain_weights(const void* const* params, const Layout& L, int with_backward, hipStream_t s) {
-  TilePackTable t{};
-  auto seg = [&](int pid, long long dst, int rows, int cols, int ld, int transposed, int j0, int t0, int nks_total) {
-    const int k = t.nseg++;
-    t.src[k] = reinterpret_cast<const float*>(params[pid]); t.dst_off[k] = dst; t.rows[k] = rows; t.cols[k] = cols; t.ld[k] = ld;
-    t.transposed[k] = (unsigned char)transposed; t.j0[k] = j0; t.t0[k] = t0; t.nks_total[k] = nks_total;
-  };
-  seg(P_FP0_W, CH_FP0, HID, FUS, FUS, 0, 0, 0, FUS / 32);
-  seg(P_FP1_W, CH_FP1, HID, HID, HID, 0, 0, 0, HID / 32);
-  for (int h = 0; h < 3; ++h) {
-    seg(P_EV0_W + h, CH_EV0, EV1, HID, HID, 0, h * (EV1 / 16), 0, HID / 32);      // stacked along the output dimension
-    seg(P_EV1_W + h, CH_EV1, EV2, EV1, EV1, 0, h * (EV2 / 16), 0, EV1 / 32);      // block-diagonal: group h
-  }
-  if (with_backward) {
-    for (int h = 0; h < 3; ++h) {
-      seg(P_EV1_W + h, CH_EV1T, EV1, EV2, EV1, 1, h * (EV1 / 16), 0, EV2 / 32);   // (n = input col of head h, k = its 64 outputs)
-      seg(P_EV0_W + h, CH_EV0T, HID, EV1, HID, 1, 0, h * (EV1 / 32), 3 * EV1 / 32);   // k runs over the three stacked heads
-    }
-    seg(P_FP1_W, CH_FP1T, HID, HID, HID, 1, 0, 0, HID / 32);
-    seg(P_FP0_W, CH_FP0T, FUS, HID, FUS, 1, 0, 0, HID / 32);
-  }
-  return launch_tile_pack(t, L.wchain, s);
 }
 
 // bf16 mode: the [256][128] zero-padded copy of audio_projection.weight
@@ -437,7 +384,8 @@ int mmdeer_param_cols(int i) { return (i >= 0 && i < MMDEER_NUM_PARAMS) ? kParam
 long long mmdeer_param_offset(int i) { return (i >= 0 && i < MMDEER_NUM_PARAMS) ? kParams[i].off : -1; }
 long long mmdeer_flat_elems(void) { return MMDEER_FLAT_ELEMS; }
 
-size_t mmdeer_workspace_bytes(int batch, int compute_f32) { return make_layout(nullptr, batch, compute_f32).bytes; }
+size_t mmdeer_workspace_bytes(int batch, int compute_f32) { return make_layout(nullptr, nullptr, batch, compute_f32).bytes; }
+size_t mmdeer_weights_bytes(int compute_f32) { return make_layout(nullptr, nullptr, 0, compute_f32).wbytes; }
 
 long long mmdeer_bucket_begin(int b) {
   switch (b) { case 0: return kParams[P_FP0_W].off; case 1: return kParams[P_AVP_W].off; case 2: return 0; default: return -1; }
@@ -449,12 +397,12 @@ long long mmdeer_bucket_end(int b) {
 int mmdeer_forward(const mmdeer_forward_args* a) {
   MMDEER_CHECK(a != nullptr, "args is NULL");
   const int B = a->batch, f32 = a->compute_f32 ? 1 : 0;
-  TRY(check_common(B, a->workspace, a->workspace_bytes, f32));
+  TRY(check_common(B, a->workspace, a->workspace_bytes, a->weights, a->weights_bytes, f32));
   MMDEER_CHECK(!(f32 && a->inputs_bf16), "bf16 inputs need compute_f32 = 0");
   MMDEER_CHECK(a->dropout_p >= 0.f && a->dropout_p < 1.f, "dropout_p must be in [0,1) (got %f)", a->dropout_p);
   MMDEER_CHECK(!(a->bump_offset_dev && (f32 || B == 0)), "bump_offset_dev needs bf16 compute and a non-empty batch");
   hipStream_t s = (hipStream_t)a->stream;
-  const Layout L = make_layout(a->workspace, B, f32);
+  const Layout L = make_layout(a->workspace, a->weights, B, f32);
   if (a->repack) {
     MMDEER_CHECK(a->params != nullptr, "params is NULL");
     PackTable t{};
@@ -472,7 +420,6 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     // the parameters are unchanged, so an inference call followed by a training call on the same parameters would find
     // them missing (the backward pass then multiplied by whatever the buffer held)
     TRY(pack_transposed_weights(a->params, L, f32, s));
-    if (!f32 && env_chain()) TRY(pack_chain_weights(a->params, L, 1, s));
   }
   const bool wa_pending = a->repack && !f32;   // the padded bf16 copy of audio_projection.weight follows the parameters
   if (B == 0) {
@@ -559,25 +506,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   // F12-F13: output_projection (fusion.py:162)
   TRY(X.run1(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ)));
   TRY(launch_ln_fwd(L.y_o1, L.fused, a->fused_features, L.mean_o1, L.rstd_o1, X.V(P_OP_G), X.V(P_OP_BT), B, FUS, f32, s));
-  if (!f32 && env_chain()) {
-    // F14-F17 (bf16): feature_processor (deer.py:246) and the first two layers of the three DEERLayers (deer.py:49-54)
-    // as ONE row-block chain launch (csrc/chain.hip); every layer output is still saved for the backward pass
-    ChainArgs c{};
-    c.nlayers = 4; c.B = B; c.in = reinterpret_cast<const bf16_t*>(L.fused); c.ld_in = FUS; c.K0 = FUS; c.drop = X.dc;
-    auto lin_ = [&](int i, long long pidW, int pidB, int N, int K, void* out, int site) {
-      ChainLayer& l = c.L[i];
-      l.W = reinterpret_cast<const bf16_t*>(L.wchain) + pidW; l.bias = X.V(pidB); l.N = N; l.K = K; l.groups = 1;
-      l.out = reinterpret_cast<bf16_t*>(out); l.ld_out = N; l.relu = 1; l.drop_site = X.drop_on ? site : -1; l.mask_scale = 1.f;
-    };
-    auto lin = [&](int i, long long img, int pidB, int N, int K, void* out, int site) { lin_(i, img, pidB, N, K, out, site); };
-    lin(0, CH_FP0, P_FP0_B, HID, FUS, L.h1, SITE_FP0);
-    lin(1, CH_FP1, P_FP1_B, HID, HID, L.h2, SITE_FP1);
-    lin(2, CH_EV0, P_EV0_B, 3 * EV1, HID, L.e1, SITE_EV0);            // three heads stacked: N = 384
-    lin(3, CH_EV1, P_EV1_B, 3 * EV2, EV1, L.e2, SITE_EV1);            // three heads block-diagonal: 3 x (128 -> 64)
-    c.L[3].groups = 3;
-    c.stamps = g_chain_stamps;
-    TRY(launch_chain(c, s));
-  } else {
+  {
     // F14-F15: feature_processor (deer.py:246)
     TRY(X.run1(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0)));
     TRY(X.run1(X.fwd(L.h1, f32, HID, P_FP1_W, P_FP1_B, L.h2, HID, B, 1, SITE_FP1)));
@@ -602,12 +531,12 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
 int mmdeer_backward(const mmdeer_backward_args* a) {
   MMDEER_CHECK(a != nullptr, "args is NULL");
   const int B = a->batch, f32 = a->compute_f32 ? 1 : 0;
-  TRY(check_common(B, a->workspace, a->workspace_bytes, f32));
+  TRY(check_common(B, a->workspace, a->workspace_bytes, a->weights, a->weights_bytes, f32));
   MMDEER_CHECK(B > 0, "backward needs a non-empty batch");
   MMDEER_CHECK(a->grads != nullptr, "grads is NULL");
   MMDEER_CHECK(a->audio && a->video && a->text, "audio / video / text must be non-NULL");
   hipStream_t s = (hipStream_t)a->stream;
-  const Layout L = make_layout(a->workspace, B, f32);
+  const Layout L = make_layout(a->workspace, a->weights, B, f32);
   Exec X;
   X.B = B; X.f32 = f32; X.es = f32 ? 4 : 2; X.L = &L; X.s = s;
   X.drop_on = a->training && a->dropout_p > 0.f;
@@ -648,37 +577,24 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   GemmGroup dwg{};
   ReduceTable rt{};
   auto add_dw = [&](const GemmProblem& q) { dwg.p[dwg.nprob++] = q; };
-  // flush(bucket, last): launch what has been collected.  Default (one stream): nothing until the end, then one
-  // launch of everything.  MMDEER_SIDE=1: every bucket is launched as soon as its inputs exist, on the side stream.
-  SideCtx* sc = (env_side() && !f32) ? get_side_ctx() : nullptr;
+  // flush(bucket, last): one launch of every weight-gradient problem collected so far + the fold of all partial slabs,
+  // at the end of the pass (or of phase 1).  Per-bucket launches, also on a side stream beside the dX chain, were measured
+  // slower: a bucket alone is 30-180 workgroups of 16-32 sequential K-steps on a mostly idle chip.
   const int phase = a->phase;
   MMDEER_CHECK(phase >= 0 && phase <= 2, "backward: phase must be 0, 1 or 2 (got %d)", phase);
   int ev_done = phase == 2 ? 2 : 0;   // first bucket whose event has not been recorded yet
   auto flush = [&](int bucket, bool last) -> int {
-    if (!sc && !last) return 0;
-    hipStream_t ls = s;
-    if (sc) {
-      MMDEER_HIP(hipEventRecord(sc->fork[bucket], s));
-      MMDEER_HIP(hipStreamWaitEvent(sc->s2, sc->fork[bucket], 0));
-      ls = sc->s2;
-    }
-    Exec X2 = X;
-    X2.s = ls;
+    if (!last) return 0;
     if (dwg.nprob > 0) {
-      if (X2.run(dwg) != 0) return -1;
+      if (X.run(dwg) != 0) return -1;
       for (int i = 0; i < dwg.nprob; ++i) Exec::add_slab_segments(rt, dwg.p[i], L.slab, G);
     }
-    if (launch_reduce_partials(rt, ls) != 0) return -1;
-    // every bucket up to this one is final now
-    for (int b = ev_done; b <= bucket; ++b)
-      if (a->bucket_events[b]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[b], ls));
+    if (launch_reduce_partials(rt, s) != 0) return -1;
+    for (int b = ev_done; b <= bucket; ++b)      // every bucket up to this one is final now
+      if (a->bucket_events[b]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[b], s));
     ev_done = bucket + 1;
     dwg = GemmGroup{};
     rt = ReduceTable{};
-    if (last && sc) {
-      MMDEER_HIP(hipEventRecord(sc->join, sc->s2));
-      MMDEER_HIP(hipStreamWaitEvent(s, sc->join, 0));
-    }
     return 0;
   };
 
@@ -687,24 +603,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // B1: last head layer + NIG activations (+ loss gradient)
   TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->targets ? a->global_stats : nullptr, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
                      L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
-  if (!f32 && env_chain()) {
-    // the four dX GEMMs of the head (evidence_net layers 3 and 0, feature_processor) as one row-block chain launch
-    ChainArgs c{};
-    c.nlayers = 4; c.B = B; c.in = reinterpret_cast<const bf16_t*>(L.dz2); c.ld_in = 3 * EV2; c.K0 = 3 * EV2; c.drop = X.dc;
-    auto dxl = [&](int i, long long img, int N, int K, const void* mask, void* out) {
-      ChainLayer& l = c.L[i];
-      l.W = reinterpret_cast<const bf16_t*>(L.wchain) + img; l.N = N; l.K = K; l.groups = 1;
-      l.mask = reinterpret_cast<const bf16_t*>(mask); l.ld_mask = N; l.mask_scale = X.mask_scale;
-      l.out = reinterpret_cast<bf16_t*>(out); l.ld_out = N; l.drop_site = -1;
-    };
-    dxl(0, CH_EV1T, 3 * EV1, EV2, L.e1, L.de1);                       // per head: W^T [128][64]
-    c.L[0].groups = 3;
-    dxl(1, CH_EV0T, HID, 3 * EV1, L.h2, L.dh2);                       // W^T of the stacked heads: [256][384]
-    dxl(2, CH_FP1T, HID, HID, L.h1, L.dh1);
-    dxl(3, CH_FP0T, FUS, HID, nullptr, L.dfused);
-    c.stamps = g_chain_stamps ? g_chain_stamps + 16 : nullptr;
-    TRY(launch_chain(c, s));
-  } else {
+  {
     // evidence_net layer 3 (128 -> 64), batched over heads: dX masked by e1
     {
       GemmProblem p = X.dx(L.dz2, 3 * EV2, P_EV1_W, L.de1, 3 * EV1, B, L.e1, 3 * EV1);
@@ -804,9 +703,8 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
 }
 
 #ifdef MMDEER_STAMPS
-// diagnostic library only (not part of the ABI): 32 uint64 slots, forward chain stamps at [0,16), backward at [16,32)
+// diagnostic library only (not part of the ABI)
 int mmdeer_debug_nig_stamps(unsigned long long* out16) { return mmdeer::debug_nig_stamps(out16); }
-void mmdeer_debug_chain_stamps(void* p) { g_chain_stamps = reinterpret_cast<unsigned long long*>(p); }
 void mmdeer_debug_tf_stamps(void* p) { mmdeer::tf_set_stamps(reinterpret_cast<unsigned long long*>(p)); }
 #endif
 
@@ -814,12 +712,12 @@ void mmdeer_debug_tf_stamps(void* p) { mmdeer::tf_set_stamps(reinterpret_cast<un
 int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
   MMDEER_CHECK(a != nullptr, "args is NULL");
   const int f32 = a->compute_f32 ? 1 : 0;
-  TRY(check_common(a->batch, a->workspace, a->workspace_bytes, f32));
+  TRY(check_weights(a->weights, a->weights_bytes, f32));
   MMDEER_CHECK(a->params && a->grads && a->exp_avg && a->exp_avg_sq && a->lr, "adamw: params / grads / exp_avg / exp_avg_sq / lr must be non-NULL");
   MMDEER_CHECK(a->step >= 1, "adamw: step must be >= 1 (got %d)", a->step);
   MMDEER_CHECK(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps > 0.f, "adamw: bad betas / eps");
   hipStream_t s = (hipStream_t)a->stream;
-  const Layout L = make_layout(a->workspace, a->batch, f32);
+  const Layout L = make_layout(nullptr, a->weights, 0, f32);
   AdamTable t{};
   t.nseg = MMDEER_NUM_PARAMS;
   for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
@@ -831,7 +729,7 @@ int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
     t.lr[i] = a->lr[i];
   }
   t.grads = a->grads; t.exp_avg = a->exp_avg; t.exp_avg_sq = a->exp_avg_sq;
-  t.partials = L.slab;              // the split-K slab is idle between backward passes
+  t.partials = L.wscratch;
   t.norm_out = a->grad_norm;
   t.flat_elems = MMDEER_FLAT_ELEMS;
   t.beta1 = a->beta1; t.beta2 = a->beta2; t.eps = a->eps; t.weight_decay = a->weight_decay;
@@ -842,17 +740,15 @@ int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
   const void* const* cparams = const_cast<const void* const*>(a->params);
   if (a->pack_transposed) TRY(pack_transposed_weights(cparams, L, f32, s));
   if (!f32) TRY(pad_audio_weight(cparams, L, s));
-  if (!f32 && env_chain()) TRY(pack_chain_weights(cparams, L, a->pack_transposed, s));
   return 0;
 }
 
-int mmdeer_pack_weights(const void* const* params, void* workspace, size_t workspace_bytes, int batch, int compute_f32,
-                        void* stream) {
+int mmdeer_pack_weights(const void* const* params, void* weights, size_t weights_bytes, int compute_f32, void* stream) {
   const int f32 = compute_f32 ? 1 : 0;
   MMDEER_CHECK(params != nullptr, "pack_weights: params is NULL");
-  TRY(check_common(batch, workspace, workspace_bytes, f32));
+  TRY(check_weights(weights, weights_bytes, f32));
   hipStream_t s = (hipStream_t)stream;
-  const Layout L = make_layout(workspace, batch, f32);
+  const Layout L = make_layout(nullptr, weights, 0, f32);
   PackTable t{};
   t.nseg = MMDEER_NUM_PARAMS;
   for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
@@ -865,7 +761,6 @@ int mmdeer_pack_weights(const void* const* params, void* workspace, size_t works
   TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
   TRY(pack_transposed_weights(params, L, f32, s));
   if (!f32) TRY(pad_audio_weight(params, L, s));
-  if (!f32 && env_chain()) TRY(pack_chain_weights(params, L, 1, s));
   return 0;
 }
 
@@ -965,7 +860,7 @@ int mmdeer_loss_stats(const void* workspace, size_t workspace_bytes, int batch, 
   static_assert(MMDEER_GLOBAL_STATS == NIG_GLOBAL_STATS, "public header out of sync with nig.h");
   MMDEER_CHECK(workspace && out, "loss_stats: NULL argument");
   MMDEER_CHECK(batch > 0, "loss_stats: batch must be > 0 (got %d)", batch);
-  const Layout L = make_layout(const_cast<void*>(workspace), batch, compute_f32 ? 1 : 0);
+  const Layout L = make_layout(const_cast<void*>(workspace), nullptr, batch, compute_f32 ? 1 : 0);
   MMDEER_CHECK(workspace_bytes >= L.bytes, "loss_stats: workspace of %zu bytes is smaller than the %zu of this batch", workspace_bytes, L.bytes);
   return launch_nig_stats_sum(L.stats, batch, out, (hipStream_t)stream);
 }

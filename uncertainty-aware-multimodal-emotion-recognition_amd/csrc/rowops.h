@@ -71,23 +71,6 @@ struct PadTable {
 };
 int launch_pad_cols(PadTable& t, hipStream_t s);
 
-// Fragment-major weight image for the row-block chain kernel (chain.hip): block (fragment j, K-step t) is 1 KiB =
-// 64 lanes x 8 bf16, lane (lg, li) = lg*16 + li holding W[n = 16 j + li][k = 32 t + 8 lg .. + 8], blocks ordered
-// [j][t].  A wave's fragment load is then ONE contiguous KiB (8 full cache lines) instead of 16 half lines.
-// A segment is a dense source block: element (n, k) at src[n*ld + k], or src[k*ld + n] when `transposed`; it fills
-// fragments [j0, j0 + rows/16) x K-steps [t0, t0 + cols/32) of a layer image with nks_total K-steps per fragment.
-constexpr int TILEPACK_MAX = 24;
-struct TilePackTable {
-  int nseg;
-  const float* src[TILEPACK_MAX];
-  long long dst_off[TILEPACK_MAX];   // element offset of the layer image in the tiled buffer
-  int rows[TILEPACK_MAX], cols[TILEPACK_MAX], ld[TILEPACK_MAX];
-  int j0[TILEPACK_MAX], t0[TILEPACK_MAX], nks_total[TILEPACK_MAX];
-  unsigned char transposed[TILEPACK_MAX];
-  int bstart[TILEPACK_MAX + 1];      // filled by the launcher (256 chunks of 8 elements per block)
-};
-int launch_tile_pack(TilePackTable& t, void* dst_bf16, hipStream_t s);
-
 // keep-mask dump for the test harness: out[r*cols + c] = keep(site, r, c) ? 1 : 0   (c already in site granularity)
 int launch_dropout_mask(const DropCtx& d, int site, int rows, int cols, unsigned char* out, hipStream_t s);
 

@@ -300,32 +300,6 @@ __global__ __launch_bounds__(256) void pad_cols_kernel(const PadTable t) {
   *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(T.dst[sg]) + (long long)r * ld + c0) = o;
 }
 
-__global__ __launch_bounds__(256) void tile_pack_kernel(const TilePackTable t, bf16_t* dst) {
-  const auto& T = karg<TilePackTable>();
-  int sg = 0;
-  for (int i = 1; i < TILEPACK_MAX; ++i)
-    if (i < T.nseg && (int)blockIdx.x >= T.bstart[i]) sg = i;
-  const int rows = T.rows[sg], cols = T.cols[sg], ld = T.ld[sg];
-  const int nks = cols >> 5;
-  const long long c = (long long)(blockIdx.x - T.bstart[sg]) * 256 + threadIdx.x;   // destination chunk inside the segment
-  if (c >= (long long)rows * cols / 8) return;
-  const int blk = (int)(c >> 6), lane = (int)(c & 63);
-  const int jl = blk / nks, tl = blk - jl * nks;
-  const int n = 16 * jl + (lane & 15), k = 32 * tl + 8 * (lane >> 4);
-  const float* src = (const float*)T.src[sg];
-  float v[8];
-  if (T.transposed[sg]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = src[(long long)(k + e) * ld + n];
-  } else {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(src + (long long)n * ld + k);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(src + (long long)n * ld + k + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  }
-  const long long o = T.dst_off[sg] + (((long long)(T.j0[sg] + jl) * T.nks_total[sg] + T.t0[sg] + tl) * 64 + lane) * 8;
-  *reinterpret_cast<u32x4*>(dst + o) = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-}
-
 __global__ __launch_bounds__(256) void dropout_mask_kernel(DropCtx d, int site, int rows, int cols, unsigned char* out) {
   const long long total = (long long)rows * cols;
   for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
@@ -428,22 +402,6 @@ int launch_reduce_partials(ReduceTable& t, hipStream_t s) {
   for (int i = t.nseg; i <= REDUCE_MAX_SEGMENTS; ++i) t.bstart[i] = blocks;
   if (blocks == 0) return 0;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, s, t);
-  MMDEER_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_tile_pack(TilePackTable& t, void* dst_bf16, hipStream_t s) {
-  MMDEER_CHECK(t.nseg >= 0 && t.nseg <= TILEPACK_MAX, "tile pack: bad segment count %d", t.nseg);
-  int blocks = 0;
-  for (int i = 0; i < t.nseg; ++i) {
-    MMDEER_CHECK(t.rows[i] % 16 == 0 && t.cols[i] % 32 == 0 && t.ld[i] % 4 == 0 && ((uintptr_t)t.src[i] % 16) == 0 && t.dst_off[i] % 8 == 0,
-                 "tile pack[%d]: bad block %d x %d", i, t.rows[i], t.cols[i]);
-    t.bstart[i] = blocks;
-    blocks += (int)(((long long)t.rows[i] * t.cols[i] / 8 + 255) / 256);
-  }
-  for (int i = t.nseg; i <= TILEPACK_MAX; ++i) t.bstart[i] = blocks;
-  if (blocks == 0) return 0;
-  hipLaunchKernelGGL(tile_pack_kernel, dim3(blocks), dim3(256), 0, s, t, reinterpret_cast<bf16_t*>(dst_bf16));
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

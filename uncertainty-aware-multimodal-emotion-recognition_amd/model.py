@@ -79,11 +79,11 @@ class _State:
     """Per-model launch state shared by the autograd functions."""
 
     def __init__(self):
-        self.workspaces: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self.workspaces: Dict[Tuple[int, int, int], torch.Tensor] = {}     # activations / scratch, one per batch size
+        self.weights: Dict[Tuple[int, int], torch.Tensor] = {}             # packed parameter copies: ONE per model (and device)
         self.generation = 0
-        self.packed_key = None
+        self.packed_key = None    # (weights buffer, parameter generation and versions) the packed copies were made from
         self.param_gen = 0        # bumped by in-place parameter updates torch cannot see (optim.FusedAdamW)
-        self.last_train = None    # (workspace, batch) of the most recent train_step
 
 
 class _ForwardFn(torch.autograd.Function):
@@ -250,11 +250,21 @@ class MultimodalDEER(nn.Module):
             nbytes = _lib.load().mmdeer_workspace_bytes(B, self.compute_f32)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._st.workspaces[key] = ws
-            self._st.packed_key = None
         return ws
 
-    def _param_key(self, ws: torch.Tensor):
-        return (ws.data_ptr(), self._st.param_gen) + tuple((p.data_ptr(), p._version) for p in self._live)
+    def _weights(self, dev: torch.device) -> torch.Tensor:
+        """The packed parameter copies the kernels read: one buffer per model, shared by every batch size's workspace
+        (a graph captured for one batch size and an eager step on another read the same, always current, copies)."""
+        key = (self.compute_f32, dev.index if dev.index is not None else 0)
+        wb = self._st.weights.get(key)
+        if wb is None:
+            wb = torch.empty(_lib.load().mmdeer_weights_bytes(self.compute_f32), dtype=torch.uint8, device=dev)
+            self._st.weights[key] = wb
+            self._st.packed_key = None
+        return wb
+
+    def _param_key(self, wb: torch.Tensor):
+        return (wb.data_ptr(), self._st.param_gen) + tuple((p.data_ptr(), p._version) for p in self._live)
 
     def _launch_forward(self, audio, video, text, targets, prof_events=None, offset_dev=None, want_features=True, bump=False):
         lib = _lib.load()
@@ -276,7 +286,8 @@ class MultimodalDEER(nn.Module):
                     raise RuntimeError("mmdeer: parameters must be contiguous fp32 tensors on the inputs' device")
             self._ptr_cache = (ptrs, (C.c_void_p * len(ptrs))(*ptrs), dev)
         ws = self._workspace(B, dev)
-        key = self._param_key(ws)
+        wb = self._weights(dev)
+        key = self._param_key(wb)
         repack = key != self._st.packed_key
         training = self.training
         if training and offset_dev is None:
@@ -291,6 +302,7 @@ class MultimodalDEER(nn.Module):
         a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
         a.params = self._ptr_cache[1]
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.weights, a.weights_bytes = wb.data_ptr(), wb.numel()
         f32 = dict(dtype=torch.float32, device=dev)
         nig = torch.empty(7, B, 3, **f32)
         a.nig_out = nig.data_ptr()
@@ -312,7 +324,7 @@ class MultimodalDEER(nn.Module):
         _lib.check(lib.mmdeer_forward(C.byref(a)))
         self._st.packed_key = key
         self._st.generation += 1
-        meta = dict(B=B, training=int(training), in_bf16=int(in_bf16), offset=step, offset_dev=offset_dev, ws=ws,
+        meta = dict(B=B, training=int(training), in_bf16=int(in_bf16), offset=step, offset_dev=offset_dev, ws=ws, wb=wb,
                     inputs=(audio, video, text), targets=targets)
         return {"_nig": nig, "_meta": meta, "fused_features": fused, "audiovisual_features": avf,
                 "trimodal_features": trif, "av_attention": avw, "trimodal_attention": triw}
@@ -341,6 +353,7 @@ class MultimodalDEER(nn.Module):
         audio, video, text = meta["inputs"]
         a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
         a.workspace, a.workspace_bytes = meta["ws"].data_ptr(), meta["ws"].numel()
+        a.weights, a.weights_bytes = meta["wb"].data_ptr(), meta["wb"].numel()
         keep = []
         if targets is not None:
             a.targets = targets.data_ptr()
@@ -436,7 +449,6 @@ class MultimodalDEER(nn.Module):
                                  want_features=return_features, bump=_bump)
         meta = o["_meta"]
         dev = meta["ws"].device
-        self._st.last_train = (meta["ws"], meta["B"])
         loss_out = torch.empty(20, dtype=torch.float32, device=dev)
         bins = torch.empty(30, dtype=torch.int32, device=dev)
         # the fused path owns ONE persistent flat gradient buffer per device (zeroed once: the alignment gaps stay 0);
@@ -515,7 +527,6 @@ class MultimodalDEER(nn.Module):
                 after()
         self._graph = graph
 
-        cap_ws, cap_B = self._st.last_train          # the workspace (and its packed weight copies) frozen into the graph
         counter = self._graph_counter
         shadow = [int(self._step)]                    # the value the device-side dropout counter holds
 
@@ -524,19 +535,17 @@ class MultimodalDEER(nn.Module):
             # counter in line, so a replay never reuses the offset of the step before it
             if self._step != shadow[0]:
                 counter.fill_(int(self._step))
-            # repack = 0 is frozen into the graph.  If the parameters were last updated through ANOTHER workspace -- an
-            # eager step on a ragged tail batch, whose optimiser call refreshed only that batch size's copies -- the
-            # copies the graph reads are stale: refresh them first.
-            pk = self._st.packed_key
-            if pk is None or pk[0] != cap_ws.data_ptr() or pk[1] != self._st.param_gen:
-                lib = _lib.load()
-                _lib.check(lib.mmdeer_pack_weights(self._ptr_cache[1], cap_ws.data_ptr(), cap_ws.numel(), cap_B, self.compute_f32,
-                                                   _lib.current_stream()))
-                self._st.packed_key = self._param_key(cap_ws)
+            # repack = 0 is frozen into the graph.  The packed copies are per model, so FusedAdamW steps taken after eager
+            # steps on other batch sizes keep them current; only parameters changed behind the library's back
+            # (load_state_dict, a torch optimiser, mark_parameters_changed) need a refresh before the replay.
+            wb = self._weights(dev)
+            if self._st.packed_key != self._param_key(wb):
+                _lib.check(_lib.load().mmdeer_pack_weights(self._ptr_cache[1], wb.data_ptr(), wb.numel(), self.compute_f32,
+                                                           _lib.current_stream()))
+                self._st.packed_key = self._param_key(wb)
             graph.replay()
             self._step += 1          # keep the host-side step counter in line with the device-side one
             shadow[0] = int(self._step)
-            self._st.last_train = (cap_ws, cap_B)        # the optimiser step that follows packs into THIS workspace
             return out
         replay.first = first
         return replay

@@ -61,17 +61,16 @@ class FusedAdamW(torch.optim.Optimizer):
             raise NotImplementedError("FusedAdamW: closures are not supported")
         m = self.model
         flat = m._step_flat
-        last = m._st.last_train
-        if flat is None or last is None:
+        if flat is None:
             raise RuntimeError("FusedAdamW.step() needs the gradients of MultimodalDEER.train_step()")
-        ws, B = last
         dev = flat.device
+        wbuf = m._weights(dev)
         exp_avg, exp_avg_sq = self._moments(dev)
         self._t += 1
         g0 = self.param_groups[0]
         lib = _lib.load()
         a = _lib.AdamWArgs()
-        a.batch, a.compute_f32, a.pack_transposed, a.step = B, m.compute_f32, 1, self._t
+        a.compute_f32, a.pack_transposed, a.step = m.compute_f32, 1, self._t
         a.beta1, a.beta2 = float(g0["betas"][0]), float(g0["betas"][1])
         a.eps, a.weight_decay = float(g0["eps"]), float(g0["weight_decay"])
         a.max_grad_norm, a.grad_scale = self.max_grad_norm, float(grad_scale)
@@ -81,12 +80,12 @@ class FusedAdamW(torch.optim.Optimizer):
         a.grads, a.exp_avg, a.exp_avg_sq = flat.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr()
         norm = torch.empty((), dtype=torch.float32, device=dev)
         a.grad_norm = norm.data_ptr()
-        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.weights, a.weights_bytes = wbuf.data_ptr(), wbuf.numel()
         a.stream = _lib.current_stream()
         _lib.check(lib.mmdeer_adamw_step(C.byref(a)))
-        # the parameters changed behind torch's version counters, and the packed copies in `ws` are already current
+        # the parameters changed behind torch's version counters, and the model's packed copies are already current
         m._st.param_gen += 1
-        m._st.packed_key = m._param_key(ws)
+        m._st.packed_key = m._param_key(wbuf)
         self.last_grad_norm = norm
         return norm
 
