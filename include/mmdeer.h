@@ -250,6 +250,11 @@ int mmdeer_uncertainty_reg_loss(const float* alpha, const float* beta, int B, in
  * loss_out[1]; bin_counts[15] (optional) are the exact bin populations. */
 int mmdeer_calibration_loss(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
                             float* loss_out, int32_t* bin_counts, float* dgamma, float* dalpha, float* dbeta, void* stream);
+/* The same with any number of uniform bins (1 <= n_bins <= 32): `edges` is a HOST array of n_bins + 1 fp32 bin boundaries,
+ * torch.linspace(0, 1, n_bins + 1) as fp32 evaluates it (the reference's rule, losses.py:459); bin_counts[n_bins]. */
+int mmdeer_calibration_loss_bins(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
+                                 const float* edges, int n_bins, float* loss_out, int32_t* bin_counts, float* dgamma, float* dalpha,
+                                 float* dbeta, void* stream);
 
 /* keep-mask of one dropout site, for test harnesses: out[r*cols + c] in {0,1} */
 int mmdeer_dropout_mask(int site, int rows, int cols, float dropout_p, uint64_t seed, uint64_t offset,
@@ -312,6 +317,19 @@ int mmdeer_lstm_cell_t1(const void* gates, int ld_gates, void* out, int ld_out, 
  * the quantile-binned calibration error (metrics.py:214-279). */
 int mmdeer_eval_accumulate(const float* pred, const float* target, const float* unc, double* acc, float* sample_err,
                            float* sample_unc, int B, void* stream);
+
+/* Quantile-binned calibration error of the reference (src/utils/metrics.py:214-279) without copying per-sample arrays to
+ * the host.  err / unc: the per-sample device arrays mmdeer_eval_accumulate wrote (concatenated over the batches), n samples;
+ * a sample counts when neither value is NaN and unc is finite.
+ *   mmdeer_eval_quantile_select: for the nq = n_bins + 1 quantiles q_r = r / (nq - 1) of the valid uncertainties, the two
+ *     order statistics np.quantile interpolates between -- vals[r][0..1] = sorted[floor(q_r (nv - 1))], the one after it --
+ *     their weight frac[r] and *nvalid = nv.  (The host forms the edges: 2 nq floats, as numpy's 'linear' method does.)
+ *   mmdeer_eval_ece_bins: bins[i] = {count, sum (1 - unc), sum (1 - err)} over edges[i] <= unc < edges[i + 1]; edges is a
+ *     DEVICE array of n_bins + 1 doubles, n_bins <= 16.  ECE = sum_i count_i / nv * |sum1_i - sum2_i| / count_i. */
+int mmdeer_eval_quantile_select(const float* err, const float* unc, long long n, int nq, float* vals, double* frac,
+                                long long* nvalid, void* stream);
+int mmdeer_eval_ece_bins(const float* err, const float* unc, long long n, const double* edges, int n_bins, double* bins,
+                         void* stream);
 
 /* ---- Stack B: complete_project.CompleteDEERModel, eval forward -----------------------------------------
  * Every Linear(+ReLU) of the model runs on mmdeer_gemm; with a single key the reference's MultiHeadAttention

@@ -16,6 +16,9 @@ What is captured (SURVEY 8c golden-vector plan):
     NIG parameters incl. extreme pre-activations and empty / single-element ECE bins.
   * side_kernels.npz      -- deer.CrossModalAttention, HierarchicalDEERFusion's three
     encoders, EnhancedAudioEncoder feature branch (eval).
+  * metrics_cases.npz     -- utils/metrics.py: DEERMetrics CCC / MAE / RMSE per dimension and the quantile-binned
+    uncertainty_calibration_error on closed-form (predictions, targets, uncertainties), incl. NaN / inf rows, ties and a
+    too-small set (`python tests/golden/make_golden.py metrics` regenerates only this one).
   * stackb_B9.npz         -- complete_project.CompleteDEERModel, eval-mode forward with
     closed-form parameters (`python tests/golden/make_golden.py stackb` regenerates only this one).
 """
@@ -156,6 +159,8 @@ def capture_losses():
             for k, val in ur.items():
                 out[f"unc_reg.{tag}.{k}"] = np.asarray(float(val), dtype=np.float64)
         out[f"calibration.{tag}"] = np.asarray(float(ref_losses.CalibrationLoss()(flat, yt[sl])), dtype=np.float64)
+        for nb in (10, 7):      # other bin counts: torch.linspace(0, 1, nb + 1) boundaries (losses.py:459)
+            out[f"calibration{nb}.{tag}"] = np.asarray(float(ref_losses.CalibrationLoss(n_bins=nb)(flat, yt[sl])), dtype=np.float64)
         # variant-1 loss (deer.py) per dimension 0, defaults and the self-test's kw=0.1
         for kw in (1.0, 0.1):
             l0 = ref_deer.DEERLoss(kl_weight=kw)({"mu": mu[sl, 0:1], "nu": nu[sl, 0:1], "alpha": alpha[sl, 0:1],
@@ -238,7 +243,51 @@ def capture_stackb():
     return out
 
 
+def metric_cases():
+    """(predictions, targets, uncertainties) triples for the evaluation metrics: closed-form generators, so the test side
+    rebuilds the same inputs from the stored arrays only."""
+    cases = {}
+    n = 777
+    t = np.tanh(synth.normal(1301, n * 3).reshape(n, 3)).astype(np.float32)
+    p = (t + 0.35 * synth.normal(1302, n * 3).reshape(n, 3) + np.array([0.05, -0.1, 0.0])).astype(np.float32)
+    u = (0.05 + 0.6 * np.abs(synth.normal(1303, n * 3).reshape(n, 3))).astype(np.float32)
+    cases["main"] = (p, t, u)
+    p2, t2, u2 = p.copy(), t.copy(), u.copy()
+    p2[5, 1] = np.nan; t2[17, 0] = np.nan; p2[40:44, 2] = np.nan; u2[77, 1] = np.inf; u2[300, 0] = np.nan
+    cases["nan"] = (p2, t2, u2)
+    cases["small"] = (p[:9].copy(), t[:9].copy(), u[:9].copy())            # fewer valid samples than bins: ECE = 1.0
+    p3 = p[:200].copy(); p3[:, 2] = 0.25                                   # a constant column: CCC = 0.0
+    u3 = u[:200].copy(); u3[:, :] = np.round(u3 * 8) / 8                   # heavily tied uncertainties: quantile edges on ties
+    cases["ties"] = (p3, t[:200].copy(), u3)
+    return cases
+
+
+def capture_metrics():
+    """DEERMetrics.concordance_correlation_coefficient / mean_absolute_error / root_mean_squared_error (reference
+    src/utils/metrics.py:59-125) per emotion dimension and uncertainty_calibration_error (:214-279)."""
+    import metrics as ref_metrics  # (reference)
+    m = ref_metrics.DEERMetrics()
+    out = {}
+    for tag, (p, t, u) in metric_cases().items():
+        out[f"{tag}.predictions"], out[f"{tag}.targets"], out[f"{tag}.uncertainties"] = p, t, u
+        for i, d in enumerate(DIM_NAMES):
+            out[f"{tag}.ccc_{d}"] = np.float64(m.concordance_correlation_coefficient(t[:, i], p[:, i]))
+            out[f"{tag}.mae_{d}"] = np.float64(m.mean_absolute_error(t[:, i], p[:, i]))
+            out[f"{tag}.rmse_{d}"] = np.float64(m.root_mean_squared_error(t[:, i], p[:, i]))
+        out[f"{tag}.ece"] = np.float64(ref_metrics.uncertainty_calibration_error(p, t, u))
+        out[f"{tag}.ece_15"] = np.float64(ref_metrics.uncertainty_calibration_error(p, t, u, n_bins=15))
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "losses":
+        np.savez_compressed(os.path.join(HERE, "loss_cases.npz"), **capture_losses())
+        print("loss_cases.npz", os.path.getsize(os.path.join(HERE, "loss_cases.npz")), "bytes")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        np.savez_compressed(os.path.join(HERE, "metrics_cases.npz"), **capture_metrics())
+        print("metrics_cases.npz", os.path.getsize(os.path.join(HERE, "metrics_cases.npz")), "bytes")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "stackb":
         np.savez_compressed(os.path.join(HERE, "stackb_B9.npz"), **capture_stackb())
         print("stackb_B9.npz", os.path.getsize(os.path.join(HERE, "stackb_B9.npz")), "bytes")
@@ -254,6 +303,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "stackc_missing.npz"), **miss)
     np.savez_compressed(os.path.join(HERE, "loss_cases.npz"), **capture_losses())
     np.savez_compressed(os.path.join(HERE, "side_kernels.npz"), **capture_side())
+    np.savez_compressed(os.path.join(HERE, "metrics_cases.npz"), **capture_metrics())
     import json
     f, h = build_reference(0.3)
     names = {"fusion": list(f.state_dict().keys()), "head": list(h.state_dict().keys()),

@@ -196,3 +196,47 @@ def test_loss_classes_keep_the_reference_protocol_and_refuse_cpu_tensors():
     per_dim = {"valence_alpha": torch.ones(4, 1)}
     assert float(losses.UncertaintyRegularizationLoss()(per_dim, torch.zeros(4))["reg_loss"]) == 0.0
     assert float(losses.CalibrationLoss()(per_dim, torch.zeros(4))) == 0.0
+
+
+def test_host_metrics_match_the_reference_vectors():
+    """mmdeer/metrics.py (the numpy mirror used by the CPU-side evaluators) against vectors captured from the imported
+    reference's DEERMetrics / uncertainty_calibration_error (tests/golden/make_golden.py metrics): CCC, MAE, RMSE per
+    dimension and the quantile-binned ECE, incl. NaN / inf rows, tied uncertainties and a too-small set."""
+    import os
+
+    import numpy as np
+    import pytest
+
+    from mmdeer.metrics import DEERMetrics, uncertainty_calibration_error, validation_metrics
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_cases.npz"))
+    m = DEERMetrics()
+    for tag in ("main", "nan", "small", "ties"):
+        p, t, u = g[f"{tag}.predictions"], g[f"{tag}.targets"], g[f"{tag}.uncertainties"]
+        for i, d in enumerate(("valence", "arousal", "dominance")):
+            assert m.concordance_correlation_coefficient(t[:, i], p[:, i]) == pytest.approx(float(g[f"{tag}.ccc_{d}"]), rel=1e-6, abs=1e-9), (tag, d)
+            assert m.mean_absolute_error(t[:, i], p[:, i]) == pytest.approx(float(g[f"{tag}.mae_{d}"]), rel=1e-5), (tag, d)
+            assert m.root_mean_squared_error(t[:, i], p[:, i]) == pytest.approx(float(g[f"{tag}.rmse_{d}"]), rel=1e-5), (tag, d)
+        assert uncertainty_calibration_error(p, t, u) == pytest.approx(float(g[f"{tag}.ece"]), rel=1e-5, abs=1e-8), tag
+        assert uncertainty_calibration_error(p, t, u, n_bins=15) == pytest.approx(float(g[f"{tag}.ece_15"]), rel=1e-5, abs=1e-8), tag
+    p, t, u = g["main.predictions"], g["main.targets"], g["main.uncertainties"]
+    vm = validation_metrics(p, t, u)
+    assert vm["ece"] == pytest.approx(float(g["main.ece"]), rel=1e-5)
+    assert vm["ccc_overall"] == pytest.approx(np.mean([float(g[f"main.ccc_{d}"]) for d in ("valence", "arousal", "dominance")]), rel=1e-6)
+
+
+def test_create_fusion_module_factory():
+    """fusion.create_fusion_module (fusion.py:557-592): the 'hierarchical' branch with the reference's defaults and key
+    names; the uncalled alternatives raise a clear NotImplementedError."""
+    import pytest
+
+    from mmdeer.model import HierarchicalMultimodalFusion, create_fusion_module
+
+    with pytest.raises(NotImplementedError, match="libmmdeer_hip.so is specialised"):
+        create_fusion_module("hierarchical", {})                       # the reference's defaults are 256/256/256 inputs
+    m = create_fusion_module("Hierarchical", {"audio_dim": 84, "video_dim": 256, "text_dim": 768, "dropout": 0.1})
+    assert isinstance(m, HierarchicalMultimodalFusion)
+    assert "trimodal_fusion.modality_attention.in_proj_weight" in m.state_dict()
+    for other in ("attention", "concatenation", "bilinear"):
+        with pytest.raises(NotImplementedError, match="only 'hierarchical' is built"):
+            create_fusion_module(other, {"input_dims": [256, 256, 256]})

@@ -79,6 +79,10 @@ def test_loss_classes_match_reference_vectors(tag, sl):
     cal = losses.CalibrationLoss()
     close(cal(flat, cu(y[sl])), g[f"calibration.{tag}"], "calibration")
     assert int(cal.last_bin_counts.sum()) <= 3 * (sl.stop - sl.start)
+    for nb in (10, 7):                                    # any n_bins: boundaries = fp32 torch.linspace, the reference's rule
+        caln = losses.CalibrationLoss(n_bins=nb)
+        close(caln(flat, cu(y[sl])), g[f"calibration{nb}.{tag}"], f"calibration n_bins={nb}")
+        assert caln.last_bin_counts.numel() == nb
 
 
 def test_loss_gradients_match_the_oracle():
@@ -148,4 +152,6 @@ def test_large_batch_and_interface():
     with pytest.raises(ValueError, match="Unknown loss type"):
         losses.create_deer_loss("other")
     with pytest.raises(NotImplementedError):
-        losses.CalibrationLoss(n_bins=10)
+        losses.CalibrationLoss(bin_strategy="quantile")
+    with pytest.raises(NotImplementedError):
+        losses.CalibrationLoss(n_bins=64)

@@ -325,3 +325,34 @@ def test_fused_adamw_checkpoint_round_trip_resumes_bit_for_bit():
     assert got == want
     for (n, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
         assert torch.equal(p1, p2), n
+
+
+@pytest.mark.parametrize("tag", ["main", "nan", "small", "ties"])
+def test_streaming_metrics_match_the_reference_vectors(tag):
+    """metrics.StreamingMetrics (mmdeer_eval_accumulate + the on-device quantile selection and bin sums of the calibration
+    error: no per-sample array is copied to the host) against vectors captured from the imported reference's DEERMetrics
+    and uncertainty_calibration_error, fed in ragged batches."""
+    import os
+
+    import numpy as np
+
+    from mmdeer.metrics import StreamingMetrics, device_calibration_error
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_cases.npz"))
+    p, t, u = (torch.from_numpy(g[f"{tag}.{k}"]).to("cuda:0") for k in ("predictions", "targets", "uncertainties"))
+    sm = StreamingMetrics("cuda:0")
+    n, lo = p.shape[0], 0
+    for step in (5, 64, 1, 300, 10 ** 6):
+        hi = min(n, lo + step)
+        if hi > lo:
+            sm.update(p[lo:hi], t[lo:hi], u[lo:hi])
+        lo = hi
+    out = sm.compute()
+    for d in ("valence", "arousal", "dominance"):
+        assert out[f"ccc_{d}"] == pytest.approx(float(g[f"{tag}.ccc_{d}"]), rel=1e-5, abs=1e-7), d
+        assert out[f"mae_{d}"] == pytest.approx(float(g[f"{tag}.mae_{d}"]), rel=1e-5), d
+        assert out[f"rmse_{d}"] == pytest.approx(float(g[f"{tag}.rmse_{d}"]), rel=1e-5), d
+    assert out["ece"] == pytest.approx(float(g[f"{tag}.ece"]), rel=2e-5, abs=1e-7)
+    err, unc = torch.cat(sm._err), torch.cat(sm._unc)
+    assert err.is_cuda and unc.is_cuda                       # the per-sample arrays stayed on the device
+    assert device_calibration_error(err, unc, n_bins=15) == pytest.approx(float(g[f"{tag}.ece_15"]), rel=2e-5, abs=1e-7)

@@ -152,12 +152,15 @@ SYMBOLS = [
     ("mmdeer_deer_loss_v1", c_int, [c_void_p] * 5 + [c_ll, c_float, c_float] + [c_void_p] * 6 + [c_void_p]),
     ("mmdeer_uncertainty_reg_loss", c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("mmdeer_calibration_loss", c_int, [c_void_p] * 4 + [c_ll] + [c_void_p] * 5 + [c_void_p]),
+    ("mmdeer_calibration_loss_bins", c_int, [c_void_p] * 4 + [c_ll, C.POINTER(c_float), c_int] + [c_void_p] * 5 + [c_void_p]),
     ("mmdeer_dropout_mask", c_int, [c_int, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p]),
     ("mmdeer_adamw_step", c_int, [C.POINTER(AdamWArgs)]),
     ("mmdeer_pack_weights", c_int, [C.POINTER(c_void_p), c_void_p, c_size_t, c_int, c_void_p]),
     ("mmdeer_cross_modal_attn_fwd", c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     ("mmdeer_lstm_cell_t1", c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_eval_accumulate", c_int, [c_void_p] * 6 + [c_int, c_void_p]),
+    ("mmdeer_eval_quantile_select", c_int, [c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("mmdeer_eval_ece_bins", c_int, [c_void_p, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_void_p]),
     ("mmdeer_stackb_residual_ln", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_stackb_attn_mix", c_int, [C.POINTER(StackBAttnArgs)]),
     ("mmdeer_stackb_gate_mix", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

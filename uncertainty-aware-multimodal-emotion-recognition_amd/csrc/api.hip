@@ -888,7 +888,16 @@ int mmdeer_calibration_loss(const float* gamma, const float* alpha, const float*
   MMDEER_CHECK(n > 0, "calibration_loss: n must be > 0 (got %lld)", n);
   const int ng = (dgamma != nullptr) + (dalpha != nullptr) + (dbeta != nullptr);
   MMDEER_CHECK(ng == 0 || ng == 3, "calibration_loss: pass all three gradient buffers or none");
-  return launch_calibration_loss(gamma, alpha, beta, targets, n, loss_out, bin_counts, dgamma, dalpha, dbeta, (hipStream_t)stream);
+  return launch_calibration_loss(gamma, alpha, beta, targets, n, loss_out, bin_counts, dgamma, dalpha, dbeta, nullptr, 15, (hipStream_t)stream);
+}
+int mmdeer_calibration_loss_bins(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
+                                 const float* edges, int n_bins, float* loss_out, int32_t* bin_counts, float* dgamma, float* dalpha,
+                                 float* dbeta, void* stream) {
+  MMDEER_CHECK(gamma && alpha && beta && targets && loss_out && edges, "calibration_loss_bins: NULL argument");
+  MMDEER_CHECK(n > 0, "calibration_loss_bins: n must be > 0 (got %lld)", n);
+  const int ng = (dgamma != nullptr) + (dalpha != nullptr) + (dbeta != nullptr);
+  MMDEER_CHECK(ng == 0 || ng == 3, "calibration_loss_bins: pass all three gradient buffers or none");
+  return launch_calibration_loss(gamma, alpha, beta, targets, n, loss_out, bin_counts, dgamma, dalpha, dbeta, edges, n_bins, (hipStream_t)stream);
 }
 
 long long mmdeer_nig_stats_elems(int B) { return (long long)nig_nblocks(B) * 3 * NIG_NSTAT; }

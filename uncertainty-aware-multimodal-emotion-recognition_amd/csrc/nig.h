@@ -59,8 +59,11 @@ int launch_deer_loss_v1(const float* mu, const float* nu, const float* alpha, co
 int launch_unc_reg_loss(const float* alpha, const float* beta, int B, int D, float dw, float sw, float* loss_out, float* dalpha,
                         float* dbeta, hipStream_t s);
 // losses.CalibrationLoss, 15 uniform bins (losses.py:419-497): loss_out[1], bin_counts[15] (optional)
+constexpr int CAL_MAX_BINS = 32;
+// edges: HOST array of n_bins + 1 fp32 values (torch.linspace(0, 1, n_bins + 1)), or null for the embedded 15-bin edges
 int launch_calibration_loss(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
-                            float* loss_out, int* bin_counts, float* dgamma, float* dalpha, float* dbeta, hipStream_t s);
+                            float* loss_out, int* bin_counts, float* dgamma, float* dalpha, float* dbeta, const float* edges,
+                            int n_bins, hipStream_t s);
 
 #ifdef MMDEER_STAMPS
 // diagnostic library only: the 16 s_memtime slots nig_bwd_kernel's workgroup (0, 0) wrote (tools/nig_stamps.py)

@@ -544,30 +544,36 @@ __global__ __launch_bounds__(256) void unc_reg_kernel(const float* alpha, const 
   }
 }
 
-// losses.CalibrationLoss, 15 uniform bins (losses.py:419-497): torch.linspace(0, 1, 16) in fp32 is NOT float32(i)/15
-__device__ const float kCalEdges[16] = {0.0f, 0x1.111112p-4f, 0x1.111112p-3f, 0x1.99999cp-3f, 0x1.111112p-2f, 0x1.555556p-2f,
-                                        0x1.99999cp-2f, 0x1.dddde0p-2f, 0x1.111110p-1f, 0x1.333332p-1f, 0x1.555554p-1f,
-                                        0x1.777778p-1f, 0x1.99999ap-1f, 0x1.bbbbbcp-1f, 0x1.dddddep-1f, 1.0f};
-__device__ __forceinline__ int cal_bin(float conf) {
+// losses.CalibrationLoss, uniform bins (losses.py:419-497).  The edges travel as kernel arguments: the caller supplies
+// torch.linspace(0, 1, n_bins + 1) as fp32 computes it (for 15 bins that is NOT float32(i)/15: kCalEdges15 below holds the
+// values captured from the reference's torch).
+struct CalEdges { float e[CAL_MAX_BINS + 1]; int nb; };
+const float kCalEdges15[16] = {0.0f, 0x1.111112p-4f, 0x1.111112p-3f, 0x1.99999cp-3f, 0x1.111112p-2f, 0x1.555556p-2f,
+                               0x1.99999cp-2f, 0x1.dddde0p-2f, 0x1.111110p-1f, 0x1.333332p-1f, 0x1.555554p-1f,
+                               0x1.777778p-1f, 0x1.99999ap-1f, 0x1.bbbbbcp-1f, 0x1.dddddep-1f, 1.0f};
+__device__ __forceinline__ int cal_bin(const float* ed, int nb, float conf) {
   int bin = -1;
-#pragma unroll
-  for (int k = 0; k < 15; ++k) {
-    const bool in = conf >= kCalEdges[k] && (k == 14 ? conf <= kCalEdges[k + 1] : conf < kCalEdges[k + 1]);   // [lo, hi), last [lo, hi]
+  for (int k = 0; k < nb; ++k) {
+    const bool in = conf >= ed[k] && (k == nb - 1 ? conf <= ed[k + 1] : conf < ed[k + 1]);   // [lo, hi), last [lo, hi]
     if (in) bin = k;
   }
   return bin;
 }
 __global__ __launch_bounds__(256) void calibration_kernel(const float* gamma, const float* alpha, const float* beta,
                                                           const float* targets, long long n, float* loss_out, int* bin_counts,
-                                                          float* dgamma, float* dalpha, float* dbeta) {
+                                                          float* dgamma, float* dalpha, float* dbeta, const CalEdges ce) {
   __shared__ float sm[4][3];
-  __shared__ float sgn[15];
+  __shared__ float sgn[CAL_MAX_BINS];
+  __shared__ float ed[CAL_MAX_BINS + 1];
+  const int nb = ce.nb;
+  if ((int)threadIdx.x <= nb) ed[threadIdx.x] = ce.e[threadIdx.x];
+  __syncthreads();
   float loss = 0.f;
-  for (int k = 0; k < 15; ++k) {     // 15 passes over a few thousand elements: each bin's three sums in a fixed order
+  for (int k = 0; k < nb; ++k) {     // nb passes over a few thousand elements: each bin's three sums in a fixed order
     float v[3] = {0.f, 0.f, 0.f};
     for (long long i = threadIdx.x; i < n; i += 256) {
       const float conf = 1.0f / (1.0f + beta[i] / (alpha[i] - 1.f + kEps));
-      if (cal_bin(conf) == k) {
+      if (cal_bin(ed, nb, conf) == k) {
         const float err = fabsf(targets[i] - gamma[i]);
         v[0] += 1.f; v[1] += conf; v[2] += 1.0f - fminf(fmaxf(err / 2.0f, 0.f), 1.f);
       }
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(256) void calibration_kernel(const float* gamma, co
   const float inv = 1.f / (float)n;
   for (long long i = threadIdx.x; i < n; i += 256) {
     const float den = alpha[i] - 1.f + kEps, u = beta[i] / den, conf = 1.0f / (1.0f + u);
-    const int b = cal_bin(conf);
+    const int b = cal_bin(ed, nb, conf);
     const float s = b >= 0 ? sgn[b] * inv : 0.f;        // d loss / d conf_i = s, d loss / d acc_i = -s
     const float d = targets[i] - gamma[i], h = fabsf(d) / 2.0f;
     const float sd = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
@@ -684,9 +690,16 @@ int launch_unc_reg_loss(const float* alpha, const float* beta, int B, int D, flo
 }
 
 int launch_calibration_loss(const float* gamma, const float* alpha, const float* beta, const float* targets, long long n,
-                            float* loss_out, int* bin_counts, float* dgamma, float* dalpha, float* dbeta, hipStream_t s) {
+                            float* loss_out, int* bin_counts, float* dgamma, float* dalpha, float* dbeta, const float* edges,
+                            int n_bins, hipStream_t s) {
   MMDEER_CHECK(n > 0, "calibration loss needs a non-empty batch");
-  hipLaunchKernelGGL(calibration_kernel, dim3(1), dim3(256), 0, s, gamma, alpha, beta, targets, n, loss_out, bin_counts, dgamma, dalpha, dbeta);
+  MMDEER_CHECK(n_bins >= 1 && n_bins <= CAL_MAX_BINS, "calibration loss: 1 <= n_bins <= %d (got %d)", CAL_MAX_BINS, n_bins);
+  CalEdges ce{};
+  ce.nb = n_bins;
+  const float* src = edges ? edges : kCalEdges15;
+  MMDEER_CHECK(edges || n_bins == 15, "calibration loss: edges must be given unless n_bins == 15");
+  for (int i = 0; i <= n_bins; ++i) ce.e[i] = src[i];
+  hipLaunchKernelGGL(calibration_kernel, dim3(1), dim3(256), 0, s, gamma, alpha, beta, targets, n, loss_out, bin_counts, dgamma, dalpha, dbeta, ce);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

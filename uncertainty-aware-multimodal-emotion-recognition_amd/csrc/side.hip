@@ -133,6 +133,104 @@ __global__ __launch_bounds__(256) void eval_accumulate_kernel(const float* pred,
   if (tid < 8) acc[d * 8 + tid] += sm[tid][0];   // calls on one stream are ordered: a plain read-modify-write
 }
 
+// ---- quantile-binned calibration error (reference src/utils/metrics.py:214-279) on per-sample device arrays --------------
+// The reference bins the per-sample mean uncertainty by its own quantiles (np.quantile, linear interpolation) and compares,
+// per bin, mean(1 - uncertainty) with mean(1 - error).  Two launches keep it on the device: an exact order-statistic
+// selection for the 2 (nq) ranks np.quantile interpolates between, and the bin sums against the edges the host derives from
+// those 2 nq values.  A sample counts when its error and uncertainty are not NaN and the uncertainty is finite (:243).
+__device__ __forceinline__ bool ece_valid(float e, float u) { return e == e && u == u && fabsf(u) != __builtin_inff(); }
+__device__ __forceinline__ unsigned ece_key(float f) {      // order-preserving map of a float to an unsigned integer
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ece_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+// block b: quantile r = b >> 1 (q_r = linspace(0, 1, nq)[r]), neighbour (b & 1): the floor(q (n - 1))-th smallest valid
+// uncertainty or the one after it, by a 4-pass radix selection (8 bits per pass, integer histograms: exact, deterministic)
+__global__ __launch_bounds__(256) void eval_quantile_select_kernel(const float* err, const float* unc, long long n, int nq,
+                                                                   float* vals, double* frac, long long* nvalid) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long s_cnt;
+  __shared__ unsigned s_digit;
+  __shared__ long long s_k;
+  const int tid = threadIdx.x, r = blockIdx.x >> 1, which = blockIdx.x & 1;
+  if (tid == 0) s_cnt = 0ull;
+  __syncthreads();
+  unsigned long long c = 0;
+  for (long long i = tid; i < n; i += 256) c += ece_valid(err[i], unc[i]) ? 1ull : 0ull;
+  atomicAdd(&s_cnt, c);
+  __syncthreads();
+  const long long nv = (long long)s_cnt;
+  if (nv == 0) {
+    if (tid == 0) { vals[2 * r + which] = 0.f; if (!which) { frac[r] = 0.0; if (r == 0) *nvalid = 0; } }
+    return;
+  }
+  const double q = (r == nq - 1) ? 1.0 : (double)r * (1.0 / (double)(nq - 1));      // np.linspace(0, 1, nq)[r]
+  const double virt = q * (double)(nv - 1);                                        // np.quantile, method 'linear'
+  const long long lo = (long long)floor(virt);
+  long long k = which ? (lo + 1 < nv ? lo + 1 : nv - 1) : lo;
+  unsigned prefix = 0u, mask = 0u;
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = 8 * pass;
+    hist[tid] = 0u;
+    __syncthreads();
+    for (long long i = tid; i < n; i += 256) {
+      const float u = unc[i];
+      if (!ece_valid(err[i], u)) continue;
+      const unsigned key = ece_key(u);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      long long cum = 0;
+      unsigned d = 0;
+      for (; d < 255u; ++d) {
+        if (k < cum + (long long)hist[d]) break;
+        cum += hist[d];
+      }
+      s_digit = d; s_k = k - cum;
+    }
+    __syncthreads();
+    prefix |= s_digit << shift; mask |= 255u << shift; k = s_k;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    vals[2 * r + which] = ece_unkey(prefix);
+    if (!which) { frac[r] = virt - (double)lo; if (r == 0) *nvalid = nv; }
+  }
+}
+
+// bins[i] = {count, sum (1 - u), sum (1 - e)} over the valid samples with edges[i] <= u < edges[i + 1] (nb <= 16).  One
+// workgroup, per-thread accumulators in LDS, fixed-order tree reduction: deterministic.
+constexpr int ECE_MAX_BINS = 16;
+__global__ __launch_bounds__(256) void eval_ece_bins_kernel(const float* err, const float* unc, long long n, const double* edges,
+                                                            int nb, double* bins) {
+  __shared__ double sm[ECE_MAX_BINS * 3][256];
+  __shared__ double ed[ECE_MAX_BINS + 1];
+  const int tid = threadIdx.x;
+  if (tid <= nb) ed[tid] = edges[tid];
+  for (int j = 0; j < nb * 3; ++j) sm[j][tid] = 0.0;
+  __syncthreads();
+  for (long long i = tid; i < n; i += 256) {
+    const float e = err[i], uf = unc[i];
+    if (!ece_valid(e, uf)) continue;
+    const double u = (double)uf;
+    for (int b = 0; b < nb; ++b) {
+      if (u >= ed[b] && u < ed[b + 1]) {
+        sm[3 * b][tid] += 1.0; sm[3 * b + 1][tid] += 1.0 - u; sm[3 * b + 2][tid] += 1.0 - (double)e;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off)
+      for (int j = 0; j < nb * 3; ++j) sm[j][tid] += sm[j][tid + off];
+    __syncthreads();
+  }
+  if (tid < nb * 3) bins[tid] = sm[tid][0];
+}
+
 }  // namespace
 }  // namespace mmdeer
 
@@ -185,6 +283,24 @@ int mmdeer_eval_accumulate(const float* pred, const float* target, const float* 
   MMDEER_CHECK(pred && target && acc, "eval_accumulate: pred / target / acc must be non-NULL");
   MMDEER_CHECK(!sample_unc || unc, "eval_accumulate: sample_unc needs unc");
   hipLaunchKernelGGL(eval_accumulate_kernel, dim3(4), dim3(256), 0, (hipStream_t)stream, pred, target, unc, acc, sample_err, sample_unc, B);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int mmdeer_eval_quantile_select(const float* err, const float* unc, long long n, int nq, float* vals, double* frac,
+                                long long* nvalid, void* stream) {
+  MMDEER_CHECK(err && unc && vals && frac && nvalid, "eval_quantile_select: NULL argument");
+  MMDEER_CHECK(n > 0 && nq >= 2 && nq <= 64, "eval_quantile_select: need n > 0 and 2 <= nq <= 64 (got n = %lld, nq = %d)", n, nq);
+  hipLaunchKernelGGL(eval_quantile_select_kernel, dim3(2 * nq), dim3(256), 0, (hipStream_t)stream, err, unc, n, nq, vals, frac, nvalid);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int mmdeer_eval_ece_bins(const float* err, const float* unc, long long n, const double* edges, int n_bins, double* bins,
+                         void* stream) {
+  MMDEER_CHECK(err && unc && edges && bins, "eval_ece_bins: NULL argument");
+  MMDEER_CHECK(n > 0 && n_bins >= 1 && n_bins <= ECE_MAX_BINS, "eval_ece_bins: need n > 0 and 1 <= n_bins <= %d (got %d)", ECE_MAX_BINS, n_bins);
+  hipLaunchKernelGGL(eval_ece_bins_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, err, unc, n, edges, n_bins, bins);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

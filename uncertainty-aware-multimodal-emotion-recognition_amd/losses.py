@@ -184,15 +184,18 @@ class UncertaintyRegularizationLoss(nn.Module):
 
 class _CalFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gamma, alpha, beta, targets):
+    def forward(ctx, gamma, alpha, beta, targets, edges):
+        import ctypes as C
         lib = _lib.load()
         n = gamma.numel()
+        nb = len(edges) - 1
         grads = torch.empty(3, n, dtype=torch.float32, device=gamma.device)
         out = torch.empty(1, dtype=torch.float32, device=gamma.device)
-        bins = torch.empty(15, dtype=torch.int32, device=gamma.device)
-        _lib.check(lib.mmdeer_calibration_loss(gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(), targets.data_ptr(), n,
-                                               out.data_ptr(), bins.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
-                                               grads[2].data_ptr(), _lib.current_stream()))
+        bins = torch.empty(nb, dtype=torch.int32, device=gamma.device)
+        _lib.check(lib.mmdeer_calibration_loss_bins(gamma.data_ptr(), alpha.data_ptr(), beta.data_ptr(), targets.data_ptr(), n,
+                                                    (C.c_float * (nb + 1))(*edges), nb, out.data_ptr(), bins.data_ptr(),
+                                                    grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(),
+                                                    _lib.current_stream()))
         ctx.save_for_backward(grads)
         ctx.shape = gamma.shape
         ctx.mark_non_differentiable(bins)
@@ -201,18 +204,24 @@ class _CalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, _g_bins):
         (grads,) = ctx.saved_tensors
-        return tuple((grads[i] * g_out[0]).view(ctx.shape) for i in range(3)) + (None,)
+        return tuple((grads[i] * g_out[0]).view(ctx.shape) for i in range(3)) + (None, None)
 
 
 class CalibrationLoss(nn.Module):
-    """``losses.CalibrationLoss`` (src/utils/losses.py:419-497), the default 15 uniform bins; flat keys as in the reference
-    (0 when they are absent).  ``last_bin_counts`` holds the exact bin populations of the last call."""
+    """``losses.CalibrationLoss`` (src/utils/losses.py:419-497) with ``n_bins`` uniform bins (default 15, at most 32): the bin
+    boundaries are ``torch.linspace(0, 1, n_bins + 1)`` in fp32, the reference's own rule (:459), evaluated once on the host
+    and handed to the kernel.  Flat keys as in the reference (0 when they are absent).  ``bin_strategy='quantile'``
+    (data-dependent boundaries through torch.quantile, :461-462) is not built.  ``last_bin_counts`` holds the exact bin
+    populations of the last call."""
 
     def __init__(self, n_bins: int = 15, bin_strategy: str = "uniform"):
         super().__init__()
-        if n_bins != 15 or bin_strategy != "uniform":
-            raise NotImplementedError("the kernel embeds torch.linspace(0, 1, 16): n_bins=15, bin_strategy='uniform'")
-        self.n_bins, self.bin_strategy = n_bins, bin_strategy
+        if bin_strategy != "uniform":
+            raise NotImplementedError("CalibrationLoss: only bin_strategy='uniform' is built (the quantile variant is not)")
+        if not 1 <= int(n_bins) <= 32:
+            raise NotImplementedError("CalibrationLoss: 1 <= n_bins <= 32")
+        self.n_bins, self.bin_strategy = int(n_bins), bin_strategy
+        self._edges = [float(x) for x in torch.linspace(0, 1, self.n_bins + 1, dtype=torch.float32)]
         self.last_bin_counts: Optional[torch.Tensor] = None
 
     def forward(self, predictions: Dict[str, torch.Tensor], targets: torch.Tensor) -> torch.Tensor:
@@ -224,7 +233,7 @@ class CalibrationLoss(nn.Module):
         y = _match(_gpu_f32(targets, "targets"), gamma, "targets").contiguous()
         if gamma.numel() == 0:
             raise ValueError("CalibrationLoss: empty batch")
-        out, bins = _CalFn.apply(gamma, alpha, beta, y)
+        out, bins = _CalFn.apply(gamma, alpha, beta, y, self._edges)
         self.last_bin_counts = bins
         return out[0]
 

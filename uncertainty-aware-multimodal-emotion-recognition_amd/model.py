@@ -631,6 +631,25 @@ class HierarchicalMultimodalFusion(nn.Module):
         return {k: out[k] for k in self.KEYS}
 
 
+def create_fusion_module(fusion_type: str, config: Dict) -> nn.Module:
+    """``fusion.create_fusion_module`` (src/models/fusion.py:557-592).  ``'hierarchical'`` (:568-578) returns this package's
+    ``HierarchicalMultimodalFusion`` with the reference's key lookups and defaults.  The other two branches -- ``'attention'``
+    (``AttentionFusion``, :504-528) and the concatenation fallback -- as well as ``AdaptiveFusionGating`` / ``BilinearFusion``
+    (:421-554) have no caller anywhere in the reference and are not built."""
+    kind = str(fusion_type).lower()
+    if kind == "hierarchical":
+        return HierarchicalMultimodalFusion(
+            audio_dim=config.get("audio_dim", 256), video_dim=config.get("video_dim", 256), text_dim=config.get("text_dim", 256),
+            fusion_dim=config.get("fusion_dim", 512), intermediate_dim=config.get("intermediate_dim", 256),
+            num_attention_heads=config.get("num_attention_heads", 8), dropout=config.get("dropout", 0.3),
+            use_uncertainty_weighting=config.get("use_uncertainty_weighting", True),
+            **{k: config[k] for k in ("compute_dtype", "seed") if k in config})
+    raise NotImplementedError(
+        f"create_fusion_module({fusion_type!r}): only 'hierarchical' is built.  The reference's 'attention' (AttentionFusion) "
+        "and concatenation branches, AdaptiveFusionGating and BilinearFusion (fusion.py:421-592) are never called by any of "
+        "its scripts and have no HIP implementation here; use the reference's torch modules for them.")
+
+
 def create_model(config: Optional[ModelConfig] = None, device: Optional[str] = None) -> MultimodalDEER:
     m = MultimodalDEER(config)
     return m.to(device) if device else m
