@@ -296,7 +296,8 @@ def main():
     from mmdeer.parallel import BucketedAllReduce
 
     B = args.batch
-    model = MultimodalDEER(ModelConfig(compute_dtype=args.dtype, dropout=0.3, seed=42)).to(dev).train()
+    # same parameters on every rank (seed), a dropout stream of its own per rank (dropout_seed): uncorrelated masks across shards
+    model = MultimodalDEER(ModelConfig(compute_dtype=args.dtype, dropout=0.3, seed=42, dropout_seed=42 + 1000003 * rank)).to(dev).train()
     data = synth.make_batch(B, seed=42, row_offset=rank * B)       # rank r owns rows [rB, (r+1)B) of the global stream
     a, v, t, y = (torch.from_numpy(data[k]).to(dev) for k in ("audio", "video", "text", "targets"))
     if args.dtype == "bf16":

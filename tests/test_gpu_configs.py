@@ -189,3 +189,25 @@ def test_trainer_graph_step_in_exact_global_mode_equals_the_eager_step(tmp_path)
     assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-8)
     for (n_, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.allclose(p1, p2, rtol=1e-4, atol=1e-6), n_
+
+
+def test_data_parallel_ranks_share_parameters_but_not_dropout_masks():
+    """ranks build the model with the same seed (identical parameters) -- their dropout masks must still differ
+    (ModelConfig.dropout_seed, set per rank by bench.py), while one rank's masks stay a pure function of (seed, step)."""
+    from mmdeer import _lib
+    lib = _lib.load()
+    ranks = [MultimodalDEER(ModelConfig(compute_dtype="bf16", dropout=0.3, seed=42, dropout_seed=42 + 1000003 * r)).to(DEV).train() for r in range(2)]
+    for (n0, p0), (_, p1) in zip(ranks[0].named_parameters(), ranks[1].named_parameters()):
+        assert torch.equal(p0, p1), n0
+    b = batch(64, seed=2)
+    a, v, t, y = (b[k].to(DEV) for k in ("audio", "video", "text", "targets"))
+    masks = []
+    for m in ranks:
+        m.train_step(a.bfloat16(), v.bfloat16(), t.bfloat16(), y)
+        mk = torch.empty(64, 512, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.mmdeer_dropout_mask(5, 64, 512, 0.3, m.dropout_seed, m._step, mk.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        masks.append(mk.clone())
+    torch.cuda.synchronize()
+    agree = float((masks[0] == masks[1]).float().mean())
+    assert 0.5 < agree < 0.66            # independent Bernoulli(0.7) masks agree with probability 0.58
+    assert ranks[0].dropout_seed != ranks[1].dropout_seed and not torch.equal(ranks[0].flat_grad(), ranks[1].flat_grad())

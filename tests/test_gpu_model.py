@@ -131,7 +131,7 @@ def test_autograd_path_equals_fused_step():
 def dump_masks(m, B, offset):
     """Regenerate the keep-masks of a training forward (seed, offset) for the oracle."""
     lib = _lib.load()
-    p, seed = m.dims.dropout, m.config.seed
+    p, seed = m.dims.dropout, m.dropout_seed
     s = torch.cuda.current_stream().cuda_stream
 
     def mask(site, rows, cols):

@@ -31,8 +31,8 @@ def loaders(n, bs, seed, as_dict):
 @pytest.mark.parametrize("as_dict", [False, True])
 def test_trainer_reduces_loss_and_reports_metrics(tmp_path, as_dict):
     model = MultimodalDEER(ModelConfig(compute_dtype="fp32", dropout=0.1, seed=3))
-    cfg = TrainingConfig(learning_rate=3e-4, batch_size=32, num_epochs=4, output_dir=str(tmp_path / "out"),
-                         log_dir=str(tmp_path / "log"), checkpoint_dir=str(tmp_path / "ckpt"))
+    cfg = TrainingConfig(learning_rate=3e-4, batch_size=32, num_epochs=4, output_dir=str(tmp_path / "out"), val_frequency=1,
+                         save_frequency=2, log_dir=str(tmp_path / "log"), checkpoint_dir=str(tmp_path / "ckpt"))
     tr = DEERTrainer(model, cfg, "cuda:0")
     assert len(tr.optimizer.param_groups) >= 2                 # 'attention'-named group + default group
     hist = tr.train(loaders(256, 32, 1, as_dict), loaders(96, 32, 2, as_dict))
@@ -43,10 +43,36 @@ def test_trainer_reduces_loss_and_reports_metrics(tmp_path, as_dict):
     for k in ("ccc_valence", "mae_arousal", "rmse_dominance", "ece", "ccc_overall", "test_loss"):
         assert np.isfinite(ev[k]), k
     ck = torch.load(tmp_path / "ckpt" / "best_model.pt", weights_only=False)
-    assert set(ck) == {"model_state_dict", "training_config", "training_history", "training_time"}
+    assert {"model_state_dict", "training_config", "training_history", "training_time"} <= set(ck)     # run_multimodal_deer.py:512-517
+    assert {"optimizer_state_dict", "scheduler_state_dict", "epoch", "loss"} <= set(ck)                  # what a resume needs
+    assert sorted(f for f in os.listdir(tmp_path / "ckpt")) == ["best_model.pt", "checkpoint_epoch_0.pt", "checkpoint_epoch_2.pt", "final_model.pt"]
     m2 = MultimodalDEER(ModelConfig()).to("cuda:0")
     m2.load_state_dict(ck["model_state_dict"])
     assert np.isfinite(evaluate_deer_model(m2, loaders(64, 32, 5, as_dict), "cuda:0")["ccc_overall"])
+
+
+def test_trainer_validation_frequency_patience_and_resume(tmp_path):
+    """training.py:379-425 semantics: validation every val_frequency epochs, the best model by ccc_overall, patience counted
+    in validations; no validation loaders -> no best model, no early stop, every epoch runs; load_checkpoint resumes the
+    optimiser (moments, step) and the scheduler."""
+    mk = lambda: MultimodalDEER(ModelConfig(compute_dtype="fp32", dropout=0.0, seed=3))
+    cfg = dict(learning_rate=3e-4, batch_size=32, output_dir=str(tmp_path / "o"), log_dir=str(tmp_path / "l"))
+    tr = DEERTrainer(mk(), TrainingConfig(num_epochs=6, val_frequency=2, save_frequency=100, patience=50,
+                                          checkpoint_dir=str(tmp_path / "c1"), **cfg), "cuda:0")
+    h = tr.train(loaders(64, 32, 1, False), loaders(64, 32, 2, False))
+    assert len(h["val_loss"]) == 3 and len(h["learning_rate"]) == 6            # epochs 0, 2, 4 validated
+    assert os.path.exists(tmp_path / "c1" / "best_model.pt")
+    tr2 = DEERTrainer(mk(), TrainingConfig(num_epochs=5, patience=1, checkpoint_dir=str(tmp_path / "c2"), **cfg), "cuda:0")
+    h2 = tr2.train(loaders(64, 32, 1, False), {})                               # no validation: all epochs, no best model
+    assert len(h2["train_loss"]) == 5 and not os.path.exists(tmp_path / "c2" / "best_model.pt")
+    assert os.path.exists(tmp_path / "c2" / "final_model.pt")
+    # resume: optimiser step count, moments and the scheduler's epoch come back
+    tr3 = DEERTrainer(mk(), TrainingConfig(num_epochs=5, checkpoint_dir=str(tmp_path / "c3"), **cfg), "cuda:0")
+    ck = tr3.load_checkpoint(str(tmp_path / "c2" / "final_model.pt"))
+    assert tr3.optimizer._t == tr2.optimizer._t and tr3.scheduler.last_epoch == tr2.scheduler.last_epoch
+    assert torch.equal(tr3.optimizer._exp_avg.cpu(), tr2.optimizer._exp_avg.cpu()) and ck["epoch"] == 4
+    for (n1, p1), (_, p2) in zip(tr3.model.named_parameters(), tr2.model.named_parameters()):
+        assert torch.equal(p1, p2), n1
 
 
 def test_clip_matches_torch_clip_grad_norm():
@@ -78,7 +104,8 @@ def test_launcher_quick_run(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     exp = [d for d in os.listdir(tmp_path) if d.startswith("experiment_")]
     rep = json.load(open(tmp_path / exp[0] / "report.json"))
-    assert len(rep["history"]["train_loss"]) == 2
+    # the reference's defaults (training.py:64, 379): validation -- and a history row -- every val_frequency = 5 epochs
+    assert len(rep["history"]["train_loss"]) == 1 and len(rep["history"]["learning_rate"]) == 2
     assert rep["sample_predictions"]["nig_keys"] == ["gamma", "nu", "alpha", "beta"]
     assert np.array(rep["sample_predictions"]["predictions"]).shape == (4, 3)
 

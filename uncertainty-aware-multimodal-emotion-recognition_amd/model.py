@@ -49,7 +49,11 @@ class ModelConfig:
     gradient_clip: float = 1.0
     # build-specific knobs (not in the reference)
     compute_dtype: str = "fp32"   # "fp32": exact-fp32 MFMA (parity config); "bf16": bf16 MFMA, fp32 accumulate
-    seed: int = 42
+    seed: int = 42                # parameter initialisation AND (unless dropout_seed is given) the dropout stream
+    # Data parallel: every rank builds the model with the same `seed` (identical parameters) and indexes its rows from 0, so
+    # with one dropout key all ranks would draw the SAME masks for their local rows -- correlated noise across the shards,
+    # unlike DDP with per-rank RNG state.  Give each rank its own dropout_seed (bench.py: seed + 1000003 * rank).
+    dropout_seed: Optional[int] = None
 
 
 class _ParamTree(nn.Module):
@@ -222,6 +226,11 @@ class MultimodalDEER(nn.Module):
     def compute_f32(self) -> int:
         return 1 if self.config.compute_dtype == "fp32" else 0
 
+    @property
+    def dropout_seed(self) -> int:
+        ds = getattr(self.config, "dropout_seed", None)
+        return int(self.config.seed if ds is None else ds)
+
     def live_parameters(self):
         return list(self._live)
 
@@ -296,7 +305,7 @@ class MultimodalDEER(nn.Module):
         a.batch, a.compute_f32, a.training, a.inputs_bf16, a.repack = B, self.compute_f32, int(training), int(in_bf16), int(repack)
         # graph mode: the step counter lives on the device (offset_dev) and the host-side offset is 0
         step = 0 if offset_dev is not None else int(self._step)
-        a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), step
+        a.dropout_p, a.seed, a.offset = float(self.dims.dropout), self.dropout_seed, step
         a.offset_dev = _lib.ptr(offset_dev)
         a.bump_offset_dev = int(bump)
         a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
@@ -348,7 +357,7 @@ class MultimodalDEER(nn.Module):
             flat = torch.zeros(self._flat_elems, dtype=torch.float32, device=dev)
         a = _lib.BackwardArgs()
         a.batch, a.compute_f32, a.training, a.inputs_bf16 = B, self.compute_f32, meta["training"], meta["in_bf16"]
-        a.dropout_p, a.seed, a.offset = float(self.dims.dropout), int(self.config.seed), meta["offset"]
+        a.dropout_p, a.seed, a.offset = float(self.dims.dropout), self.dropout_seed, meta["offset"]
         a.offset_dev = _lib.ptr(meta.get("offset_dev"))
         audio, video, text = meta["inputs"]
         a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()

@@ -171,39 +171,78 @@ class DEERTrainer:
         return m
 
     def train(self, train_loaders, val_loaders) -> Dict:
-        """Returns a JSON-serialisable history (run_multimodal_deer.py:503-509)."""
+        """The loop of training.py:356-455.  Validation every ``val_frequency`` epochs (:379); the best model is the one with
+        the highest ``ccc_overall`` (:406-418) and early stopping counts validations without improvement (:419-425); a
+        checkpoint every ``save_frequency`` epochs (:433-439) and a final one (:445-448); the plateau scheduler steps on the
+        validation loss when there is one, else on the training loss (:428-429).  Without validation loaders nothing is
+        validated, so there is no best model and no early stopping.  Returns a JSON-serialisable history
+        (run_multimodal_deer.py:503-509)."""
         t0 = time.time()
-        best, bad = float("inf"), 0
-        for epoch in range(self.config.num_epochs):
+        c = self.config
+        self.best_ccc, self.best_val_loss, self.patience_counter = -float("inf"), float("inf"), 0
+        vf, sf = max(1, int(c.val_frequency)), max(1, int(c.save_frequency))
+        for epoch in range(c.num_epochs):
             self.current_epoch = epoch
             tr = self.train_epoch(train_loaders)
-            va = self.validate_epoch(val_loaders) if val_loaders else {"val_loss": float("nan")}
-            if isinstance(self.scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau):
-                self.scheduler.step(va["val_loss"])
-            else:
-                self.scheduler.step()
-            self.history["train_loss"].append(tr["total_loss"])
-            self.history["val_loss"].append(va["val_loss"])
-            self.history["train_ccc"].append(float("nan"))
-            self.history["val_ccc"].append(va.get("ccc_overall", float("nan")))
+            va, stop = None, False
+            if val_loaders and epoch % vf == 0:
+                va = self.validate_epoch(val_loaders)
+                self.history["train_loss"].append(tr["total_loss"])
+                self.history["val_loss"].append(va["val_loss"])
+                self.history["train_ccc"].append(float("nan"))
+                self.history["val_ccc"].append(va.get("ccc_overall", float("nan")))
+                for k in ("ccc_valence", "ccc_arousal", "ccc_dominance", "ece"):
+                    self.history.setdefault(k, []).append(va.get(k, 0.0))
+                cur = va.get("ccc_overall", 0.0)
+                if cur > self.best_ccc:
+                    self.best_ccc, self.best_val_loss, self.patience_counter = cur, va["val_loss"], 0
+                    self.save_checkpoint(os.path.join(c.checkpoint_dir, "best_model.pt"), time.time() - t0, epoch=epoch, loss=va["val_loss"])
+                else:
+                    self.patience_counter += 1
+                stop = bool(c.early_stopping) and self.patience_counter >= c.patience
+            elif not val_loaders:
+                self.history["train_loss"].append(tr["total_loss"])
+                self.history["val_loss"].append(float("nan"))
+                self.history["train_ccc"].append(float("nan"))
+                self.history["val_ccc"].append(float("nan"))
             self.history["learning_rate"].append(self.optimizer.param_groups[0]["lr"])
             self.history["grad_norm"].append(tr["grad_norm"])
-            if va["val_loss"] < best - 1e-6:
-                best, bad = va["val_loss"], 0
-                self.save_checkpoint(os.path.join(self.config.checkpoint_dir, "best_model.pt"), time.time() - t0)
+            if stop:
+                break
+            if isinstance(self.scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau):
+                self.scheduler.step(va["val_loss"] if va is not None else tr["total_loss"])
             else:
-                bad += 1
-                if self.config.early_stopping and bad >= self.config.patience:
-                    break
+                self.scheduler.step()
+            if epoch % sf == 0:
+                self.save_checkpoint(os.path.join(c.checkpoint_dir, f"checkpoint_epoch_{epoch}.pt"), time.time() - t0, epoch=epoch,
+                                     loss=tr["total_loss"])
         self.history["training_time"] = time.time() - t0
-        with open(os.path.join(self.config.output_dir, "training_history.json"), "w") as f:
+        self.save_checkpoint(os.path.join(c.checkpoint_dir, "final_model.pt"), self.history["training_time"], epoch=self.current_epoch)
+        with open(os.path.join(c.output_dir, "training_history.json"), "w") as f:
             json.dump(self.history, f, indent=2)
         return self.history
 
-    def save_checkpoint(self, path: str, training_time: float = 0.0) -> None:
-        """Checkpoint layout of run_multimodal_deer.py:512-517."""
+    def save_checkpoint(self, path: str, training_time: float = 0.0, epoch: Optional[int] = None, loss: Optional[float] = None) -> None:
+        """Checkpoint layout of run_multimodal_deer.py:512-517 (model_state_dict / training_config / training_history /
+        training_time) plus what a resume needs and the reference's ModelCheckpoint calls pass (training.py:415-418):
+        optimiser state (FusedAdamW: step count and the flat moment buffers), scheduler state, epoch, loss."""
         torch.save({"model_state_dict": self.model.state_dict(), "training_config": asdict(self.config),
-                    "training_history": self.history, "training_time": training_time}, path)
+                    "training_history": self.history, "training_time": training_time,
+                    "optimizer_state_dict": self.optimizer.state_dict(), "scheduler_state_dict": self.scheduler.state_dict(),
+                    "epoch": epoch, "loss": loss}, path)
+
+    def load_checkpoint(self, path: str) -> Dict:
+        """Resume from ``save_checkpoint``: parameters, optimiser moments / step, scheduler, history."""
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.model.load_state_dict(ck["model_state_dict"])
+        if ck.get("optimizer_state_dict") is not None:
+            self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        if ck.get("scheduler_state_dict") is not None:
+            self.scheduler.load_state_dict(ck["scheduler_state_dict"])
+        self.history = ck.get("training_history", self.history)
+        if ck.get("epoch") is not None:
+            self.current_epoch = int(ck["epoch"])
+        return ck
 
 
 @torch.no_grad()
