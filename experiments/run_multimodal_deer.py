@@ -23,6 +23,7 @@ import yaml  # noqa: E402
 from torch.utils.data import DataLoader, TensorDataset  # noqa: E402
 
 from mmdeer import synth  # noqa: E402
+from mmdeer import stackb  # noqa: E402
 from mmdeer.model import CompleteDEERModel, ModelConfig  # noqa: E402
 from mmdeer.trainer import DEERTrainer, TrainingConfig  # noqa: E402
 
@@ -50,6 +51,9 @@ def main():
     ap.add_argument("--output_dir", default="./results")
     ap.add_argument("--compute_dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--stack", default="c", choices=["c", "b"],
+                    help="which class the script's name CompleteDEERModel resolves to: c = multimodal_deer.MultimodalDEER (the model "
+                         "the reference trains, fused HIP step), b = complete_project.CompleteDEERModel (operator-sequence training)")
     args = ap.parse_args()
 
     cfg = json.loads(json.dumps(DEFAULT_CONFIG))
@@ -70,9 +74,14 @@ def main():
     exp_dir = os.path.join(args.output_dir, time.strftime("experiment_%Y%m%d_%H%M%S"))
     os.makedirs(exp_dir, exist_ok=True)
 
-    mc = ModelConfig(**{k: v for k, v in cfg["model"].items() if k in ModelConfig.__dataclass_fields__},
-                     compute_dtype=args.compute_dtype, seed=args.seed)
-    model = CompleteDEERModel(mc).to(device)
+    if args.stack == "b":
+        fields = stackb.ModelConfig.__dataclass_fields__
+        model = stackb.CompleteDEERModel(stackb.ModelConfig(**{k: v for k, v in cfg["model"].items() if k in fields}, dropout_seed=args.seed),
+                                         compute_dtype=args.compute_dtype).to(device)
+    else:
+        mc = ModelConfig(**{k: v for k, v in cfg["model"].items() if k in ModelConfig.__dataclass_fields__},
+                         compute_dtype=args.compute_dtype, seed=args.seed)
+        model = CompleteDEERModel(mc).to(device)
     print(f"model: {sum(p.numel() for p in model.parameters()):,} parameters, compute {args.compute_dtype}")
     bs = cfg["training"]["batch_size"]
     train = synthetic_loader(1000, bs, "train", args.seed)
@@ -97,10 +106,11 @@ def main():
         model.eval()
         with torch.no_grad():
             b = {k: torch.from_numpy(v).to(device) for k, v in synth.make_batch(4, seed=7).items()}
-            out = model({"audio": b["audio"], "video": b["video"], "text": b["text"]})     # :707-719
+            out = (model(b["audio"], b["video"], b["text"]) if args.stack == "b" else
+                   model({"audio": b["audio"], "video": b["video"], "text": b["text"]}))     # :707-719
             preds, unc = model.get_predictions_and_uncertainties(out)
         report["sample_predictions"] = {"predictions": preds.cpu().tolist(), "uncertainties": unc.cpu().tolist(),
-                                        "nig_keys": [k for k in ("gamma", "nu", "alpha", "beta") if k in out]}
+                                        "nig_keys": [k for k in (("valence_mu", "valence_nu") if args.stack == "b" else ("gamma", "nu", "alpha", "beta")) if k in out]}
     with open(os.path.join(exp_dir, "report.json"), "w") as f:
         json.dump(report, f, indent=2, default=float)
     print("report:", os.path.join(exp_dir, "report.json"))

@@ -380,6 +380,46 @@ int mmdeer_stackb_gate_mix(const void* gate_logits, int ld_g, const void* tri, i
 int mmdeer_stackb_head(const float* ev, int ld_ev, const float* temperature, const float* w1, const float* b1, const float* w2,
                        const float* b2, const float* w3, const float* b3, float* out, int B, void* stream);
 
+/* ---- Stack B training (forward with dropout + backward).  The Linear / LayerNorm layers run on mmdeer_gemm (forward,
+ * dX with the ReLU / dropout mask in the epilogue, dW + bias gradient) and mmdeer_layernorm_fwd / _bwd, sequenced by
+ * the host (mmdeer/stackb.py); these are the remaining row operators.  Nothing here sums over the batch. */
+typedef struct mmdeer_stackb_attn_train_args {
+  /* forward operands: as mmdeer_stackb_attn_args */
+  const void* h2; const void* pre; const void* self_out; const void* cross_out;
+  const float* est_w3; const float* est_b3; const float* wn_w1_unc; const float* wn_w2; const float* wn_b2;
+  void* out_av; void* out_text;
+  /* saved by the forward, read by the backward */
+  void* r;                  /* act [B][256]: weight_network hidden after ReLU and dropout */
+  float* weights4;          /* fp32 [B][4]: softmax weights (audio, video, text, 0) */
+  float* unc4;              /* fp32 [B][4]: modality uncertainties (audio, video, text, 0) */
+  /* backward: gradients in (d_av: rows of stride ld_av, audio | video; d_text: stride ld_text) and out */
+  const void* d_av; const void* d_text;
+  void* d_self; void* d_cross;    /* act [B][768] */
+  void* d_pre;                    /* act [B][256] */
+  void* d_logits8;                /* act [B][8]: columns 0..2, the rest written as zeros (8 columns = one 16-byte bf16 row,
+                                     the narrowest k-contiguous operand mmdeer_gemm's vector loads take) */
+  void* d_z8;                     /* act [3B][8]: column 0 = gradient at the estimator's pre-sigmoid output, the rest zeros */
+  void* d_h2;                     /* act [3B][64] */
+  int32_t ld_w1_unc, ld_av, ld_text, B, act_f32;
+  int32_t training, drop_site;    /* weight_network.2 dropout: keep mask = hash(seed, offset, drop_site, row, col) */
+  float dropout_p;
+  uint64_t seed, offset;
+  void* stream;
+} mmdeer_stackb_attn_train_args;
+int mmdeer_stackb_attn_mix_train_fwd(const mmdeer_stackb_attn_train_args* a);
+int mmdeer_stackb_attn_mix_bwd(const mmdeer_stackb_attn_train_args* a);
+/* d of mmdeer_stackb_gate_mix: dg (gate logits), dtri (already masked by tri > 0: tri is a Linear + ReLU output), dav */
+int mmdeer_stackb_gate_mix_bwd(const void* dout, int ld_do, const void* gate_logits, int ld_g, const void* tri, int ld_t, const void* av,
+                               int ld_av, void* dg, int ld_dg, void* dtri, int ld_dt, void* dav, int ld_dav, int B, int N, int act_f32,
+                               void* stream);
+/* g4: fp32 [4][B][3] gradients wrt (mu, nu, alpha, beta); dev: act [B][ld_dev >= 24], dev[b][8 d + k] = gradient wrt
+ * head d's raw output k (k < 4), columns 8 d + 4 .. 8 d + 7 written as zeros */
+int mmdeer_stackb_head_bwd(const float* ev, int ld_ev, const float* g4, void* dev, int ld_dev, int B, int act_f32, void* stream);
+/* out = (x + y) * (mask > 0 ? scale : 0) on [M][N] activation views (y, mask optional): gradient joins, residual sums,
+ * ReLU / dropout masks that no GEMM epilogue can carry */
+int mmdeer_add_masked(void* out, int ld_out, const void* x, int ld_x, const void* y, int ld_y, const void* mask, int ld_mask,
+                      float scale, int M, int N, int act_f32, void* stream);
+
 /* The whole eval forward as ONE call: 25 launches per batch (26 in bf16 mode), the three encoders / the layers that
  * share an input side by side in grouped GEMM launches.  `mmdeer_stackb_weights` is the device-side operand image the
  * host builds once per parameter update from the reference's state_dict (mmdeer/stackb.py does it): matrices ("W") in

@@ -238,6 +238,22 @@ def capture_stackb():
     with torch.no_grad():
         o = model(*(torch.from_numpy(batch[k]) for k in ("audio", "video", "text")))
     out = {"out." + k: tnp(v) for k, v in o.items()}
+    # gradients of MultiTaskDEERLoss through the eval-mode model (every dropout site open): per parameter the sum, the
+    # l2 norm and 256 evenly spaced elements of the flattened gradient -- digests, so the fixture stays small
+    model.zero_grad()
+    o = model(*(torch.from_numpy(batch[k]) for k in ("audio", "video", "text")))
+    loss = ref_losses.MultiTaskDEERLoss()(o, torch.from_numpy(batch["targets"]))
+    loss["total_loss"].backward()
+    out["grad.total_loss"] = tnp(loss["total_loss"])
+    for name, prm in model.named_parameters():
+        if prm.grad is None:
+            out["gradnone." + name] = np.zeros(0, np.float32)
+            continue
+        g = prm.grad.detach().double().reshape(-1)
+        idx = torch.linspace(0, g.numel() - 1, min(256, g.numel())).round().long()
+        out["gradsum." + name] = np.float64(g.sum().item())
+        out["gradnorm." + name] = np.float64(g.norm().item())
+        out["gradsample." + name] = g[idx].numpy().astype(np.float32)
     with open(os.path.join(HERE, "stackb_state_dict_names.json"), "w") as fh:
         json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, fh, indent=0)
     return out

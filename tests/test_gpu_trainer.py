@@ -110,6 +110,25 @@ def test_launcher_quick_run(tmp_path):
     assert np.array(rep["sample_predictions"]["predictions"]).shape == (4, 3)
 
 
+def test_launcher_stack_b(tmp_path):
+    """`--stack b`: the script's CompleteDEERModel resolved to complete_project's class -- trainer, validation,
+    evaluation, checkpoint and report over the operator-sequence training path."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "experiments", "run_multimodal_deer.py"), "--mode", "full", "--quick", "--stack", "b",
+                        "--batch_size", "32", "--epochs", "5", "--learning_rate", "1e-3", "--output_dir", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = [d for d in os.listdir(tmp_path) if d.startswith("experiment_")]
+    rep = json.load(open(tmp_path / exp[0] / "report.json"))
+    assert len(rep["history"]["train_loss"]) == 1 and len(rep["history"]["learning_rate"]) == 5
+    assert np.isfinite(rep["history"]["train_loss"][0]) and np.isfinite(rep["history"]["val_loss"][0])
+    assert np.isfinite(rep["evaluation"]["test_loss"]) and "ccc_overall" in rep["evaluation"]
+    assert rep["sample_predictions"]["nig_keys"] == ["valence_mu", "valence_nu"]
+    ck = torch.load(tmp_path / exp[0] / "models" / "final_model.pt", map_location="cpu", weights_only=False)
+    from mmdeer import stackb
+    m = stackb.CompleteDEERModel()
+    m.load_state_dict(ck["model_state_dict"])
+
+
 def test_fused_adamw_matches_torch_adamw_with_clipping():
     """optim.FusedAdamW (mmdeer_adamw_step) against clip_grad_norm_ + torch.optim.AdamW on the same gradients, three
     steps, two learning-rate groups; and the packed weights it leaves behind drive the next forward."""

@@ -244,3 +244,39 @@ def test_stackb_single_key_attention_is_two_linears(golden_dir):
     full = O._stackb_mha(P, "attention_module.cross_attention", q, x, x)
     short = O._lin(O._lin(x, P, "attention_module.cross_attention.value_proj"), P, "attention_module.cross_attention.output_proj")
     assert torch.equal(full, short)
+
+
+def stackb_oracle_gradients(O, P, batch):
+    """MultiTaskDEERLoss gradients of the oracle's Stack B (dropout sites open), by autograd.  Shared with the GPU tests."""
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    o = O.stackb_forward(Pg, *(torch.from_numpy(batch[k]) for k in ("audio", "video", "text")))
+    pred = {k: v.unsqueeze(1) for k, v in o.items() if k.split("_")[-1] in ("mu", "nu", "alpha", "beta") and v.dim() == 1}
+    loss = O.multitask_loss(pred, torch.from_numpy(batch["targets"]))
+    loss["total_loss"].backward()
+    return loss["total_loss"].detach(), {k: v.grad for k, v in Pg.items()}
+
+
+def check_gradient_digests(g, grads, rtol, atol_frac):
+    """`grads` against the digests of tests/golden/stackb_B9.npz (sum, l2 norm, 256 evenly spaced elements per parameter)."""
+    names = [k[len("gradnorm."):] for k in g if k.startswith("gradnorm.")]
+    assert len(names) == 112          # every parameter but the calibration layer's (query / key projections: exact zeros)
+    for n in names:
+        v = grads[n].detach().double().cpu().reshape(-1)
+        norm = float(g["gradnorm." + n])
+        assert float(v.norm()) == pytest.approx(norm, rel=rtol, abs=1e-12), n
+        idx = torch.linspace(0, v.numel() - 1, min(256, v.numel())).round().long()
+        scale = max(float(np.abs(g["gradsample." + n]).max()), norm / max(v.numel(), 1) ** 0.5)
+        np.testing.assert_allclose(v[idx].numpy(), g["gradsample." + n], rtol=rtol, atol=atol_frac * scale, err_msg=n)
+        assert float(v.sum()) == pytest.approx(float(g["gradsum." + n]), rel=rtol, abs=atol_frac * norm * max(v.numel(), 1) ** 0.5), n
+    for k in g:
+        if k.startswith("gradnone."):
+            assert grads.get(k[len("gradnone."):]) is None, k
+
+
+def test_stackb_gradients(golden_dir):
+    """Backward of complete_project.CompleteDEERModel under MultiTaskDEERLoss, captured from the reference in eval mode
+    (SURVEY 8f-1 training): the oracle's autograd reproduces loss and every parameter gradient digest."""
+    g = _load(golden_dir, "stackb_B9.npz")
+    loss, grads = stackb_oracle_gradients(O, _stackb_params(golden_dir), synth.make_batch(9, seed=78))
+    assert float(loss) == pytest.approx(float(g["grad.total_loss"]), rel=1e-5)
+    check_gradient_digests(g, grads, rtol=2e-4, atol_frac=2e-5)

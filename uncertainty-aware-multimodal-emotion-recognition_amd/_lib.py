@@ -92,6 +92,19 @@ class StackBAttnArgs(C.Structure):
     ]
 
 
+class StackBAttnTrainArgs(C.Structure):
+    _fields_ = [
+        ("h2", c_void_p), ("pre", c_void_p), ("self_out", c_void_p), ("cross_out", c_void_p),
+        ("est_w3", c_void_p), ("est_b3", c_void_p), ("wn_w1_unc", c_void_p), ("wn_w2", c_void_p), ("wn_b2", c_void_p),
+        ("out_av", c_void_p), ("out_text", c_void_p), ("r", c_void_p), ("weights4", c_void_p), ("unc4", c_void_p),
+        ("d_av", c_void_p), ("d_text", c_void_p), ("d_self", c_void_p), ("d_cross", c_void_p), ("d_pre", c_void_p),
+        ("d_logits8", c_void_p), ("d_z8", c_void_p), ("d_h2", c_void_p),
+        ("ld_w1_unc", c_int), ("ld_av", c_int), ("ld_text", c_int), ("B", c_int), ("act_f32", c_int),
+        ("training", c_int), ("drop_site", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
+        ("stream", c_void_p),
+    ]
+
+
 class StackBWeights(C.Structure):
     _fields_ = [
         ("audio_dim", c_int), ("video_dim", c_int), ("text_dim", c_int), ("encoder_layers", c_int), ("audio_ld", c_int),
@@ -165,6 +178,11 @@ SYMBOLS = [
     ("mmdeer_stackb_attn_mix", c_int, [C.POINTER(StackBAttnArgs)]),
     ("mmdeer_stackb_gate_mix", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_stackb_head", c_int, [c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
+    ("mmdeer_stackb_attn_mix_train_fwd", c_int, [C.POINTER(StackBAttnTrainArgs)]),
+    ("mmdeer_stackb_attn_mix_bwd", c_int, [C.POINTER(StackBAttnTrainArgs)]),
+    ("mmdeer_stackb_gate_mix_bwd", c_int, [c_void_p, c_int] * 7 + [c_int, c_int, c_int, c_void_p]),
+    ("mmdeer_stackb_head_bwd", c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    ("mmdeer_add_masked", c_int, [c_void_p, c_int] * 4 + [c_float, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_stackb_workspace_bytes", c_size_t, [c_int, c_int, c_int]),
     ("mmdeer_stackb_forward", c_int, [C.POINTER(StackBForwardArgs)]),
     ("mmdeer_comm_unique_id", c_int, [c_void_p]),

@@ -1,4 +1,5 @@
-"""Stack B: ``CompleteDEERModel`` of the reference's src/models/complete_project.py, inference forward.
+"""Stack B: ``CompleteDEERModel`` of the reference's src/models/complete_project.py -- inference forward as
+one library call, training forward (dropout) + backward as operator sequences (``stackb_train.py``).
 
 Same constructor protocol (``ModelConfig``), ``state_dict()`` keys and shapes, output dictionary and
 ``get_predictions_and_uncertainties`` as the reference class (complete_project.py:33-56, 462-602), so a reference
@@ -19,9 +20,12 @@ How the batch is laid out (csrc/stackb.hip carves the intermediates out of one w
     modality-major (3, B, 256) hidden state plus one residual-LayerNorm launch;
   * the first layer of the three prediction heads is one N = 768 GEMM, the other two are batched over the heads.
 
-Training (dropout, backward) is not built for this stack: the reference trains Stack C, which is the path
-``mmdeer.model.MultimodalDEER`` accelerates end to end.  ``forward`` raises in training mode instead of silently
-skipping dropout.
+Training: in ``.train()`` mode ``forward`` runs ``stackb_train.forward_train`` (every ``nn.Dropout`` site of the reference
+as counter-hash dropout in the GEMM epilogues) and returns (mu, nu, alpha, beta) attached to an autograd node whose
+backward is ``stackb_train.backward`` -- so ``model.compute_loss(model(a, v, t), y)['total_loss'].backward()`` fills
+``.grad`` of every parameter on the path, and ``torch.optim.AdamW`` (complete_project.py:640-650 builds exactly that)
+steps them.  The uncertainty planes (aleatoric / epistemic / total / calibrated) are returned as values: no loss of
+the reference reads them, and ``calibration_layer`` therefore never receives a gradient there either.
 """
 from __future__ import annotations
 
@@ -55,6 +59,7 @@ class ModelConfig:
     learning_rate: float = 1e-4
     weight_decay: float = 1e-5
     gradient_clip: float = 1.0
+    dropout_seed: int = 0        # (not a reference field) seed of the counter-hash dropout; give each data-parallel rank its own
 
 
 # ---- parameter containers: the module tree (and therefore every state_dict key) of the reference classes.  The
@@ -142,6 +147,7 @@ class CompleteDEERModel(nn.Module):
         self.calibration_layer = _Calibration(config.emotion_dims)
         self._initialize_weights()
         self._packed = None
+        self._train_step = 0          # dropout counter: one tick per training forward
 
     def _initialize_weights(self) -> None:
         """Xavier-uniform Linear weights, zero biases, unit LayerNorm (complete_project.py:503-513)."""
@@ -219,18 +225,68 @@ class CompleteDEERModel(nn.Module):
         self._packed = {"key": key, "keep": keep, "struct": sw}
         return self._packed
 
-    @torch.no_grad()
     def forward(self, audio_features: torch.Tensor, video_features: torch.Tensor, text_features: torch.Tensor) -> Dict[str, torch.Tensor]:
         if self.training:
-            raise NotImplementedError("mmdeer.stackb.CompleteDEERModel is inference-only: call .eval() first "
-                                      "(training runs on mmdeer.model.MultimodalDEER, the stack the reference trains)")
+            return self.forward_train(audio_features, video_features, text_features, dropout=True)
+        with torch.no_grad():
+            return self._forward_eval(audio_features, video_features, text_features)
+
+    def _check_inputs(self, xs):
         cfg = self.config
-        xs = (audio_features, video_features, text_features)
         ops._check_dev(*xs)
         B = xs[0].shape[0]
         for x, k in zip(xs, (cfg.audio_dim, cfg.video_dim, cfg.text_dim)):
             if x.dim() != 2 or x.shape != (B, k):
                 raise ValueError(f"expected features of shape ({B}, {k}), got {tuple(x.shape)}")
+        return B
+
+    def forward_train(self, audio_features: torch.Tensor, video_features: torch.Tensor, text_features: torch.Tensor,
+                      dropout: bool = True) -> Dict[str, torch.Tensor]:
+        """Differentiable forward (what ``forward`` runs in ``.train()`` mode).  ``dropout=False`` keeps every site open --
+        the reference in ``.eval()`` mode with gradients, which is how the golden gradients were taken."""
+        from . import stackb_train
+        xs = (audio_features, video_features, text_features)
+        B = self._check_inputs(xs)
+        if B == 0:
+            raise ValueError("training forward on an empty batch")
+        xs = [x.detach().float().contiguous() for x in xs]
+        drop = None
+        if dropout:
+            drop = (self.config.dropout, int(self.config.dropout_seed), self._train_step)
+            self._train_step += 1
+        names = [n for n, _ in self.named_parameters()]
+        core, tape = _StackBFn.apply(self, xs, drop, names, *[p for _, p in self.named_parameters()])
+        planes = tape["planes"]
+        out: Dict[str, torch.Tensor] = {}
+        for d, name in enumerate(DIM_NAMES):
+            for k, key in enumerate(HEAD_KEYS):
+                out[f"{name}_{key}"] = core[k, :, d] if k < 4 else planes[k, :, d]
+        out["mu_all"], out["uncertainty_all"], out["calibrated_uncertainty"] = core[0], planes[6], planes[7]
+        out["attention_weights"], out["modality_uncertainties"] = tape["w4"][:, :3], tape["u4"][:, :3]
+        out["fused_features"] = tape["fused32"]
+        return out
+
+    def compute_loss(self, predictions: Dict[str, torch.Tensor], targets: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """The trainer hook (training.py:210): ``MultiTaskDEERLoss`` defaults on this model's ``{dim}_{mu|nu|alpha|beta}``
+        keys (src/utils/losses.py:286-291 reads exactly those)."""
+        from .model import multitask_deer_loss
+        return multitask_deer_loss(predictions, targets)
+
+    def train_step(self, audio, video, text, targets) -> Dict[str, torch.Tensor]:
+        """``compute_loss(model(a, v, t), y)['total_loss'].backward()`` -- gradients accumulate into ``.grad``."""
+        was = self.training
+        self.train()
+        try:
+            loss = self.compute_loss(self(audio, video, text), targets)
+            loss["total_loss"].backward()
+        finally:
+            self.train(was)
+        return loss
+
+    def _forward_eval(self, audio_features, video_features, text_features) -> Dict[str, torch.Tensor]:
+        cfg = self.config
+        xs = (audio_features, video_features, text_features)
+        B = self._check_inputs(xs)
         xs = [x.detach().float().contiguous() for x in xs]
         dev = xs[0].device
         P = self._pack()
@@ -289,6 +345,39 @@ class CompleteDEERModel(nn.Module):
     def get_predictions_and_uncertainties(self, outputs: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
         """(mu_all, calibrated_uncertainty or uncertainty_all) -- complete_project.py:591-602."""
         return outputs["mu_all"], outputs.get("calibrated_uncertainty", outputs["uncertainty_all"])
+
+
+class _StackBFn(torch.autograd.Function):
+    """(mu, nu, alpha, beta) of a training forward; backward = stackb_train.backward.  The parameters are inputs so that
+    autograd accumulates their gradients; the tape (saved activations) rides on ctx."""
+
+    @staticmethod
+    def forward(ctx, model, xs, drop, names, *params):
+        from . import stackb_train
+        tape = stackb_train.forward_train(model, xs, drop)
+        ctx.model, ctx.tape, ctx.names = model, tape, names
+        ctx.set_materialize_grads(False)
+        core = tape["planes"][:4].clone()
+        ctx.mark_non_differentiable()
+        return core, _Tape(tape)
+
+    @staticmethod
+    def backward(ctx, g_core, _g_tape):
+        from . import stackb_train
+        if g_core is None:
+            return (None,) * (4 + len(ctx.names))
+        G = stackb_train.backward(ctx.model, ctx.tape, g_core.float().contiguous())
+        params = dict(ctx.model.named_parameters())
+        grads = []
+        for n in ctx.names:
+            g = G.get(n)
+            grads.append(None if g is None else g.to(params[n].dtype).view_as(params[n]))
+        ctx.tape = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class _Tape(dict):
+    """The forward's saved tensors as a (non-tensor) second output of the autograd node."""
 
 
 def create_complete_deer_model(config: Optional[ModelConfig] = None, compute_dtype: str = "fp32") -> CompleteDEERModel:

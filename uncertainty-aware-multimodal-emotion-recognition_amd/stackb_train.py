@@ -1,0 +1,393 @@
+"""Stack B training path: forward with dropout and backward of ``complete_project.CompleteDEERModel``
+(reference src/models/complete_project.py:462-602) as a sequence of C-ABI operator calls.
+
+This file is host logic only -- it owns buffers and the ORDER of the launches; every number is produced by
+``libmmdeer_hip.so``: the Linear layers by ``mmdeer_gemm`` (forward with bias / ReLU / hash dropout in the epilogue;
+``dX = dY W`` with the ``(Y > 0) / (1 - p)`` mask of the layer below in the epilogue; ``dW = dY^T X`` with the bias gradient
+from the same launch), LayerNorm by ``mmdeer_layernorm_fwd`` / ``_bwd`` (the backward folds the ReLU + dropout mask of the
+``Linear-ReLU-Dropout-LayerNorm`` blocks, complete_project.py:65-70, 315-333), and the row operators of
+``csrc/stackb_train.hip`` (attention tail forward / backward, gate mix backward, softplus backward, masked adds).
+
+Dropout sites (all ``nn.Dropout``; masks are the library's counter hash keyed by (seed, step, site, row, column), so the
+backward regenerates them): ResidualBlock (:68), MultiHeadAttention attention weights (:141, 172 -- one decision per (row,
+head) because every softmax is over a single key), UncertaintyEstimator (:186, p = 0.2 whatever the config says),
+weight_network (:237), the two fusion stages (:318, 328) and the prediction heads (:379, 382).
+
+Layout conventions are those of the inference executor (csrc/stackb.hip): encoder outputs in column blocks of one (B, 768)
+matrix whose (3B, 256) reading is the row set of the shared-weight attention layers; heads stacked along N.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+
+ENC, FUS, HID = 256, 512, 256
+SITE_RES, SITE_ATTN_S, SITE_ATTN_C, SITE_EST, SITE_WN, SITE_AV, SITE_TRI, SITE_H0, SITE_H3 = 32, 64, 65, 66, 67, 68, 69, 70, 71     # H3: 71..73
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class Exec:
+    """One training step's launches.  ``drop``: (p_config, seed, step) or None (no dropout anywhere)."""
+
+    def __init__(self, model, drop):
+        self.m = model
+        self.f32 = int(model.compute_dtype == "fp32")
+        self.dt = torch.float32 if self.f32 else torch.bfloat16
+        self.drop = drop
+        self.lib = _lib.load()
+        self.s = _lib.current_stream()
+
+    # ---- operator wrappers ------------------------------------------------------------------------------------------
+    def gemm(self, A, W, Cm, M, N, K, lda, ldw, ldc, *, bias=None, relu=0, ta=0, tw=0, Y=None, ldy=0, mask_scale=1.0, bias_grad=None,
+             drop_site=-1, drop_shift=0, regen_site=-1, p=0.0):
+        if M == 0 or N == 0:
+            return Cm
+        a = _lib.GemmArgs()
+        a.A, a.W, a.C = A.data_ptr(), W.data_ptr(), Cm.data_ptr()
+        a.bias, a.bias_grad, a.Y = _ptr(bias), _ptr(bias_grad), _ptr(Y)
+        a.M, a.N, a.K, a.lda, a.ldw, a.ldc, a.ldy = M, N, K, lda, ldw, ldc, ldy
+        a.a_f32, a.w_f32, a.c_f32 = int(A.dtype == torch.float32), int(W.dtype == torch.float32), int(Cm.dtype == torch.float32)
+        a.y_f32 = int(Y is not None and Y.dtype == torch.float32)
+        a.trans_a, a.trans_w, a.relu = ta, tw, relu
+        a.compute_f32, a.tile = self.f32, -1
+        a.drop_site, a.drop_shift, a.regen_site = drop_site, drop_shift, regen_site
+        a.mask_scale = mask_scale
+        if self.drop is not None:
+            a.dropout_p, a.seed, a.offset = p, self.drop[1], self.drop[2]
+        a.stream = self.s
+        _lib.check(self.lib.mmdeer_gemm(C.byref(a)))
+        return Cm
+
+    def p_of(self, p):          # effective dropout probability of a site
+        return float(p) if self.drop is not None and p > 0 else 0.0
+
+    def scale_of(self, p):
+        p = self.p_of(p)
+        return 1.0 / (1.0 - p) if p > 0 else 1.0
+
+    def linear(self, x, ldx, w, b, out, ldo, M, relu=0, site=-1, p=0.0, shift=0):
+        """out = drop?(relu?(x w^T + b)); w: (N, K) parameter in the compute dtype (packed by the caller)."""
+        N, K = w.shape
+        p = self.p_of(p)
+        return self.gemm(x, w, out, M, N, K, ldx, w.stride(0), ldo, bias=b, relu=relu, drop_site=site if p > 0 else -1, drop_shift=shift, p=p)
+
+    def dx(self, dy, ldy_, w, out, ldo, M, mask=None, ldm=0, mask_scale=1.0, regen_site=-1, shift=0, p=0.0):
+        """out = (dy w) [* ((mask > 0) * mask_scale)] [* regenerated dropout factor]; w: (N, K) as stored."""
+        N, K = w.shape
+        p = self.p_of(p)
+        return self.gemm(dy, w, out, M, K, N, ldy_, w.stride(0), ldo, tw=1, Y=mask, ldy=ldm, mask_scale=mask_scale,
+                         regen_site=regen_site if p > 0 else -1, drop_shift=shift, p=p)
+
+    def dw(self, dy, ldy_, x, ldx, gw, gb, M, N, K):
+        """gw (N, K) fp32 = dy^T x, gb (N,) = column sums of dy; dy: (M, N) view, x: (M, K) view."""
+        return self.gemm(dy, x, gw, N, K, M, ldy_, ldx, gw.stride(0), ta=1, tw=1, bias_grad=gb)
+
+    def ln_fwd(self, y, gamma, beta):
+        M, N = y.shape
+        out = torch.empty_like(y)
+        mean = torch.empty(M, dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+        if M:
+            _lib.check(self.lib.mmdeer_layernorm_fwd(y.data_ptr(), out.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                                     beta.data_ptr(), M, N, self.f32, self.s))
+        return out, mean, rstd
+
+    def ln_bwd(self, dout, y, mean, rstd, gamma, ggamma, gbeta, mask_scale):
+        """dz = (y > 0) * mask_scale * LayerNorm'(dout); ggamma / gbeta fp32 (N,)."""
+        M, N = y.shape
+        dz = torch.empty_like(y)
+        if M:
+            part = torch.empty(self.lib.mmdeer_layernorm_bwd_nparts(M) * 2 * N, dtype=torch.float32, device=y.device)
+            _lib.check(self.lib.mmdeer_layernorm_bwd(dout.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                                     dz.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(), part.data_ptr(), M, N, self.f32,
+                                                     mask_scale, self.s))
+        return dz
+
+    def add(self, out, x, y=None, mask=None, scale=1.0):
+        M, N = x.shape
+        _lib.check(self.lib.mmdeer_add_masked(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
+                                              _ptr(mask), mask.stride(0) if mask is not None else 0, scale, M, N, self.f32, self.s))
+        return out
+
+
+def _params(model, dt):
+    """Compute-dtype copies of the matrices (a cast per step: torch here is memory plumbing, the casts carry no arithmetic
+    of the path) and fp32 vectors, keyed like the module tree."""
+    W = lambda t: t.detach().to(dt).contiguous()
+    V = lambda t: t.detach().float().contiguous()
+    P = {"enc": []}
+    cfg = model.config
+    for e in (model.audio_encoder, model.video_encoder, model.text_encoder):
+        d = {"w0": e.input_projection[0].weight, "b0": V(e.input_projection[0].bias), "g0": V(e.input_projection[2].weight),
+             "be0": V(e.input_projection[2].bias), "res": [], "wo": W(e.output_projection.weight), "bo": V(e.output_projection.bias)}
+        d["w0"] = W(d["w0"])
+        for blk in e.encoder_layers:
+            d["res"].append({"w": W(blk.layers[0].weight), "b": V(blk.layers[0].bias), "g": V(blk.layers[3].weight), "be": V(blk.layers[3].bias)})
+        P["enc"].append(d)
+    att = model.attention_module
+    sa, ca, est, wn = att.self_attention, att.cross_attention, att.uncertainty_estimator.estimator, att.weight_network
+    P["wv"] = W(torch.cat([sa.value_proj.weight, ca.value_proj.weight], 0))                # (512, 256)
+    P["bv"] = V(torch.cat([sa.value_proj.bias, ca.value_proj.bias], 0))
+    P["wos"], P["bos"], P["woc"], P["boc"] = W(sa.output_proj.weight), V(sa.output_proj.bias), W(ca.output_proj.weight), V(ca.output_proj.bias)
+    P["we1"], P["be1"], P["we2"], P["be2"] = W(est[0].weight), V(est[0].bias), W(est[3].weight), V(est[3].bias)
+    P["we3"], P["be3"] = V(est[5].weight).reshape(-1), V(est[5].bias)
+    D3 = 3 * cfg.encoder_dim
+    P["wn1"], P["bn1"] = W(wn[0].weight[:, :D3]), V(wn[0].bias)
+    P["wn1u"] = V(wn[0].weight[:, D3:])                                                     # (256, 3) fp32
+    P["wn2"], P["bn2"] = V(wn[3].weight), V(wn[3].bias)
+    fu = model.fusion_module
+    for name, seq in (("av", fu.av_fusion), ("tri", fu.trimodal_fusion)):
+        P[name] = {"w0": W(seq[0].weight), "b0": V(seq[0].bias), "g": V(seq[3].weight), "be": V(seq[3].bias), "w4": W(seq[4].weight), "b4": V(seq[4].bias)}
+    P["wg"], P["bg"] = W(fu.fusion_gate[0].weight), V(fu.fusion_gate[0].bias)
+    nets = [model.prediction_heads[n].evidence_network for n in ("valence", "arousal", "dominance")]
+    P["wh0"], P["bh0"] = W(torch.cat([n[0].weight for n in nets], 0)), V(torch.cat([n[0].bias for n in nets], 0))      # (768, 512)
+    P["wh3"], P["bh3"] = [W(n[3].weight) for n in nets], [V(n[3].bias) for n in nets]
+    P["wh6"], P["bh6"] = [W(n[6].weight) for n in nets], [V(n[6].bias) for n in nets]
+    P["wh6p"] = [torch.nn.functional.pad(w, (0, 0, 0, 4)) for w in P["wh6"]]              # (8, 128): rows 4..7 zero (8-column gradient blocks)
+    return P
+
+
+def forward_train(model, xs: List[torch.Tensor], drop) -> Dict:
+    """Forward with every intermediate the backward needs kept on a tape.  Returns the tape (incl. planes (8, B, 3))."""
+    ex = Exec(model, drop)
+    dt, f32, dev = ex.dt, ex.f32, xs[0].device
+    cfg = model.config
+    pc = cfg.dropout
+    B = xs[0].shape[0]
+    P = _params(model, dt)
+    new = lambda *s, d=None: torch.empty(*s, dtype=d or dt, device=dev)
+    T: Dict = {"P": P, "B": B, "xs": xs, "ex": ex}
+    E = new(B, 3 * ENC)
+    T["enc"] = []
+    for m, (x, pe) in enumerate(zip(xs, P["enc"])):
+        t = {}
+        y0 = new(B, ENC)
+        # inputs are read as fp32 (the loader's dtype) and converted while staging; the 84-wide bf16 audio weight rows are
+        # 8-byte aligned, which the GEMM's narrow-vector operand mode takes
+        w0 = pe["w0"]
+        t["xin"] = x
+        ex.gemm(x, w0, y0, B, ENC, x.shape[1], x.stride(0), w0.stride(0), ENC, bias=pe["b0"], relu=1)
+        t["y0"] = y0
+        h, t["m0"], t["r0"] = ex.ln_fwd(y0, pe["g0"], pe["be0"])
+        t["h"], t["y"], t["st"] = [h], [], []
+        for l, pr in enumerate(pe["res"]):
+            y = new(B, ENC)
+            ex.linear(h, ENC, pr["w"], pr["b"], y, ENC, B, relu=1, site=SITE_RES + 3 * l + m, p=pc)
+            ln, mean, rstd = ex.ln_fwd(y, pr["g"], pr["be"])
+            h = ex.add(new(B, ENC), h, ln)                                             # x + LayerNorm(...)      (:73)
+            t["y"].append(y); t["st"].append((mean, rstd)); t["h"].append(h)
+        ex.linear(h, ENC, pe["wo"], pe["bo"], E[:, m * ENC:(m + 1) * ENC], 3 * ENC, B)
+        T["enc"].append(t)
+    T["E"] = E
+    E3 = E.view(3 * B, ENC)
+    # attention: every softmax is over ONE key, so a block is output_proj(drop(value_proj(x))) with one dropout decision per
+    # (row, 32-column head) (:141, 172); the two blocks write the halves of one (3B, 512) matrix
+    VV = new(3 * B, 2 * ENC)
+    ex.linear(E3, ENC, P["wv"][:ENC], P["bv"][:ENC], VV[:, :ENC], 2 * ENC, 3 * B, site=SITE_ATTN_S, p=pc, shift=5)
+    ex.linear(E3, ENC, P["wv"][ENC:], P["bv"][ENC:], VV[:, ENC:], 2 * ENC, 3 * B, site=SITE_ATTN_C, p=pc, shift=5)
+    S, X = new(3 * B, ENC), new(3 * B, ENC)
+    ex.linear(VV[:, :ENC], 2 * ENC, P["wos"], P["bos"], S, ENC, 3 * B)
+    ex.linear(VV[:, ENC:], 2 * ENC, P["woc"], P["boc"], X, ENC, 3 * B)
+    H1, H2 = new(3 * B, ENC // 2), new(3 * B, ENC // 4)
+    ex.linear(E3, ENC, P["we1"], P["be1"], H1, ENC // 2, 3 * B, relu=1, site=SITE_EST, p=0.2)       # (:186): p = 0.2 always
+    ex.linear(H1, ENC // 2, P["we2"], P["be2"], H2, ENC // 4, 3 * B, relu=1)
+    pre = new(B, ENC)
+    ex.linear(S.view(B, 3 * ENC), 3 * ENC, P["wn1"], P["bn1"], pre, ENC, B)
+    AV, Tt = new(B, 2 * ENC), new(B, FUS + ENC)
+    r, w4, u4 = new(B, ENC), new(B, 4, d=torch.float32), new(B, 4, d=torch.float32)
+    a = _lib.StackBAttnTrainArgs()
+    a.h2, a.pre, a.self_out, a.cross_out = H2.data_ptr(), pre.data_ptr(), S.data_ptr(), X.data_ptr()
+    a.est_w3, a.est_b3, a.wn_w1_unc, a.wn_w2, a.wn_b2 = (P[k].data_ptr() for k in ("we3", "be3", "wn1u", "wn2", "bn2"))
+    a.out_av, a.out_text = AV.data_ptr(), Tt[:, FUS:].data_ptr()
+    a.r, a.weights4, a.unc4 = r.data_ptr(), w4.data_ptr(), u4.data_ptr()
+    a.ld_w1_unc, a.ld_av, a.ld_text, a.B, a.act_f32 = 3, 2 * ENC, FUS + ENC, B, f32
+    a.training, a.drop_site, a.dropout_p = int(drop is not None), SITE_WN, ex.p_of(pc)
+    if drop is not None:
+        a.seed, a.offset = drop[1], drop[2]
+    a.stream = ex.s
+    if B:
+        _lib.check(ex.lib.mmdeer_stackb_attn_mix_train_fwd(C.byref(a)))
+    T.update(VV=VV, S=S, X=X, H1=H1, H2=H2, pre=pre, AV=AV, T=Tt, r=r, w4=w4, u4=u4, attn_args=a)
+    # fusion
+    def stage(inp, ldi, K, pp, site, out, ldo):
+        a1 = new(B, FUS)
+        ex.gemm(inp, pp["w0"], a1, B, FUS, K, ldi, pp["w0"].stride(0), FUS, bias=pp["b0"], relu=1,
+                drop_site=site if ex.p_of(pc) > 0 else -1, p=ex.p_of(pc))
+        n1, mean, rstd = ex.ln_fwd(a1, pp["g"], pp["be"])
+        ex.linear(n1, FUS, pp["w4"], pp["b4"], out, ldo, B, relu=1)
+        return a1, n1, mean, rstd
+    T["av"] = stage(AV, 2 * ENC, 2 * ENC, P["av"], SITE_AV, Tt[:, :FUS], FUS + ENC)
+    R2 = new(B, FUS)
+    T["tri"] = stage(Tt, FUS + ENC, FUS + ENC, P["tri"], SITE_TRI, R2, FUS)
+    G = new(B, FUS)
+    ex.linear(Tt, FUS + ENC, P["wg"], P["bg"], G, FUS, B)
+    fused = new(B, FUS)
+    fused32 = new(B, FUS, d=torch.float32)
+    if B:
+        _lib.check(ex.lib.mmdeer_stackb_gate_mix(G.data_ptr(), FUS, R2.data_ptr(), FUS, Tt.data_ptr(), FUS + ENC, fused.data_ptr(), FUS,
+                                                 fused32.data_ptr(), B, FUS, f32, ex.s))
+    T.update(R2=R2, G=G, fused=fused, fused32=fused32)
+    # heads
+    H0, H3 = new(B, 3 * HID), new(B, 3 * HID // 2)
+    ev = new(B, 12, d=torch.float32)
+    ex.linear(fused, FUS, P["wh0"], P["bh0"], H0, 3 * HID, B, relu=1, site=SITE_H0, p=pc)
+    for d in range(3):
+        ex.linear(H0[:, d * HID:(d + 1) * HID], 3 * HID, P["wh3"][d], P["bh3"][d], H3[:, d * 128:(d + 1) * 128], 3 * HID // 2, B, relu=1,
+                  site=SITE_H3 + d, p=pc)
+        ex.linear(H3[:, d * 128:(d + 1) * 128], 3 * HID // 2, P["wh6"][d], P["bh6"][d], ev[:, 4 * d:4 * d + 4], 12, B)
+    planes = new(8, B, 3, d=torch.float32)
+    cal = model.calibration_layer
+    cn = cal.calibration_network
+    cps = [t.detach().float().reshape(-1).contiguous() for t in (cal.temperature, cn[0].weight, cn[0].bias, cn[2].weight, cn[2].bias, cn[4].weight, cn[4].bias)]
+    if B:
+        _lib.check(ex.lib.mmdeer_stackb_head(ev.data_ptr(), 12, *[t.data_ptr() for t in cps], planes.data_ptr(), B, ex.s))
+    T.update(H0=H0, H3=H3, ev=ev, planes=planes, cal_keep=cps)
+    return T
+
+
+def backward(model, T: Dict, g4: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Gradients of every parameter on the path from d (mu, nu, alpha, beta) = g4 (4, B, 3) fp32.  Returns
+    {state_dict key: fp32 gradient}; the calibration layer (not on the path of mu / nu / alpha / beta) gets none."""
+    ex: Exec = T["ex"]
+    P, B, dt, f32 = T["P"], T["B"], ex.dt, ex.f32
+    cfg = model.config
+    pc = cfg.dropout
+    dev = g4.device
+    new = lambda *s, d=None: torch.empty(*s, dtype=d or dt, device=dev)
+    z32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+    G: Dict[str, torch.Tensor] = {}
+    sc = ex.scale_of(pc)
+
+    def grads(prefix, N, K):
+        G[prefix + ".weight"], G[prefix + ".bias"] = z32(N, K), z32(N)
+        return G[prefix + ".weight"], G[prefix + ".bias"]
+
+    # ---- heads
+    dev_ = new(B, 24)                                                   # head d in columns 8 d .. 8 d + 3, zeros in 8 d + 4 .. 8 d + 7
+    _lib.check(ex.lib.mmdeer_stackb_head_bwd(T["ev"].data_ptr(), 12, g4.contiguous().data_ptr(), dev_.data_ptr(), 24, B, f32, ex.s))
+    H0, H3 = T["H0"], T["H3"]
+    dH3, dH0 = new(B, 3 * HID // 2), new(B, 3 * HID)
+    names = ("valence", "arousal", "dominance")
+    for d, nm in enumerate(names):
+        pre = f"prediction_heads.{nm}.evidence_network"
+        h3, dh3, ev_d = H3[:, d * 128:(d + 1) * 128], dH3[:, d * 128:(d + 1) * 128], dev_[:, 8 * d:8 * d + 8]
+        ex.dx(ev_d, 24, P["wh6p"][d], dh3, 3 * HID // 2, B, mask=h3, ldm=3 * HID // 2, mask_scale=sc)
+        w8, b8 = z32(8, 128), z32(8)
+        ex.dw(ev_d, 24, h3, 3 * HID // 2, w8, b8, B, 8, 128)
+        G[pre + ".6.weight"], G[pre + ".6.bias"] = w8[:4], b8[:4]
+        h0, dh0 = H0[:, d * HID:(d + 1) * HID], dH0[:, d * HID:(d + 1) * HID]
+        ex.dx(dh3, 3 * HID // 2, P["wh3"][d], dh0, 3 * HID, B, mask=h0, ldm=3 * HID, mask_scale=sc)
+        ex.dw(dh3, 3 * HID // 2, h0, 3 * HID, *grads(pre + ".3", 128, HID), B, 128, HID)
+    dfused = new(B, FUS)
+    ex.dx(dH0, 3 * HID, P["wh0"], dfused, FUS, B)
+    gw0, gb0 = z32(3 * HID, FUS), z32(3 * HID)
+    ex.dw(dH0, 3 * HID, T["fused"], FUS, gw0, gb0, B, 3 * HID, FUS)
+    for d, nm in enumerate(names):
+        G[f"prediction_heads.{nm}.evidence_network.0.weight"] = gw0[d * HID:(d + 1) * HID]
+        G[f"prediction_heads.{nm}.evidence_network.0.bias"] = gb0[d * HID:(d + 1) * HID]
+    # ---- fusion: gate mix, trimodal stage, gate, audio-visual stage
+    Tt, R2, Gt = T["T"], T["R2"], T["G"]
+    dG, dZ4, dav_a = new(B, FUS), new(B, FUS), new(B, FUS)
+    _lib.check(ex.lib.mmdeer_stackb_gate_mix_bwd(dfused.data_ptr(), FUS, Gt.data_ptr(), FUS, R2.data_ptr(), FUS, Tt.data_ptr(), FUS + ENC,
+                                                 dG.data_ptr(), FUS, dZ4.data_ptr(), FUS, dav_a.data_ptr(), FUS, B, FUS, f32, ex.s))
+
+    def stage_bwd(name, dz4, st, inp, ldi, K):
+        a1, n1, mean, rstd = st
+        pp = P[name]
+        pre = f"fusion_module.{'av_fusion' if name == 'av' else 'trimodal_fusion'}"
+        dn1 = ex.dx(dz4, FUS, pp["w4"], new(B, FUS), FUS, B)
+        ex.dw(dz4, FUS, n1, FUS, *grads(pre + ".4", FUS, FUS), B, FUS, FUS)
+        G[pre + ".3.weight"], G[pre + ".3.bias"] = z32(FUS), z32(FUS)
+        dz0 = ex.ln_bwd(dn1, a1, mean, rstd, pp["g"], G[pre + ".3.weight"], G[pre + ".3.bias"], sc)
+        ex.dw(dz0, FUS, inp, ldi, *grads(pre + ".0", FUS, K), B, FUS, K)
+        return dz0
+
+    dz0_tri = stage_bwd("tri", dZ4, T["tri"], Tt, FUS + ENC, FUS + ENC)
+    dT = ex.dx(dz0_tri, FUS, P["tri"]["w0"], new(B, FUS + ENC), FUS + ENC, B)
+    dT2 = ex.dx(dG, FUS, P["wg"], new(B, FUS + ENC), FUS + ENC, B)
+    ex.dw(dG, FUS, Tt, FUS + ENC, *grads("fusion_module.fusion_gate.0", FUS, FUS + ENC), B, FUS, FUS + ENC)
+    dtext = ex.add(new(B, ENC), dT[:, FUS:], dT2[:, FUS:])
+    # d av_fused: through the trimodal input, the gate input and the gate mix; av_fused = relu(.)
+    tmp = ex.add(new(B, FUS), dT[:, :FUS], dT2[:, :FUS])
+    dz4_av = ex.add(new(B, FUS), tmp, dav_a, mask=Tt[:, :FUS], scale=1.0)
+    dz0_av = stage_bwd("av", dz4_av, T["av"], T["AV"], 2 * ENC, 2 * ENC)
+    dAV = ex.dx(dz0_av, FUS, P["av"]["w0"], new(B, 2 * ENC), 2 * ENC, B)
+    # ---- attention tail
+    a = T["attn_args"]
+    dS, dX, dpre = new(3 * B, ENC), new(3 * B, ENC), new(B, ENC)
+    dlog8, dz8e, dh2 = new(B, 8), new(3 * B, 8), new(3 * B, ENC // 4)
+    a.d_av, a.d_text = dAV.data_ptr(), dtext.data_ptr()
+    a.ld_text = ENC                                  # the text gradient is a dense (B, 256) matrix here
+    a.d_self, a.d_cross, a.d_pre = dS.data_ptr(), dX.data_ptr(), dpre.data_ptr()
+    a.d_logits8, a.d_z8, a.d_h2 = dlog8.data_ptr(), dz8e.data_ptr(), dh2.data_ptr()
+    if B:
+        _lib.check(ex.lib.mmdeer_stackb_attn_mix_bwd(C.byref(a)))
+    att = "attention_module"
+    t4w, t4b = z32(8, ENC), z32(8)
+    ex.dw(dlog8, 8, T["r"], ENC, t4w, t4b, B, 8, ENC)                                      # weight_network.3 (3 x 256)
+    G[att + ".weight_network.3.weight"], G[att + ".weight_network.3.bias"] = t4w[:3], t4b[:3]
+    gwn = z32(ENC, 3 * ENC + 3)
+    G[att + ".weight_network.0.weight"], G[att + ".weight_network.0.bias"] = gwn, z32(ENC)
+    feat = z32(ENC, 3 * ENC)
+    ex.dw(dpre, ENC, T["S"].view(B, 3 * ENC), 3 * ENC, feat, G[att + ".weight_network.0.bias"], B, ENC, 3 * ENC)
+    unc = z32(ENC, 4)
+    if B >= 2:
+        ex.dw(dpre, ENC, T["u4"], 4, unc, None, B, ENC, 4)
+    else:           # a (1, 4) operand is below the GEMM's 8-element minimum: the same product over two rows, the second zero
+        d2, u2 = torch.zeros(2, ENC, dtype=dt, device=dev), z32(2, 4)
+        d2[:1].copy_(dpre); u2[:1].copy_(T["u4"])
+        ex.dw(d2, ENC, u2, 4, unc, None, 2, ENC, 4)
+    gwn[:, :3 * ENC].copy_(feat); gwn[:, 3 * ENC:].copy_(unc[:, :3])                       # (memory plumbing: two column blocks of one parameter)
+    dS_b = ex.dx(dpre, ENC, P["wn1"], new(B, 3 * ENC), 3 * ENC, B)
+    dS = ex.add(new(3 * B, ENC), dS, dS_b.view(3 * B, ENC))
+    # uncertainty estimator
+    est = att + ".uncertainty_estimator.estimator"
+    t4w2, t4b2 = z32(8, ENC // 4), z32(8)
+    ex.dw(dz8e, 8, T["H2"], ENC // 4, t4w2, t4b2, 3 * B, 8, ENC // 4)
+    G[est + ".5.weight"], G[est + ".5.bias"] = t4w2[:1], t4b2[:1]
+    dH1 = ex.dx(dh2, ENC // 4, P["we2"], new(3 * B, ENC // 2), ENC // 2, 3 * B, mask=T["H1"], ldm=ENC // 2, mask_scale=ex.scale_of(0.2))
+    ex.dw(dh2, ENC // 4, T["H1"], ENC // 2, *grads(est + ".3", ENC // 4, ENC // 2), 3 * B, ENC // 4, ENC // 2)
+    E3 = T["E"].view(3 * B, ENC)
+    dE_est = ex.dx(dH1, ENC // 2, P["we1"], new(3 * B, ENC), ENC, 3 * B)
+    ex.dw(dH1, ENC // 2, E3, ENC, *grads(est + ".0", ENC // 2, ENC), 3 * B, ENC // 2, ENC)
+    # the two attention blocks: output_proj, then the value projections (attention-dropout factor regenerated)
+    VV = T["VV"]
+    dVV = new(3 * B, 2 * ENC)
+    ex.dx(dS, ENC, P["wos"], dVV[:, :ENC], 2 * ENC, 3 * B, regen_site=SITE_ATTN_S, shift=5, p=pc)
+    ex.dx(dX, ENC, P["woc"], dVV[:, ENC:], 2 * ENC, 3 * B, regen_site=SITE_ATTN_C, shift=5, p=pc)
+    ex.dw(dS, ENC, VV[:, :ENC], 2 * ENC, *grads(att + ".self_attention.output_proj", ENC, ENC), 3 * B, ENC, ENC)
+    ex.dw(dX, ENC, VV[:, ENC:], 2 * ENC, *grads(att + ".cross_attention.output_proj", ENC, ENC), 3 * B, ENC, ENC)
+    gwv, gbv = z32(2 * ENC, ENC), z32(2 * ENC)
+    ex.dw(dVV, 2 * ENC, E3, ENC, gwv, gbv, 3 * B, 2 * ENC, ENC)
+    for i, blk in enumerate(("self_attention", "cross_attention")):
+        G[f"{att}.{blk}.value_proj.weight"], G[f"{att}.{blk}.value_proj.bias"] = gwv[i * ENC:(i + 1) * ENC], gbv[i * ENC:(i + 1) * ENC]
+        # one key per query: the softmax is the constant 1, so query / key projections get exact zeros (as autograd gives)
+        for q in ("query_proj", "key_proj"):
+            G[f"{att}.{blk}.{q}.weight"], G[f"{att}.{blk}.{q}.bias"] = z32(ENC, ENC), z32(ENC)
+    dE_v = ex.dx(dVV, 2 * ENC, P["wv"], new(3 * B, ENC), ENC, 3 * B)
+    dE = ex.add(new(3 * B, ENC), dE_v, dE_est).view(B, 3 * ENC)
+    # ---- encoders
+    for m, (t, pe, ename) in enumerate(zip(T["enc"], P["enc"], ("audio_encoder", "video_encoder", "text_encoder"))):
+        dEm = dE[:, m * ENC:(m + 1) * ENC]
+        hs = t["h"]
+        dh = ex.dx(dEm, 3 * ENC, pe["wo"], new(B, ENC), ENC, B)
+        ex.dw(dEm, 3 * ENC, hs[-1], ENC, *grads(ename + ".output_projection", ENC, ENC), B, ENC, ENC)
+        for l in reversed(range(len(pe["res"]))):
+            pr, pre = pe["res"][l], f"{ename}.encoder_layers.{l}.layers"
+            G[pre + ".3.weight"], G[pre + ".3.bias"] = z32(ENC), z32(ENC)
+            dz = ex.ln_bwd(dh, t["y"][l], *t["st"][l], pr["g"], G[pre + ".3.weight"], G[pre + ".3.bias"], sc)
+            ex.dw(dz, ENC, hs[l], ENC, *grads(pre + ".0", ENC, ENC), B, ENC, ENC)
+            dh = ex.add(new(B, ENC), dh, ex.dx(dz, ENC, pr["w"], new(B, ENC), ENC, B))
+        pre = ename + ".input_projection"
+        G[pre + ".2.weight"], G[pre + ".2.bias"] = z32(ENC), z32(ENC)
+        dz0 = ex.ln_bwd(dh, t["y0"], t["m0"], t["r0"], pe["g0"], G[pre + ".2.weight"], G[pre + ".2.bias"], 1.0)
+        K = t["xin"].shape[1]
+        ex.dw(dz0, ENC, t["xin"], t["xin"].stride(0), *grads(pre + ".0", ENC, K), B, ENC, K)
+    return G

@@ -64,6 +64,11 @@ class DEERTrainer:
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         self.model = model.to(self.device)
         self.comm = comm                     # optional mmdeer.parallel.BucketedAllReduce (data parallel)
+        # Stack B (stackb.CompleteDEERModel) trains through autograd: forward -> compute_loss -> backward into .grad, then
+        # clip_grad_norm_ + torch.optim.AdamW exactly as training.py:205-224; Stack C has the fused step + flat buffer
+        self.generic = not hasattr(model, "flat_grad")
+        if self.generic and comm is not None:
+            raise NotImplementedError("data-parallel training is built for MultimodalDEER (Stack C); Stack B trains on one device")
         self.optimizer = self._create_optimizer()
         self.scheduler = self._create_scheduler()
         self.current_epoch = 0
@@ -78,7 +83,7 @@ class DEERTrainer:
             (enc if "encoder" in name else att if "attention" in name else rest).append(p)
         lr = self.config.learning_rate
         groups = [g for g in ({"params": enc, "lr": lr * 0.5}, {"params": att, "lr": lr}, {"params": rest, "lr": lr}) if g["params"]]
-        if self.config.fused_optimizer:
+        if self.config.fused_optimizer and not self.generic:
             # clip_grad_norm_ + AdamW + weight pack as one device-side step (optim.FusedAdamW)
             return FusedAdamW(self.model, groups, lr=lr, weight_decay=self.config.weight_decay, eps=1e-8,
                               max_grad_norm=self.config.gradient_clip)
@@ -137,6 +142,16 @@ class DEERTrainer:
             w = float(self.config.dataset_weights.get(name, 1.0))
             for batch in loader:
                 a, v, t, y = unpack_batch(batch, self.device)
+                if self.generic:
+                    self.optimizer.zero_grad(set_to_none=True)
+                    ld = self.model.compute_loss(self.model(a, v, t), y)
+                    (ld["total_loss"] * w).backward()                       # weighted_loss.backward() (:211-216)
+                    norms.append(torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.config.gradient_clip))
+                    self.optimizer.step()
+                    bs = a.shape[0]
+                    sums += torch.stack([ld[k].detach().double() for k in keys]) * bs
+                    total += bs
+                    continue
                 # no zero_grad(): the fused step overwrites every live gradient slice of the flat buffer
                 ld = self._graph_step(a, v, t, y) if self._graph_ok(a) else None
                 if ld is None:
