@@ -25,6 +25,11 @@ int env_nt192() {   // MMDEER_NT192=0: the forward 256-row kernel keeps 256-colu
   return v;
 }
 // MMDEER_GLDS=0 forces the register-staged kernel for NT problems (A/B comparison, debugging)
+int env_nt128() {   // MMDEER_NT128=0: never trade two 128x64 workgroups per CU for one 8-wave 128x128 workgroup
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMDEER_NT128"); v = e ? atoi(e) : 1; }
+  return v;
+}
 int env_glds() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MMDEER_GLDS"); v = e ? atoi(e) : 1; }
@@ -126,7 +131,27 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
               q.ldc % 8 == 0 &&
               (!q.bias || ((uintptr_t)q.bias % 16 == 0 && q.sBias % 4 == 0));
     }
-    const GemmTile tile = (tt256 || nt256) ? TILE_256x256 : (tile_req == TILE_256x256 ? (ta ? TILE_128x128 : TILE_128x64) : tile_req);
+    GemmTile tile = (tt256 || nt256) ? TILE_256x256 : (tile_req == TILE_256x256 ? (ta ? TILE_128x128 : TILE_128x64) : tile_req);
+    // LDS-DMA fast path: bf16 NT problems whose operands are 16-byte aligned, row-contiguous and K % 64 == 0
+    bool glds_ok = !ta && !tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 && env_glds();
+    for (int j = 0; j < sub.nprob && glds_ok; ++j)
+      glds_ok = sub.p[j].K % 64 == 0 && sub.p[j].splitk == 1 && !sub.p[j].bias_grad;
+    // These launches are bound by the bytes a CU pulls through its vector-memory path (~40 B/clk of LDS-DMA): when 128x64
+    // tiles need two workgroups per CU (in_proj dX: 512 tiles x 576 KB) and 128x128 tiles cover the problems with about one
+    // 8-wave workgroup per CU (256 x 768 KB), the square tile moves a third fewer bytes per CU
+    bool glds128 = false;
+    if (glds_ok && tile == TILE_128x64 && env_nt128()) {
+      long long t64 = 0, t128 = 0;
+      bool ok = true;
+      for (int j = 0; j < sub.nprob; ++j) {
+        const GemmProblem& q = sub.p[j];
+        ok = ok && q.N % 128 == 0;
+        t64 += (long long)((q.M + 127) / 128) * ((q.N + 63) / 64) * q.batch;
+        t128 += (long long)((q.M + 127) / 128) * ((q.N + 127) / 128) * q.batch;
+      }
+      glds128 = ok && t64 > 320 && t128 >= 160 && t128 <= 320;
+      if (glds128) tile = TILE_128x128;
+    }
     int BM = bm_of[tile], BN = bn_of[tile];
     if (nt256 && env_nt192()) {   // 256x192 tiles when they fill the chip in one round and 256x256 tiles do not
       long long t256 = 0, t192 = 0;
@@ -150,12 +175,8 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
     for (int j = sub.nprob; j <= GEMM_MAX_PROBLEMS; ++j) sub.tile_start[j] = total;
     if (total == 0) continue;  // empty batch: nothing to do
     int rc;
-    // LDS-DMA fast path: bf16 NT problems whose operands are 16-byte aligned, row-contiguous and K % 64 == 0
-    // (128x128 tiles keep the register-staged kernel: its 74 KiB of LDS allow two workgroups per CU, the ring would not)
-    bool glds = !ta && !tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 && env_glds() &&
-                tile != TILE_128x128;
-    for (int j = 0; j < sub.nprob && glds; ++j)
-      glds = sub.p[j].K % 64 == 0 && sub.p[j].splitk == 1 && !sub.p[j].bias_grad;
+    // (other 128x128 launches keep the register-staged kernel: its 74 KiB of LDS allow two workgroups per CU)
+    const bool glds = glds_ok && (tile != TILE_128x128 || glds128);
     if (tt256) rc = gemm_dispatch_tt256(sub, total, stream);
     else if (nt256) rc = gemm_dispatch_nt256(sub, total, BN, stream);
     else if (glds) rc = gemm_dispatch_nt_glds(sub, total, tile, stream);

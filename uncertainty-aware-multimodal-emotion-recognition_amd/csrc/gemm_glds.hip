@@ -249,7 +249,7 @@ int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStrea
       // up to ~one workgroup per CU: the 8-wave form (96 KiB ring, one per CU); more tiles: 4 waves, 72 KiB ring, two per CU
       if (total <= 320 && env_nt8()) return launch_glds<128, 64, 4, 8>(g, total, s);
       return launch_glds<128, 64, 3, 4>(g, total, s);
-    default: return launch_glds<128, 128, 4, 4>(g, total, s);
+    default: return launch_glds<128, 128, 4, 8>(g, total, s);   // one 8-wave workgroup per CU (128 KiB ring), 32x64 per wave
   }
 }
 
