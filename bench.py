@@ -76,6 +76,8 @@ def rocprof_record(batch, dtype, step_ms):
            "ln_bwd_kernel<false, 2, true>": 3 * B * 512 * s, "ln_bwd_kernel<false, 1, true>": 3 * B * 256 * s,
            "nig_fwd_kernel<false>": B * 192 * s + B * 12 * 4 + 7 * B * 3 * 4, "nig_bwd_kernel<false>": 2 * B * 192 * s + B * 12 * 4 + B * 3 * 4,
            "tri_fused_kernel<1>": 2 * B * 512 * s + 1536 * 512 * s + B * 512 * s + B * 32 * 4 + 2 * B * 1536 * s}
+    if B == 4096:   # the weight-gradient fold: 240 split-K slabs of 256 x 256 fp32 in, the 2,907,212-element gradient out
+        hbm["reduce_partials_kernel"] = 240 * 256 * 256 * 4 + 2907212 * 4
     out = {"file": "profiles/" + meta["csv"], "hbm_gbps": {}}
     k = "tri_fused_kernel<0>"
     if k in avg:

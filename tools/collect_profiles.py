@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Copy the summaries of tools/gpu_round_profiles.sh (gpurun_out/round/) into profiles/ under round-numbered names and write
+the metadata bench.py checks before quoting them (which kernel sources, batch and dtype they were measured on).
+usage: collect_profiles.py r02"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src, dst = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profiles")
+sha = bench.kernel_sources_sha()
+for name in ("bench_b4096_bf16.json", "bench_b8192_bf16.json", "bench_b1024_fp32.json", "bench_b7_bf16.json", "step_trace.txt",
+             "pmc_fused_summary.txt", "tf_stamps.txt", "fwd_only.txt"):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
+        print("copied", name)
+stats = glob.glob(os.path.join(src, "prof", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+    line = json.load(open(os.path.join(src, "bench_b4096_bf16.json")))
+    meta = {"csv": f"{tag}_bench_kernel_stats.csv", "src_sha": sha, "batch": 4096, "dtype": "bf16",
+            "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline",
+            "bench_line_of_the_same_box": {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}}
+    json.dump(meta, open(os.path.join(dst, "r02_bench_kernel_stats.json"), "w"), indent=1)
+    print("kernel stats ->", meta["csv"], "sha", sha)
+pt = os.path.join(src, "pmc_traffic.json")
+if os.path.exists(pt):
+    rec = json.load(open(pt))
+    if rec.get("src_sha") != sha:
+        print("WARNING: pmc_traffic.json was measured on other kernel sources:", rec.get("src_sha"), "!=", sha)
+    json.dump(rec, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    print("pmc traffic ->", rec)

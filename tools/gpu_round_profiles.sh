@@ -1,0 +1,20 @@
+#!/bin/bash
+# Everything profiles/ holds for one round, in one gpurun call (about 6 minutes of box time):
+#   bench lines (default B=4096 bf16 with the CPU baseline; B=8192 bf16; B=1024 fp32; B=7 launch floor),
+#   rocprofv3 --kernel-trace --stats of the default command, the --pmc passes over the fused kernel (separate passes),
+#   and the in-kernel phase stamps of the diagnostic build.
+# tools/collect_profiles.py then copies the summaries into profiles/ under round-numbered names.
+set -u
+ROOT=$(pwd); export TMPDIR=/tmp
+OUT=gpurun_out/round; rm -rf $OUT; mkdir -p $OUT
+timeout -k 10 500 python bench.py > $OUT/bench_b4096_bf16.json 2> $OUT/bench_b4096_bf16.err; echo "bench default rc=$?"
+timeout -k 10 300 python bench.py --batch 8192 --no-cpu-baseline > $OUT/bench_b8192_bf16.json 2> /dev/null; echo "bench B=8192 rc=$?"
+timeout -k 10 300 python bench.py --batch 1024 --dtype fp32 --no-cpu-baseline > $OUT/bench_b1024_fp32.json 2> /dev/null; echo "bench fp32 rc=$?"
+timeout -k 10 300 python bench.py --batch 7 --no-cpu-baseline > $OUT/bench_b7_bf16.json 2> /dev/null; echo "bench B=7 rc=$?"
+timeout -k 10 200 python tools/fwd_only.py > $OUT/fwd_only.txt 2> /dev/null; echo "fwd only rc=$?"
+( cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $ROOT/$OUT/rocprof.log 2>&1; echo "rocprof rc=$?" )
+python tools/step_trace.py $OUT/prof/*/*_kernel_trace.csv 3 > $OUT/step_trace.txt 2>&1; echo "step trace rc=$?"
+bash tools/gpu_pmc_fused.sh > $OUT/pmc.log 2>&1; echo "pmc rc=$?"
+cp gpurun_out/pmc_fused_summary.txt gpurun_out/pmc_traffic.json $OUT/ 2>/dev/null
+timeout -k 10 200 python tools/tf_stamps.py > $OUT/tf_stamps.txt 2>&1; echo "stamps rc=$?"
+ls -la $OUT

@@ -57,6 +57,8 @@ for half in (0, 1):
     print(f"--- {mode} B={B} wave {4 * half}: issue done +{t[1]-t[0]}  loop start +{t[2]-t[0]}  loop end +{t[3]-t[0]}  after final barrier +{t[4]-t[0]}  "
           f"exchange done +{t[5]-t[0]}  epilogue math done +{t[6]-t[0]}  end +{t[7]-t[0]}")
     rows = []
+    if not t[8:56].any():          # per-phase stamps exist only in the MMDEER_STAMPS_LOOP build (they perturb the loop)
+        continue
     for kt in range(16):
         a, b, c = t[8 + 3 * kt: 11 + 3 * kt]
         nxt = t[8 + 3 * (kt + 1)] if kt < 15 else t[3]
