@@ -276,21 +276,24 @@ def test_streaming_metrics_match_host_metrics():
 
 def test_evaluate_deer_model_accepts_stack_b():
     """evaluation.evaluate_deer_model over loaders for the Stack B model: streaming metrics equal the host metrics of
-    the concatenated predictions; no loss exists for this stack in the reference (NaN)."""
+    the concatenated predictions; the loss is stackb.CompleteDEERModel.compute_loss (MultiTaskDEERLoss on its keys), the mean of
+    the per-batch values as training.py:285-299 accumulates them."""
     from mmdeer import stackb
     from mmdeer.metrics import validation_metrics
     m = stackb.CompleteDEERModel().to("cuda:0")
     ld = loaders(96, 32, 9, True)
     ev = evaluate_deer_model(m, ld, "cuda:0")
-    assert not m.training and np.isnan(ev["test_loss"])
-    preds, tgts, uncs = [], [], []
+    assert not m.training
+    preds, tgts, uncs, losses = [], [], [], []
     for b in ld["iemocap"]:
         out = m(b["audio_features"].cuda(), b["video_features"].cuda(), b["text_features"].cuda())
+        losses.append(float(m.compute_loss(out, b["targets"].cuda())["total_loss"]))
         p, u = m.get_predictions_and_uncertainties(out)
         preds.append(p.cpu().numpy()); tgts.append(b["targets"].numpy()); uncs.append(u.cpu().numpy())
     ref = validation_metrics(np.concatenate(preds), np.concatenate(tgts), np.concatenate(uncs))
     for k in ("ccc_valence", "ccc_overall", "mae_arousal", "rmse_dominance"):
         np.testing.assert_allclose(ev[k], ref[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    assert ev["test_loss"] == pytest.approx(np.mean(losses), rel=1e-6) and np.isfinite(ev["test_loss"])
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -264,7 +264,8 @@ class DEERTrainer:
 def evaluate_loaders(model, loaders: Dict[str, Iterable], device=None) -> Dict[str, float]:
     """Validation pass of training.py:247-314 for any model of this package that maps (audio, video, text) to an output
     dictionary understood by its ``get_predictions_and_uncertainties`` -- ``MultimodalDEER`` (Stack C) or
-    ``stackb.CompleteDEERModel`` (Stack B, which has no loss in the reference: ``val_loss`` is then NaN).
+    ``stackb.CompleteDEERModel`` (Stack B; its ``compute_loss`` is MultiTaskDEERLoss on its keys).  A model without a
+    ``compute_loss`` gets ``val_loss`` = NaN.
 
     CCC / MAE / RMSE statistics are accumulated on the device batch by batch (mmdeer_eval_accumulate); only 24 doubles and
     the per-sample (mean error, mean uncertainty) pairs of the calibration error reach the host."""
