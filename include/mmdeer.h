@@ -420,6 +420,33 @@ int mmdeer_stackb_head_bwd(const float* ev, int ld_ev, const float* g4, void* de
 int mmdeer_add_masked(void* out, int ld_out, const void* x, int ld_x, const void* y, int ld_y, const void* mask, int ld_mask,
                       float scale, int M, int N, int act_f32, void* stream);
 
+/* ---- alternative fusion modules of src/models/fusion.py:421-554 (AttentionFusion, BilinearFusion, AdaptiveFusionGating):
+ * their Linear layers run on mmdeer_gemm; these are the row operators (mmdeer/fusions.py is the call sequence).
+ *
+ * Softmax over S <= 8 stacked feature rows of one sample and their weighted sum.  P(b, s, :) = P + b ldp + s sp (elements, D
+ * columns each).  Logits: P(b, s, :) . w_att + b_att[0] (AttentionFusion.forward, fusion.py:523: the Linear(D, 1) `attention`)
+ * when w_att != NULL, else logits[b ld_logits + s] (AdaptiveFusionGating.forward, fusion.py:470-489: strategy_selector's output
+ * before its Softmax).  Forward writes weights8 (fp32 [B][8], zeros beyond S) and out; backward reads weights8 and dout and
+ * writes dP (same addressing as P; includes the path through w_att) and dlogits8 (act [B][8], zeros beyond S). */
+typedef struct mmdeer_softmax_mix_args {
+  const void* P; int64_t ldp, sp;
+  int32_t S, D, B, act_f32;
+  const float* w_att; const float* b_att;
+  const float* logits; int32_t ld_logits;
+  float* weights8;
+  void* out; int32_t ld_out;
+  const void* dout; int32_t ld_dout;
+  void* dP; void* dlogits8;
+  void* stream;
+} mmdeer_softmax_mix_args;
+int mmdeer_softmax_mix_fwd(const mmdeer_softmax_mix_args* a);
+int mmdeer_softmax_mix_bwd(const mmdeer_softmax_mix_args* a);
+/* z[b][i J + j] = x1[b][i] x2[b][j] (act [B][I J], dense): nn.Bilinear (fusion.py:536, 546) = mmdeer_gemm(z, weight read as
+ * [out][I J]).  Backward: dx1[b][i] = sum_j dz[b][i J + j] x2[b][j], dx2[b][j] = sum_i dz[b][i J + j] x1[b][i]  (J <= 1024). */
+int mmdeer_outer_fwd(const void* x1, int ld1, const void* x2, int ld2, void* z, int B, int I, int J, int act_f32, void* stream);
+int mmdeer_outer_bwd(const void* dz, const void* x1, int ld1, const void* x2, int ld2, void* dx1, int ldd1, void* dx2, int ldd2, int B, int I,
+                     int J, int act_f32, void* stream);
+
 /* The whole eval forward as ONE call: 25 launches per batch (26 in bf16 mode), the three encoders / the layers that
  * share an input side by side in grouped GEMM launches.  `mmdeer_stackb_weights` is the device-side operand image the
  * host builds once per parameter update from the reference's state_dict (mmdeer/stackb.py does it): matrices ("W") in

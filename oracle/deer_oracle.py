@@ -461,6 +461,43 @@ def stackb_forward(P, audio, video, text, heads=8, layers=3):
     return out
 
 
+# --------------------------------------------------------------------------- a5: the alternative fusions (fusion.py:421-592)
+def attention_fusion(P, feats, prefix=""):
+    """AttentionFusion.forward -- fusion.py:515-528.  Returns (weighted sum, attention weights)."""
+    st = torch.stack([_lin(f, P, f"{prefix}projections.{i}") for i, f in enumerate(feats)], dim=1)
+    w = torch.softmax(_lin(st, P, prefix + "attention").squeeze(-1), dim=-1)
+    return (w.unsqueeze(-1) * st).sum(dim=1), w
+
+
+def bilinear_fusion(P, feats, prefix=""):
+    """BilinearFusion.forward -- fusion.py:545-554 (nn.Bilinear: y_o = x1^T W_o x2 + b_o)."""
+    if len(feats) < 2:
+        return _lin(feats[0], P, prefix + "linear")
+    y = torch.einsum("bi,oij,bj->bo", feats[0], P[prefix + "bilinear.weight"], feats[1]) + P[prefix + "bilinear.bias"]
+    if len(feats) > 2:
+        y = y + _lin(torch.cat(list(feats[2:]), dim=-1), P, prefix + "additional_linear")
+    return y
+
+
+def adaptive_fusion(P, feats, strategies, prefix=""):
+    """AdaptiveFusionGating.forward in eval mode -- fusion.py:458-501 (strategies 'attention' / 'bilinear')."""
+    cat = torch.cat(list(feats), dim=-1)
+    h = torch.relu(_lin(torch.relu(_lin(cat, P, prefix + "feature_encoder.0")), P, prefix + "feature_encoder.3"))
+    w = torch.softmax(_lin(h, P, prefix + "strategy_selector.0"), dim=-1)
+    outs = []
+    for name in strategies:
+        if name == "attention":
+            outs.append(attention_fusion(P, feats, prefix + "fusion_modules.attention.")[0])
+        elif name == "bilinear":
+            outs.append(bilinear_fusion(P, feats, prefix + "fusion_modules.bilinear."))
+    return (w.unsqueeze(-1) * torch.stack(outs, dim=1)).sum(dim=1), w
+
+
+def concat_fusion(P, x, prefix=""):
+    """The concatenation branch of create_fusion_module in eval mode -- fusion.py:584-592: LayerNorm(ReLU(Linear(x)))."""
+    return _layer_norm(torch.relu(_lin(x, P, prefix + "0")), P[prefix + "3.weight"], P[prefix + "3.bias"])
+
+
 # --------------------------------------------------------------------------- metric
 def ccc(x, y):
     """Concordance correlation coefficient, population variance -- metrics.py:85-101."""

@@ -295,7 +295,67 @@ def capture_metrics():
     return out
 
 
+FUSION_DIMS = [84, 256, 768]
+
+
+def fusion_alt_modules():
+    """(tag, reference module, state shapes) of the a5 row: the alternative fusions of fusion.py:421-554 and the two non-hierarchical
+    branches of its factory (:579-592)."""
+    return [("attention", ref_fusion.AttentionFusion(FUSION_DIMS, 256)),
+            ("bilinear", ref_fusion.BilinearFusion(FUSION_DIMS, 256)),
+            ("bilinear2", ref_fusion.BilinearFusion(FUSION_DIMS[:2], 256)),
+            ("adaptive", ref_fusion.AdaptiveFusionGating(FUSION_DIMS, ["attention", "bilinear"], 256)),
+            ("factory_attention", ref_fusion.create_fusion_module("attention", {})),
+            ("factory_concat", ref_fusion.create_fusion_module("concatenation", {"input_dims": FUSION_DIMS}))]
+
+
+def capture_fusion_alt():
+    """Eval-mode outputs of every module above at B = 9 with closed-form parameters, and the gradients of sum(out * c) (c a
+    fixed closed-form tensor) with respect to every parameter and every input, stored whole (the modules are small except for
+    the bilinear weight, which is stored as digests)."""
+    import json
+    out, shapes = {}, {}
+    B = 9
+    for tag, mod in fusion_alt_modules():
+        mod.eval()
+        sd = fill_module(mod, "fa_" + tag)
+        shapes[tag] = {k: list(v.shape) for k, v in sd.items()}
+        dims = [256, 256, 256] if tag == "factory_attention" else (FUSION_DIMS[:2] if tag == "bilinear2" else FUSION_DIMS)
+        xs = [torch.from_numpy(synth.normal(700 + 10 * len(tag) + i, B * d).reshape(B, d).astype(np.float32)).requires_grad_(True)
+              for i, d in enumerate(dims)]
+        if tag == "adaptive":
+            o = mod(*xs)
+            y, extra = o["fused_features"], {"strategy_weights": o["strategy_weights"]}
+        elif tag == "factory_concat":
+            y, extra = mod(torch.cat(xs, dim=-1)), {}
+        else:
+            y, extra = mod(xs), {}
+        c = torch.from_numpy(synth.normal(990 + len(tag), y.numel()).reshape(y.shape).astype(np.float32))
+        (y * c).sum().backward()
+        out[f"{tag}.out"] = tnp(y)          # inputs and c are closed-form: the tests rebuild them (fusion_alt_inputs)
+        for k, v in extra.items():
+            out[f"{tag}.{k}"] = tnp(v)
+        for i, x in enumerate(xs):
+            out[f"{tag}.dx{i}"] = tnp(x.grad)
+        for name, prm in mod.named_parameters():
+            if prm.grad is None:
+                out[f"{tag}.gradnone.{name}"] = np.zeros(0, np.float32)
+            elif prm.numel() > 20000:
+                g = prm.grad.detach().double().reshape(-1)
+                idx = torch.linspace(0, g.numel() - 1, 1024).round().long()
+                out[f"{tag}.gradnorm.{name}"], out[f"{tag}.gradsample.{name}"] = np.float64(g.norm().item()), g[idx].numpy().astype(np.float32)
+            else:
+                out[f"{tag}.grad.{name}"] = tnp(prm.grad)
+    with open(os.path.join(HERE, "fusion_alt_state_dict_names.json"), "w") as fh:
+        json.dump(shapes, fh, indent=0)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "fusion_alt":
+        np.savez_compressed(os.path.join(HERE, "fusion_alt.npz"), **capture_fusion_alt())
+        print("fusion_alt.npz", os.path.getsize(os.path.join(HERE, "fusion_alt.npz")), "bytes")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "losses":
         np.savez_compressed(os.path.join(HERE, "loss_cases.npz"), **capture_losses())
         print("loss_cases.npz", os.path.getsize(os.path.join(HERE, "loss_cases.npz")), "bytes")

@@ -227,7 +227,7 @@ def test_host_metrics_match_the_reference_vectors():
 
 def test_create_fusion_module_factory():
     """fusion.create_fusion_module (fusion.py:557-592): the 'hierarchical' branch with the reference's defaults and key
-    names; the uncalled alternatives raise a clear NotImplementedError."""
+    names; the 'attention' and concatenation branches build the mirrors of mmdeer.fusions (same state_dict keys), CPU tensors raise."""
     import pytest
 
     from mmdeer.model import HierarchicalMultimodalFusion, create_fusion_module
@@ -237,6 +237,13 @@ def test_create_fusion_module_factory():
     m = create_fusion_module("Hierarchical", {"audio_dim": 84, "video_dim": 256, "text_dim": 768, "dropout": 0.1})
     assert isinstance(m, HierarchicalMultimodalFusion)
     assert "trimodal_fusion.modality_attention.in_proj_weight" in m.state_dict()
-    for other in ("attention", "concatenation", "bilinear"):
-        with pytest.raises(NotImplementedError, match="only 'hierarchical' is built"):
-            create_fusion_module(other, {"input_dims": [256, 256, 256]})
+    from mmdeer import fusions
+    att = create_fusion_module("attention", {})                        # fusion.py:579-583
+    assert isinstance(att, fusions.AttentionFusion) and att.attention.weight.shape == (1, 512) and len(att.projections) == 3
+    seq = create_fusion_module("concatenation", {"input_dims": [84, 256, 768], "dropout": 0.2})     # fusion.py:584-592
+    assert isinstance(seq, torch.nn.Sequential) and seq[0].weight.shape == (512, 1108) and seq[2].p == 0.2
+    assert sorted(seq.state_dict()) == ["0.bias", "0.weight", "3.bias", "3.weight"]
+    ada = fusions.AdaptiveFusionGating([84, 256, 768], ["attention", "bilinear"], 256)
+    assert ada.fusion_modules["bilinear"].bilinear.weight.shape == (256, 84, 256) and ada.strategy_selector[0].out_features == 2
+    with pytest.raises(RuntimeError, match="no CPU fallback"):         # product path: HIP or nothing
+        att([torch.zeros(2, 256)] * 3)

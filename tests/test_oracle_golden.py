@@ -280,3 +280,76 @@ def test_stackb_gradients(golden_dir):
     loss, grads = stackb_oracle_gradients(O, _stackb_params(golden_dir), synth.make_batch(9, seed=78))
     assert float(loss) == pytest.approx(float(g["grad.total_loss"]), rel=1e-5)
     check_gradient_digests(g, grads, rtol=2e-4, atol_frac=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------- a5: alternative fusions
+FUSION_ALT_TAGS = ("attention", "bilinear", "bilinear2", "adaptive", "factory_attention", "factory_concat")
+
+
+def fusion_alt_params(golden_dir, tag, dtype=torch.float32):
+    import json
+    with open(os.path.join(golden_dir, "fusion_alt_state_dict_names.json")) as fh:
+        shapes = json.load(fh)[tag]
+    return {k: torch.from_numpy(v).to(dtype) for k, v in synth.module_fill("fa_" + tag, shapes).items()}
+
+
+def fusion_alt_oracle(O, tag, P, xs):
+    """(output, extras) of the oracle's restatement of golden case `tag`."""
+    if tag in ("attention", "factory_attention"):
+        y, w = O.attention_fusion(P, xs)
+        return y, {"attention_weights": w}
+    if tag in ("bilinear", "bilinear2"):
+        return O.bilinear_fusion(P, xs), {}
+    if tag == "adaptive":
+        y, w = O.adaptive_fusion(P, xs, ["attention", "bilinear"])
+        return y, {"strategy_weights": w}
+    return O.concat_fusion(P, torch.cat(xs, dim=-1)), {}
+
+
+def check_fusion_alt_grads(g, tag, grads, dxs, rtol, atol_frac):
+    """Parameter and input gradients of case `tag` against tests/golden/fusion_alt.npz (whole tensors, digests for the large ones)."""
+    seen = 0
+    for k in g:
+        if not k.startswith(tag + "."):
+            continue
+        kind, _, name = k[len(tag) + 1:].partition(".")
+        if kind == "grad":
+            ref = g[k]
+            scale = max(float(np.abs(ref).max()), 1e-12)
+            if name.endswith("attention.bias"):      # softmax is shift invariant: this gradient is zero up to rounding -- scale by its weight's
+                scale = float(np.abs(g[k[:-len("bias")] + "weight"]).max())
+                rtol_k = 0.0
+            else:
+                rtol_k = rtol
+            np.testing.assert_allclose(grads[name].detach().cpu().numpy(), ref, rtol=rtol_k, atol=max(atol_frac, 1e-5) * scale, err_msg=k)
+        elif kind == "gradnorm":
+            v = grads[name].detach().double().cpu().reshape(-1)
+            assert float(v.norm()) == pytest.approx(float(g[k]), rel=rtol), k
+            ref = g[f"{tag}.gradsample.{name}"]
+            idx = torch.linspace(0, v.numel() - 1, 1024).round().long()
+            np.testing.assert_allclose(v[idx].numpy(), ref, rtol=rtol, atol=atol_frac * float(np.abs(ref).max()), err_msg=k)
+        elif kind == "gradnone":
+            assert grads[name] is None, k
+        else:
+            continue
+        seen += 1
+    assert seen >= 2, tag
+    for i, dx in enumerate(dxs):
+        ref = g[f"{tag}.dx{i}"]
+        np.testing.assert_allclose(dx.detach().cpu().numpy(), ref, rtol=rtol, atol=atol_frac * float(np.abs(ref).max()), err_msg=f"{tag}.dx{i}")
+
+
+@pytest.mark.parametrize("tag", FUSION_ALT_TAGS)
+def test_alternative_fusions(golden_dir, tag):
+    """AttentionFusion / BilinearFusion / AdaptiveFusionGating and the factory's non-hierarchical branches (fusion.py:421-592):
+    eval outputs, parameter gradients and input gradients of the imported reference."""
+    g = _load(golden_dir, "fusion_alt.npz")
+    P = {k: v.requires_grad_(True) for k, v in fusion_alt_params(golden_dir, tag).items()}
+    xs_np, c = synth.fusion_alt_inputs(tag, g[tag + ".out"].shape)
+    xs = [torch.from_numpy(x).requires_grad_(True) for x in xs_np]
+    y, extra = fusion_alt_oracle(O, tag, P, xs)
+    np.testing.assert_allclose(y.detach().numpy(), g[tag + ".out"], rtol=2e-5, atol=2e-5 * float(np.abs(g[tag + ".out"]).max()))
+    if tag == "adaptive":
+        np.testing.assert_allclose(extra["strategy_weights"].detach().numpy(), g["adaptive.strategy_weights"], rtol=2e-5, atol=1e-6)
+    (y * torch.from_numpy(c)).sum().backward()
+    check_fusion_alt_grads(g, tag, {k: v.grad for k, v in P.items()}, [x.grad for x in xs], rtol=2e-4, atol_frac=2e-5)

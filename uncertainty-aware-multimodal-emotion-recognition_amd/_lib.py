@@ -92,6 +92,15 @@ class StackBAttnArgs(C.Structure):
     ]
 
 
+class SoftmaxMixArgs(C.Structure):
+    _fields_ = [
+        ("P", c_void_p), ("ldp", C.c_int64), ("sp", C.c_int64), ("S", c_int), ("D", c_int), ("B", c_int), ("act_f32", c_int),
+        ("w_att", c_void_p), ("b_att", c_void_p), ("logits", c_void_p), ("ld_logits", c_int), ("weights8", c_void_p),
+        ("out", c_void_p), ("ld_out", c_int), ("dout", c_void_p), ("ld_dout", c_int), ("dP", c_void_p), ("dlogits8", c_void_p),
+        ("stream", c_void_p),
+    ]
+
+
 class StackBAttnTrainArgs(C.Structure):
     _fields_ = [
         ("h2", c_void_p), ("pre", c_void_p), ("self_out", c_void_p), ("cross_out", c_void_p),
@@ -181,6 +190,10 @@ SYMBOLS = [
     ("mmdeer_stackb_attn_mix_train_fwd", c_int, [C.POINTER(StackBAttnTrainArgs)]),
     ("mmdeer_stackb_attn_mix_bwd", c_int, [C.POINTER(StackBAttnTrainArgs)]),
     ("mmdeer_stackb_gate_mix_bwd", c_int, [c_void_p, c_int] * 7 + [c_int, c_int, c_int, c_void_p]),
+    ("mmdeer_softmax_mix_fwd", c_int, [C.POINTER(SoftmaxMixArgs)]),
+    ("mmdeer_softmax_mix_bwd", c_int, [C.POINTER(SoftmaxMixArgs)]),
+    ("mmdeer_outer_fwd", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("mmdeer_outer_bwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_stackb_head_bwd", c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_add_masked", c_int, [c_void_p, c_int] * 4 + [c_float, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_stackb_workspace_bytes", c_size_t, [c_int, c_int, c_int]),

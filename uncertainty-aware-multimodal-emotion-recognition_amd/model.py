@@ -641,11 +641,13 @@ class HierarchicalMultimodalFusion(nn.Module):
 
 
 def create_fusion_module(fusion_type: str, config: Dict) -> nn.Module:
-    """``fusion.create_fusion_module`` (src/models/fusion.py:557-592).  ``'hierarchical'`` (:568-578) returns this package's
-    ``HierarchicalMultimodalFusion`` with the reference's key lookups and defaults.  The other two branches -- ``'attention'``
-    (``AttentionFusion``, :504-528) and the concatenation fallback -- as well as ``AdaptiveFusionGating`` / ``BilinearFusion``
-    (:421-554) have no caller anywhere in the reference and are not built."""
+    """``fusion.create_fusion_module`` (src/models/fusion.py:557-592) with the reference's key lookups and defaults:
+    ``'hierarchical'`` (:568-578) -> ``HierarchicalMultimodalFusion``, ``'attention'`` (:579-583) -> ``fusions.AttentionFusion``,
+    anything else (:584-592) -> the Linear-ReLU-Dropout-LayerNorm block (``fusions.ConcatFusion``, an ``nn.Sequential`` with the
+    same child indices).  Optional extra keys: ``compute_dtype`` ('fp32' | 'bf16'), ``seed``."""
+    from . import fusions
     kind = str(fusion_type).lower()
+    extra = {k: config[k] for k in ("compute_dtype",) if k in config}
     if kind == "hierarchical":
         return HierarchicalMultimodalFusion(
             audio_dim=config.get("audio_dim", 256), video_dim=config.get("video_dim", 256), text_dim=config.get("text_dim", 256),
@@ -653,10 +655,10 @@ def create_fusion_module(fusion_type: str, config: Dict) -> nn.Module:
             num_attention_heads=config.get("num_attention_heads", 8), dropout=config.get("dropout", 0.3),
             use_uncertainty_weighting=config.get("use_uncertainty_weighting", True),
             **{k: config[k] for k in ("compute_dtype", "seed") if k in config})
-    raise NotImplementedError(
-        f"create_fusion_module({fusion_type!r}): only 'hierarchical' is built.  The reference's 'attention' (AttentionFusion) "
-        "and concatenation branches, AdaptiveFusionGating and BilinearFusion (fusion.py:421-592) are never called by any of "
-        "its scripts and have no HIP implementation here; use the reference's torch modules for them.")
+    if kind == "attention":
+        return fusions.AttentionFusion(input_dims=config.get("input_dims", [256, 256, 256]), output_dim=config.get("fusion_dim", 512), **extra)
+    return fusions.ConcatFusion(sum(config.get("input_dims", [256, 256, 256])), config.get("fusion_dim", 512), config.get("dropout", 0.3),
+                                dropout_seed=config.get("seed", 0), **extra)
 
 
 def create_model(config: Optional[ModelConfig] = None, device: Optional[str] = None) -> MultimodalDEER:

@@ -1,0 +1,104 @@
+"""Operator sequencing helper: one object per pass that turns nn.Linear / nn.LayerNorm layers into ``mmdeer_gemm`` /
+``mmdeer_layernorm_*`` calls on the current stream -- forward (bias / ReLU / counter-hash dropout in the epilogue),
+``dX = dY W`` (with the ``(Y > 0) * scale`` mask of the layer below, or a regenerated dropout factor), ``dW = dY^T X`` (+ bias
+gradient from the same launch).  Host logic only: every number comes out of ``libmmdeer_hip.so``.  Used by the modules that
+are sequences of such layers around a few row kernels (``stackb_train.py``, ``fusions.py``)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class Exec:
+    """One training step's launches.  ``drop``: (p_config, seed, step) or None (no dropout anywhere)."""
+
+    def __init__(self, compute_dtype: str, drop=None):
+        self.f32 = int(compute_dtype == "fp32")
+        self.dt = torch.float32 if self.f32 else torch.bfloat16
+        self.drop = drop
+        self.lib = _lib.load()
+        self.s = _lib.current_stream()
+
+    # ---- operator wrappers ------------------------------------------------------------------------------------------
+    def gemm(self, A, W, Cm, M, N, K, lda, ldw, ldc, *, bias=None, relu=0, ta=0, tw=0, Y=None, ldy=0, mask_scale=1.0, bias_grad=None,
+             drop_site=-1, drop_shift=0, regen_site=-1, p=0.0):
+        if M == 0 or N == 0:
+            return Cm
+        a = _lib.GemmArgs()
+        a.A, a.W, a.C = A.data_ptr(), W.data_ptr(), Cm.data_ptr()
+        a.bias, a.bias_grad, a.Y = _ptr(bias), _ptr(bias_grad), _ptr(Y)
+        a.M, a.N, a.K, a.lda, a.ldw, a.ldc, a.ldy = M, N, K, lda, ldw, ldc, ldy
+        a.a_f32, a.w_f32, a.c_f32 = int(A.dtype == torch.float32), int(W.dtype == torch.float32), int(Cm.dtype == torch.float32)
+        a.y_f32 = int(Y is not None and Y.dtype == torch.float32)
+        a.trans_a, a.trans_w, a.relu = ta, tw, relu
+        a.compute_f32, a.tile = self.f32, -1
+        a.drop_site, a.drop_shift, a.regen_site = drop_site, drop_shift, regen_site
+        a.mask_scale = mask_scale
+        if self.drop is not None:
+            a.dropout_p, a.seed, a.offset = p, self.drop[1], self.drop[2]
+        a.stream = self.s
+        _lib.check(self.lib.mmdeer_gemm(C.byref(a)))
+        return Cm
+
+    def p_of(self, p):          # effective dropout probability of a site
+        return float(p) if self.drop is not None and p > 0 else 0.0
+
+    def scale_of(self, p):
+        p = self.p_of(p)
+        return 1.0 / (1.0 - p) if p > 0 else 1.0
+
+    def linear(self, x, ldx, w, b, out, ldo, M, relu=0, site=-1, p=0.0, shift=0):
+        """out = drop?(relu?(x w^T + b)); w: (N, K) parameter in the compute dtype (packed by the caller)."""
+        N, K = w.shape
+        p = self.p_of(p)
+        return self.gemm(x, w, out, M, N, K, ldx, w.stride(0), ldo, bias=b, relu=relu, drop_site=site if p > 0 else -1, drop_shift=shift, p=p)
+
+    def dx(self, dy, ldy_, w, out, ldo, M, mask=None, ldm=0, mask_scale=1.0, regen_site=-1, shift=0, p=0.0):
+        """out = (dy w) [* ((mask > 0) * mask_scale)] [* regenerated dropout factor]; w: (N, K) as stored."""
+        N, K = w.shape
+        p = self.p_of(p)
+        return self.gemm(dy, w, out, M, K, N, ldy_, w.stride(0), ldo, tw=1, Y=mask, ldy=ldm, mask_scale=mask_scale,
+                         regen_site=regen_site if p > 0 else -1, drop_shift=shift, p=p)
+
+    def dw(self, dy, ldy_, x, ldx, gw, gb, M, N, K):
+        """gw (N, K) fp32 = dy^T x, gb (N,) = column sums of dy; dy: (M, N) view, x: (M, K) view."""
+        if M * min(ldy_, ldx) < 8:       # an operand below the GEMM's 8-element minimum (M = 1, a 4-wide matrix): append a zero row
+            d2, x2 = torch.zeros(M + 1, N, dtype=dy.dtype, device=dy.device), torch.zeros(M + 1, K, dtype=x.dtype, device=x.device)
+            d2[:M].copy_(dy[:M, :N]); x2[:M].copy_(x[:M, :K])
+            dy, ldy_, x, ldx, M = d2, N, x2, K, M + 1
+        return self.gemm(dy, x, gw, N, K, M, ldy_, ldx, gw.stride(0), ta=1, tw=1, bias_grad=gb)
+
+    def ln_fwd(self, y, gamma, beta):
+        M, N = y.shape
+        out = torch.empty_like(y)
+        mean = torch.empty(M, dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+        if M:
+            _lib.check(self.lib.mmdeer_layernorm_fwd(y.data_ptr(), out.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                                     beta.data_ptr(), M, N, self.f32, self.s))
+        return out, mean, rstd
+
+    def ln_bwd(self, dout, y, mean, rstd, gamma, ggamma, gbeta, mask_scale):
+        """dz = (y > 0) * mask_scale * LayerNorm'(dout); ggamma / gbeta fp32 (N,)."""
+        M, N = y.shape
+        dz = torch.empty_like(y)
+        if M:
+            part = torch.empty(self.lib.mmdeer_layernorm_bwd_nparts(M) * 2 * N, dtype=torch.float32, device=y.device)
+            _lib.check(self.lib.mmdeer_layernorm_bwd(dout.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                                     dz.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(), part.data_ptr(), M, N, self.f32,
+                                                     mask_scale, self.s))
+        return dz
+
+    def add(self, out, x, y=None, mask=None, scale=1.0):
+        M, N = x.shape
+        _lib.check(self.lib.mmdeer_add_masked(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
+                                              _ptr(mask), mask.stride(0) if mask is not None else 0, scale, M, N, self.f32, self.s))
+        return out

@@ -172,3 +172,17 @@ def reference_init_state(dims: Dims = DEFAULT_DIMS, seed: int = 0,
             w = np.zeros(n)
         sd[name] = np.asarray(w, dtype=np.float64).reshape(shape).astype(np.float32)
     return sd
+
+
+FUSION_ALT_DIMS = [84, 256, 768]
+
+
+def fusion_alt_inputs(tag: str, out_shape=None, B: int = 9):
+    """Closed-form inputs (and, given the output shape, the loss weights c) of the a5 golden cases
+    (tests/golden/make_golden.py: capture_fusion_alt)."""
+    dims = [256, 256, 256] if tag == "factory_attention" else (FUSION_ALT_DIMS[:2] if tag == "bilinear2" else FUSION_ALT_DIMS)
+    xs = [normal(700 + 10 * len(tag) + i, B * d).reshape(B, d).astype(np.float32) for i, d in enumerate(dims)]
+    c = None
+    if out_shape is not None:
+        c = normal(990 + len(tag), int(np.prod(out_shape))).reshape(out_shape).astype(np.float32)
+    return xs, c
