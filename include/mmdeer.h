@@ -197,6 +197,9 @@ int mmdeer_gemm(const mmdeer_gemm_args* a);
 int mmdeer_layernorm_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,
                          const float* beta, int M, int N, int act_f32, void* stream);
 int mmdeer_layernorm_bwd_nparts(int M);
+/* dz = (y > 0) * mask_scale * LayerNorm'(dout): the ReLU (+ dropout, mask_scale = 1 / (1 - p)) of the Linear-ReLU-Dropout-LayerNorm
+ * blocks folded in; mask_scale <= 0: no mask (a LayerNorm behind a plain Linear, encoders.py:113-114).  partial: scratch of
+ * mmdeer_layernorm_bwd_nparts(M) * 2 * N floats. */
 int mmdeer_layernorm_bwd(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
                          void* dz, float* dgamma, float* dbeta, float* partial, int M, int N, int act_f32,
                          float mask_scale, void* stream);
@@ -291,7 +294,7 @@ int mmdeer_adamw_step(const mmdeer_adamw_args* a);
  * changed the parameters. */
 int mmdeer_pack_weights(const void* const* params, void* weights, size_t weights_bytes, int compute_f32, void* stream);
 
-/* ---- side rows (a8, a9, a14), forward only --------------------------------------------------------
+/* ---- side rows (a8, a9, a14) ----------------------------------------------------------------------
  * Their Linear(+ReLU) layers run on mmdeer_gemm and the LayerNorm on mmdeer_layernorm_fwd; the two entry points
  * below are the parts that are neither.
  *
@@ -303,11 +306,20 @@ int mmdeer_cross_modal_attn_fwd(const void* q, const void* k_audio, const void* 
                                 const void* v_video, int ld, const float* gate_logits, float* out_audio, float* out_video,
                                 int B, int act_f32, void* stream);
 
+/* backward of the above: g_audio / g_video fp32 [B][32] -> dq, dk_*, dv_* (act [B][256], row stride ld) and the gradient at the
+ * two gate logits (fp32 [B][2]).  Recomputes the softmaxes from the saved projections. */
+int mmdeer_cross_modal_attn_bwd(const void* q, const void* k_audio, const void* v_audio, const void* k_video, const void* v_video,
+                                int ld, const float* gate_logits, const float* g_audio, const float* g_video, void* dq, void* dk_audio,
+                                void* dv_audio, void* dk_video, void* dv_video, float* dgate_logits, int B, int act_f32, void* stream);
+
 /* nn.LSTM cell at T = 1 with zero initial state (reference src/models/encoders.py:82-89, 380; torch gate order
  * i, f, g, o): gates [B][ndir*4*hidden] = W_ih x + b_ih + b_hh per direction ->
  * out[b][dir*hidden + j] = sigmoid(o) * tanh(sigmoid(i) * tanh(g)). */
 int mmdeer_lstm_cell_t1(const void* gates, int ld_gates, void* out, int ld_out, int B, int hidden, int ndir, int act_f32,
                         void* stream);
+/* d out -> d gates (act [B][ld_gates]; the forget-gate block is written as zeros: it multiplies c0 = 0) */
+int mmdeer_lstm_cell_t1_bwd(const void* gates, int ld_gates, const void* dout, int ld_dout, void* dgates, int B, int hidden, int ndir,
+                            int act_f32, void* stream);
 
 /* ---- streaming evaluation statistics (reference src/utils/metrics.py:59-125) ---------------------------
  * pred / target / unc: [B][3] fp32 (unc may be NULL).  acc: device double[3][8], zeroed by the caller before the first

@@ -189,6 +189,21 @@ def fill_module(mod, tag):
     return sd
 
 
+def store_grads(out, tag, mod, inputs):
+    """Gradients after a backward: inputs whole; parameters whole up to 20000 elements, else l2 norm + 1024 evenly spaced elements."""
+    for k, x in inputs.items():
+        out[f"{tag}.dx.{k}"] = tnp(x.grad)
+    for name, prm in mod.named_parameters():
+        if prm.grad is None:
+            out[f"{tag}.gradnone.{name}"] = np.zeros(0, np.float32)
+        elif prm.numel() > 20000:
+            g = prm.grad.detach().double().reshape(-1)
+            idx = torch.linspace(0, g.numel() - 1, 1024).round().long()
+            out[f"{tag}.gradnorm.{name}"], out[f"{tag}.gradsample.{name}"] = np.float64(g.norm().item()), g[idx].numpy().astype(np.float32)
+        else:
+            out[f"{tag}.grad.{name}"] = tnp(prm.grad)
+
+
 def capture_side():
     out = {}
     B = 9
@@ -196,9 +211,13 @@ def capture_side():
          for i, k in enumerate(("audio", "video", "text"))}
     cma = ref_deer.CrossModalAttention(256, num_heads=8).eval()
     fill_module(cma, "cma")
-    with torch.no_grad():
-        wa, wv = cma(*(torch.from_numpy(x[k]) for k in ("audio", "video", "text")))
+    xt = {k: torch.from_numpy(x[k]).requires_grad_(True) for k in ("audio", "video", "text")}
+    wa, wv = cma(xt["audio"], xt["video"], xt["text"])
     out["cma.audio"], out["cma.video"] = tnp(wa), tnp(wv)
+    # backward of sum(wa * ca + wv * cv), ca / cv closed-form (synth.normal(520 / 521)): parameter and input gradients
+    ca, cv = (torch.from_numpy(synth.normal(520 + i, B * 32).reshape(B, 32).astype(np.float32)) for i in range(2))
+    ((wa * ca).sum() + (wv * cv).sum()).backward()
+    store_grads(out, "cma", cma, xt)
     for k in x:
         out["cma.in." + k] = x[k]
     hd = ref_deer.HierarchicalDEERFusion().eval()
@@ -222,8 +241,11 @@ def capture_side():
         import encoders as ref_enc  # (reference)
         enc = ref_enc.EnhancedAudioEncoder().eval()
     fill_module(enc, "aenc")
-    with torch.no_grad():
-        out["aenc.out"] = tnp(enc(torch.from_numpy(batch["audio"])))
+    xa = torch.from_numpy(batch["audio"]).requires_grad_(True)
+    y = enc(xa)
+    out["aenc.out"] = tnp(y)
+    (y * torch.from_numpy(synth.normal(530, y.numel()).reshape(y.shape).astype(np.float32))).sum().backward()
+    store_grads(out, "aenc", enc, {"audio": xa})
     return out
 
 
@@ -352,6 +374,10 @@ def capture_fusion_alt():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "side":
+        np.savez_compressed(os.path.join(HERE, "side_kernels.npz"), **capture_side())
+        print("side_kernels.npz", os.path.getsize(os.path.join(HERE, "side_kernels.npz")), "bytes")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fusion_alt":
         np.savez_compressed(os.path.join(HERE, "fusion_alt.npz"), **capture_fusion_alt())
         print("fusion_alt.npz", os.path.getsize(os.path.join(HERE, "fusion_alt.npz")), "bytes")

@@ -53,8 +53,8 @@ def test_cross_modal_attention_matches_golden(compute):
     wa, wv = m(cuda(g["cma.in.audio"]), cuda(g["cma.in.video"]), cuda(g["cma.in.text"]))
     assert wa.shape == (9, 32) and wv.shape == (9, 32)
     tol = dict(rtol=1e-4, atol=2e-6) if compute == "fp32" else dict(rtol=5e-2, atol=5e-3)
-    np.testing.assert_allclose(wa.cpu().numpy(), g["cma.audio"], **tol)
-    np.testing.assert_allclose(wv.cpu().numpy(), g["cma.video"], **tol)
+    np.testing.assert_allclose(wa.detach().cpu().numpy(), g["cma.audio"], **tol)
+    np.testing.assert_allclose(wv.detach().cpu().numpy(), g["cma.video"], **tol)
 
 
 def test_cross_modal_attention_matches_oracle_large_batch():
@@ -66,8 +66,8 @@ def test_cross_modal_attention_matches_oracle_large_batch():
     xs = [torch.from_numpy(synth.normal(synth._stream_of(f"cma2.in{i}"), B * 256).reshape(B, 256).astype(np.float32)) for i in range(3)]
     wa, wv = m(*(x.to("cuda:0") for x in xs))
     ra, rv = O.cross_modal_attention(P, *xs)
-    np.testing.assert_allclose(wa.cpu().numpy(), ra.numpy(), rtol=1e-4, atol=2e-6)
-    np.testing.assert_allclose(wv.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(wa.detach().cpu().numpy(), ra.numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(wv.detach().cpu().numpy(), rv.numpy(), rtol=1e-4, atol=2e-6)
     # empty batch
     ea, ev = m(*(x[:0].to("cuda:0") for x in xs))
     assert ea.shape == (0, 32) and ev.shape == (0, 32)
@@ -82,9 +82,9 @@ def test_modality_encoders_match_golden(compute):
     b = synth.make_batch(9, seed=77)
     ea, ev, et = m(cuda(b["audio"]), cuda(b["video"]), cuda(b["text"]))
     tol = dict(rtol=1e-4, atol=2e-6) if compute == "fp32" else dict(rtol=5e-2, atol=2e-2)
-    np.testing.assert_allclose(ea.float().cpu().numpy(), g["hdf.audio_encoded"], **tol)
-    np.testing.assert_allclose(ev.float().cpu().numpy(), g["hdf.video_encoded"], **tol)
-    np.testing.assert_allclose(et.float().cpu().numpy(), g["hdf.text_encoded"], **tol)
+    np.testing.assert_allclose(ea.float().detach().cpu().numpy(), g["hdf.audio_encoded"], **tol)
+    np.testing.assert_allclose(ev.float().detach().cpu().numpy(), g["hdf.video_encoded"], **tol)
+    np.testing.assert_allclose(et.float().detach().cpu().numpy(), g["hdf.text_encoded"], **tol)
 
 
 @pytest.mark.parametrize("compute", ["fp32", "bf16"])
@@ -97,7 +97,7 @@ def test_audio_encoder_feature_branch_matches_golden(compute):
     out = m(cuda(b["audio"]))
     assert out.shape == (9, 512) and out.dtype == torch.float32
     tol = dict(rtol=1e-3, atol=2e-5) if compute == "fp32" else dict(rtol=1e-1, atol=8e-2)
-    np.testing.assert_allclose(out.cpu().numpy(), g["aenc.out"], **tol)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["aenc.out"], **tol)
     # (B, 1, 84) is the same path
     out3 = m(cuda(b["audio"]).unsqueeze(1))
     assert torch.equal(out3, out)
@@ -119,7 +119,7 @@ def test_audio_encoder_matches_oracle_and_state_dict_names():
     x = torch.from_numpy(synth.normal(synth._stream_of("aenc3.x"), B * 84).reshape(B, 84).astype(np.float32))
     out = m(x.to("cuda:0"))
     ref = O.audio_encoder_features(P, x)
-    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), rtol=1e-3, atol=2e-5)
 
 
 def test_side_rows_reject_what_they_do_not_cover():
@@ -132,3 +132,85 @@ def test_side_rows_reject_what_they_do_not_cover():
         side.CrossModalAttention(128, 4)
     with pytest.raises(RuntimeError):
         side.ModalityEncoders()(torch.zeros(2, 84), torch.zeros(2, 256), torch.zeros(2, 768))   # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------------- backward (a8, a14)
+def test_cross_modal_attention_backward_matches_golden_and_oracle():
+    from tests.test_oracle_golden import check_side_grads, side_loss_weights
+    g = _golden()
+    m = side.CrossModalAttention(256, 8)
+    _fill(m, "cma")
+    m = m.to("cuda:0")
+    xs = {k: cuda(g["cma.in." + k]).requires_grad_(True) for k in ("audio", "video", "text")}
+    wa, wv = m(xs["audio"], xs["video"], xs["text"])
+    ca, cv = (c.cuda() for c in side_loss_weights("cma"))
+    ((wa * ca).sum() + (wv * cv).sum()).backward()
+    check_side_grads(g, "cma", {n: p.grad for n, p in m.named_parameters()}, {k: v.grad for k, v in xs.items()}, rtol=2e-3, atol_frac=2e-3)
+    # other parameters, ragged batch, only ONE of the two outputs used downstream
+    O = _oracle()
+    m2 = side.CrossModalAttention(256, 8)
+    P = _fill(m2, "cma3")
+    m2 = m2.to("cuda:0")
+    B = 131
+    xn = [synth.normal(synth._stream_of(f"cma3.in{i}"), B * 256).reshape(B, 256).astype(np.float32) for i in range(3)]
+    xg = [cuda(x).requires_grad_(True) for x in xn]
+    m2(*xg)[1].square().sum().backward()
+    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xo = [torch.from_numpy(x).requires_grad_(True) for x in xn]
+    O.cross_modal_attention(Po, *xo)[1].square().sum().backward()
+    for n, p in m2.named_parameters():
+        if Po[n].grad is None:
+            assert p.grad is None, n
+            continue
+        ref = Po[n].grad.numpy()
+        np.testing.assert_allclose(p.grad.detach().cpu().numpy(), ref, rtol=3e-3, atol=3e-3 * max(float(np.abs(ref).max()), 1e-12), err_msg=n)
+    for a, b in zip(xg, xo):
+        np.testing.assert_allclose(a.grad.detach().cpu().numpy(), b.grad.numpy(), rtol=3e-3, atol=3e-3 * float(b.grad.abs().max()))
+
+
+def test_audio_encoder_backward_matches_golden_and_trains():
+    from tests.test_oracle_golden import check_side_grads, side_loss_weights
+    g = _golden()
+    m = side.EnhancedAudioEncoder()
+    _fill(m, "aenc")
+    m = m.to("cuda:0").eval()
+    x = cuda(synth.make_batch(9, seed=77)["audio"]).requires_grad_(True)
+    y = m(x)
+    (y * side_loss_weights("aenc")[0].cuda()).sum().backward()
+    grads = {n: p.grad for n, p in m.named_parameters()}
+    check_side_grads(g, "aenc", grads, {"audio": x.grad}, rtol=3e-3, atol_frac=3e-3)
+    # the parameters that T = 1 never reaches get exact zeros, as in the reference (not None: AdamW's weight decay still applies)
+    for n in ("lstm.weight_hh_l0", "lstm.weight_hh_l1_reverse", "attention.0.weight", "attention.2.bias"):
+        assert grads[n] is not None and not float(grads[n].abs().max()), n
+    # training mode: inter-layer LSTM dropout and the output projection's dropout are live; a few SGD steps lower a regression loss
+    m.train()
+    xs = cuda(synth.make_batch(64, seed=5)["audio"])
+    tgt = cuda(synth.normal(77, 64 * 512).reshape(64, 512).astype(np.float32))
+    assert not torch.equal(m(xs), m(xs))
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    losses = []
+    for _ in range(10):
+        opt.zero_grad(set_to_none=True)
+        loss = (m(xs) - tgt).square().mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+
+
+def test_audio_encoder_bf16_gradients_track_fp32():
+    x = synth.make_batch(128, seed=8)["audio"]
+    res = {}
+    for compute in ("fp32", "bf16"):
+        m = side.EnhancedAudioEncoder(compute_dtype=compute)
+        _fill(m, "aenc")
+        m = m.to("cuda:0").eval()
+        m(cuda(x)).square().mean().backward()
+        res[compute] = {n: p.grad.double().flatten() for n, p in m.named_parameters()}
+    for n, a in res["fp32"].items():
+        b = res["bf16"][n]
+        if not float(a.norm()):
+            assert not float(b.norm()), n
+            continue
+        assert float((a @ b) / (a.norm() * b.norm())) > 0.97, n

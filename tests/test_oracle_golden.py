@@ -353,3 +353,86 @@ def test_alternative_fusions(golden_dir, tag):
         np.testing.assert_allclose(extra["strategy_weights"].detach().numpy(), g["adaptive.strategy_weights"], rtol=2e-5, atol=1e-6)
     (y * torch.from_numpy(c)).sum().backward()
     check_fusion_alt_grads(g, tag, {k: v.grad for k, v in P.items()}, [x.grad for x in xs], rtol=2e-4, atol_frac=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------- side rows: backward (a8, a14)
+def side_shapes(tag):
+    """state_dict shapes of deer.CrossModalAttention(256, 8) ('cma') / encoders.EnhancedAudioEncoder() ('aenc')."""
+    lin = lambda n, o, i: {n + ".weight": (o, i), n + ".bias": (o,)}     # noqa: E731
+    shapes = {}
+    if tag == "cma":
+        for n in ("query_proj", "key_proj", "value_proj", "output_proj"):
+            shapes.update(lin(n, 256, 256))
+        shapes.update(lin("uncertainty_gate.0", 256, 768)); shapes.update(lin("uncertainty_gate.2", 2, 256))
+        return shapes
+    for l, inp in ((0, 84), (1, 512)):
+        for sfx in ("", "_reverse"):
+            shapes[f"lstm.weight_ih_l{l}{sfx}"] = (1024, inp)
+            shapes[f"lstm.weight_hh_l{l}{sfx}"] = (1024, 256)
+            shapes[f"lstm.bias_ih_l{l}{sfx}"] = (1024,)
+            shapes[f"lstm.bias_hh_l{l}{sfx}"] = (1024,)
+    shapes.update(lin("attention.0", 256, 512)); shapes.update(lin("attention.2", 1, 256))
+    shapes.update(lin("output_projection.0", 512, 512)); shapes.update(lin("output_projection.3", 512, 512))
+    shapes.update({"output_projection.4.weight": (512,), "output_projection.4.bias": (512,)})
+    return shapes
+
+
+def synth_state(golden_dir, tag):
+    return {k: torch.from_numpy(v) for k, v in synth.module_fill(tag, side_shapes(tag)).items()}
+
+
+def check_side_grads(g, tag, grads, dxs, rtol, atol_frac):
+    """Gradients of case `tag` ('cma' / 'aenc') against tests/golden/side_kernels.npz.  A golden zero tensor (recurrent weights at
+    T = 1, the attention pool over one step) accepts None or zeros; a golden None (CrossModalAttention.output_proj) needs None."""
+    seen = 0
+    for k in g:
+        if not k.startswith(tag + "."):
+            continue
+        kind, _, name = k[len(tag) + 1:].partition(".")
+        if kind == "grad":
+            ref = g[k]
+            if not np.abs(ref).max():
+                assert grads.get(name) is None or not float(grads[name].abs().max()), k
+            else:
+                np.testing.assert_allclose(grads[name].detach().cpu().numpy(), ref, rtol=rtol, atol=atol_frac * float(np.abs(ref).max()), err_msg=k)
+        elif kind == "gradnorm":
+            if float(g[k]) == 0.0:
+                assert grads.get(name) is None or not float(grads[name].abs().max()), k
+            else:
+                v = grads[name].detach().double().cpu().reshape(-1)
+                assert float(v.norm()) == pytest.approx(float(g[k]), rel=rtol), k
+                ref = g[f"{tag}.gradsample.{name}"]
+                idx = torch.linspace(0, v.numel() - 1, 1024).round().long()
+                np.testing.assert_allclose(v[idx].numpy(), ref, rtol=rtol, atol=atol_frac * float(np.abs(ref).max()), err_msg=k)
+        elif kind == "gradnone":
+            assert grads.get(name) is None, k
+        elif kind == "dx":
+            np.testing.assert_allclose(dxs[name].detach().cpu().numpy(), g[k], rtol=rtol, atol=atol_frac * float(np.abs(g[k]).max()), err_msg=k)
+        else:
+            continue
+        seen += 1
+    assert seen >= 10, (tag, seen)
+
+
+def side_loss_weights(tag, B=9):
+    """The closed-form loss weights of the golden backward passes (make_golden.py: capture_side)."""
+    if tag == "cma":
+        return [torch.from_numpy(synth.normal(520 + i, B * 32).reshape(B, 32).astype(np.float32)) for i in range(2)]
+    return [torch.from_numpy(synth.normal(530, B * 512).reshape(B, 512).astype(np.float32))]
+
+
+def test_side_rows_backward(golden_dir):
+    """CrossModalAttention (deer.py:379-425) and the EnhancedAudioEncoder feature branch (encoders.py:356-389): parameter and
+    input gradients of the imported reference against the oracle's autograd."""
+    g = _load(golden_dir, "side_kernels.npz")
+    P = {k: v.requires_grad_(True) for k, v in synth_state(golden_dir, "cma").items()}
+    xs = {k: torch.from_numpy(g["cma.in." + k]).requires_grad_(True) for k in ("audio", "video", "text")}
+    wa, wv = O.cross_modal_attention(P, xs["audio"], xs["video"], xs["text"])
+    ca, cv = side_loss_weights("cma")
+    ((wa * ca).sum() + (wv * cv).sum()).backward()
+    check_side_grads(g, "cma", {k: v.grad for k, v in P.items()}, {k: v.grad for k, v in xs.items()}, rtol=2e-4, atol_frac=2e-5)
+    P = {k: v.requires_grad_(True) for k, v in synth_state(golden_dir, "aenc").items()}
+    x = torch.from_numpy(synth.make_batch(9, seed=77)["audio"]).requires_grad_(True)
+    y = O.audio_encoder_features(P, x)
+    (y * side_loss_weights("aenc")[0]).sum().backward()
+    check_side_grads(g, "aenc", {k: v.grad for k, v in P.items()}, {"audio": x.grad}, rtol=3e-4, atol_frac=3e-5)

@@ -190,6 +190,8 @@ SYMBOLS = [
     ("mmdeer_stackb_attn_mix_train_fwd", c_int, [C.POINTER(StackBAttnTrainArgs)]),
     ("mmdeer_stackb_attn_mix_bwd", c_int, [C.POINTER(StackBAttnTrainArgs)]),
     ("mmdeer_stackb_gate_mix_bwd", c_int, [c_void_p, c_int] * 7 + [c_int, c_int, c_int, c_void_p]),
+    ("mmdeer_cross_modal_attn_bwd", c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 9 + [c_int, c_int, c_void_p]),
+    ("mmdeer_lstm_cell_t1_bwd", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("mmdeer_softmax_mix_fwd", c_int, [C.POINTER(SoftmaxMixArgs)]),
     ("mmdeer_softmax_mix_bwd", c_int, [C.POINTER(SoftmaxMixArgs)]),
     ("mmdeer_outer_fwd", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

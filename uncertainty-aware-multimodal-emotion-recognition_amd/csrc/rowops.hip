@@ -216,11 +216,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dout, const voi
         const int c = lane * 4 + i * 256;
         if (EXACT || c < N) {
           const f32x4 dy = (gd[i] - m1 - xh[i] * m2) * rs[r];
-          f32x4 o;
-          o.x = yv[r][i].x > 0.f ? dy.x * mask_scale : 0.f;
-          o.y = yv[r][i].y > 0.f ? dy.y * mask_scale : 0.f;
-          o.z = yv[r][i].z > 0.f ? dy.z * mask_scale : 0.f;
-          o.w = yv[r][i].w > 0.f ? dy.w * mask_scale : 0.f;
+          f32x4 o = dy;      // mask_scale <= 0: a LayerNorm behind a plain Linear (no ReLU / dropout below it)
+          if (mask_scale > 0.f) {
+            o.x = yv[r][i].x > 0.f ? dy.x * mask_scale : 0.f;
+            o.y = yv[r][i].y > 0.f ? dy.y * mask_scale : 0.f;
+            o.z = yv[r][i].z > 0.f ? dy.z * mask_scale : 0.f;
+            o.w = yv[r][i].w > 0.f ? dy.w * mask_scale : 0.f;
+          }
           store4<F32>(dz, base + c, o);
         }
       }

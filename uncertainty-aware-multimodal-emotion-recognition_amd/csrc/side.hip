@@ -28,6 +28,21 @@ __device__ __forceinline__ float ld1(const void* base, long long idx) {
   else return bf2f(reinterpret_cast<const bf16_t*>(base)[idx]);
 }
 
+template <bool F32>
+__device__ __forceinline__ void store4(void* base, long long idx, f32x4 v) {
+  if constexpr (F32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
+  } else {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16_t*>(base) + idx) = u32x2_t{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void st1(void* base, long long idx, float v) {
+  if constexpr (F32) reinterpret_cast<float*>(base)[idx] = v;
+  else reinterpret_cast<bf16_t*>(base)[idx] = f2bf(v);
+}
+
 __device__ __forceinline__ float xor_sum(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float xor_max(float v, int mask) { return fmaxf(v, __shfl_xor(v, mask, 64)); }
 
@@ -86,6 +101,81 @@ __global__ __launch_bounds__(256) void lstm_cell_t1_kernel(const void* gates, in
     const float h = sigmoidf_(go) * tanhf(c);
     if constexpr (F32) reinterpret_cast<float*>(out)[(long long)b * ld_o + r] = h;
     else reinterpret_cast<bf16_t*>(out)[(long long)b * ld_o + r] = f2bf(h);
+  }
+}
+
+// backward of cross_modal_attn_kernel: same lane layout, softmaxes recomputed.  out_m = gate_m * sum_h p_mh v_mh
+template <bool F32>
+__global__ __launch_bounds__(256) void cross_modal_attn_bwd_kernel(const void* q, const void* ka, const void* va, const void* kv, const void* vv,
+                                                                   int ld, const float* gate_logits, const float* g_a, const float* g_v,
+                                                                   void* dq, void* dka, void* dva, void* dkv, void* dvv, float* dgl, int B) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const long long o = (long long)b * ld + lane * 4;
+  const f32x4 qv = ld4<F32>(q, o);
+  const float g0 = gate_logits[2 * b], g1 = gate_logits[2 * b + 1];
+  const float gm = fmaxf(g0, g1), e0 = expf(g0 - gm), e1 = expf(g1 - gm);
+  const float gate[2] = {e0 / (e0 + e1), e1 / (e0 + e1)};
+  const void* ks[2] = {ka, kv};
+  const void* vs[2] = {va, vv};
+  void* dks[2] = {dka, dkv};
+  void* dvs[2] = {dva, dvv};
+  const float* gs[2] = {g_a, g_v};
+  const float inv = 0.17677669529663687f;
+  f32x4 dqv{0.f, 0.f, 0.f, 0.f};
+  float dgate[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const f32x4 kk = ld4<F32>(ks[m], o), vw = ld4<F32>(vs[m], o);
+    float s = qv.x * kk.x + qv.y * kk.y + qv.z * kk.z + qv.w * kk.w;
+    s = xor_sum(xor_sum(xor_sum(s, 1), 2), 4) * inv;
+    const float mx = xor_max(xor_max(xor_max(s, 8), 16), 32);
+    const float e = expf(s - mx);
+    const float p = e / xor_sum(xor_sum(xor_sum(e, 8), 16), 32);
+    f32x4 c{p * vw.x, p * vw.y, p * vw.z, p * vw.w};
+#pragma unroll
+    for (int sh = 8; sh < 64; sh <<= 1) {
+      c.x = xor_sum(c.x, sh); c.y = xor_sum(c.y, sh); c.z = xor_sum(c.z, sh); c.w = xor_sum(c.w, sh);
+    }
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gs[m] + (long long)b * 32 + (lane & 7) * 4);   // the 8 heads read the same 4 dims
+    // d gate_m = sum over the 32 dims of g c (every head group holds the same c: sum one of them)
+    float dgm = g.x * c.x + g.y * c.y + g.z * c.z + g.w * c.w;
+    dgate[m] = xor_sum(xor_sum(xor_sum(dgm, 1), 2), 4);
+    const f32x4 dc = g * gate[m];
+    store4<F32>(dvs[m], o, dc * p);                                     // d v_h = p_h dc
+    float dp = dc.x * vw.x + dc.y * vw.y + dc.z * vw.z + dc.w * vw.w;   // d p_h = dc . v_h over the head's 32 dims
+    dp = xor_sum(xor_sum(xor_sum(dp, 1), 2), 4);
+    const float dot = xor_sum(xor_sum(xor_sum(p * dp, 8), 16), 32);    // softmax over the heads
+    const float ds = p * (dp - dot) * inv;
+    store4<F32>(dks[m], o, qv * ds);
+    dqv += kk * ds;
+  }
+  store4<F32>(dq, o, dqv);
+  if (lane == 0) {
+    const float dot = gate[0] * dgate[0] + gate[1] * dgate[1];
+    dgl[2 * b] = gate[0] * (dgate[0] - dot);
+    dgl[2 * b + 1] = gate[1] * (dgate[1] - dot);
+  }
+}
+
+// backward of lstm_cell_t1_kernel: h = sigmoid(o) tanh(c), c = sigmoid(i) tanh(g)
+template <bool F32>
+__global__ __launch_bounds__(256) void lstm_cell_t1_bwd_kernel(const void* gates, int ld_g, const void* dout, int ld_o, void* dgates, int B, int H,
+                                                               int ndir) {
+  const long long total = (long long)B * ndir * H;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += gridDim.x * 256ll) {
+    const int b = (int)(e / (ndir * H)), r = (int)(e - (long long)b * ndir * H);
+    const int d = r / H, j = r - d * H;
+    const long long g0 = (long long)b * ld_g + (long long)d * 4 * H + j;
+    const float gi = ld1<F32>(gates, g0), gg = ld1<F32>(gates, g0 + 2 * H), go = ld1<F32>(gates, g0 + 3 * H);
+    const float si = sigmoidf_(gi), tg = tanhf(gg), so = sigmoidf_(go);
+    const float c = si * tg, tc = tanhf(c);
+    const float dh = ld1<F32>(dout, (long long)b * ld_o + r);
+    const float dc = dh * so * (1.f - tc * tc);
+    st1<F32>(dgates, g0, dc * tg * si * (1.f - si));
+    st1<F32>(dgates, g0 + H, 0.f);
+    st1<F32>(dgates, g0 + 2 * H, dc * si * (1.f - tg * tg));
+    st1<F32>(dgates, g0 + 3 * H, dh * tc * so * (1.f - so));
   }
 }
 
@@ -253,6 +343,44 @@ int mmdeer_cross_modal_attn_fwd(const void* q, const void* k_audio, const void* 
   else
     hipLaunchKernelGGL(cross_modal_attn_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q, k_audio, v_audio, k_video,
                        v_video, ld, gate_logits, out_audio, out_video, B);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int mmdeer_cross_modal_attn_bwd(const void* q, const void* k_audio, const void* v_audio, const void* k_video, const void* v_video,
+                                int ld, const float* gate_logits, const float* g_audio, const float* g_video, void* dq, void* dk_audio,
+                                void* dv_audio, void* dk_video, void* dv_video, float* dgate_logits, int B, int act_f32, void* stream) {
+  MMDEER_CHECK(B >= 0, "cross_modal_attn_bwd: batch must be >= 0 (got %d)", B);
+  if (B == 0) return 0;
+  MMDEER_CHECK(q && k_audio && v_audio && k_video && v_video && gate_logits && g_audio && g_video && dq && dk_audio && dv_audio && dk_video &&
+               dv_video && dgate_logits, "cross_modal_attn_bwd: NULL pointer");
+  MMDEER_CHECK(ld >= 256 && ld % 4 == 0, "cross_modal_attn_bwd: ld=%d must be >= 256 and a multiple of 4", ld);
+  const dim3 grid((B + 3) / 4);
+  if (act_f32)
+    hipLaunchKernelGGL(cross_modal_attn_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q, k_audio, v_audio, k_video, v_video, ld,
+                       gate_logits, g_audio, g_video, dq, dk_audio, dv_audio, dk_video, dv_video, dgate_logits, B);
+  else
+    hipLaunchKernelGGL(cross_modal_attn_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q, k_audio, v_audio, k_video, v_video, ld,
+                       gate_logits, g_audio, g_video, dq, dk_audio, dv_audio, dk_video, dv_video, dgate_logits, B);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+int mmdeer_lstm_cell_t1_bwd(const void* gates, int ld_gates, const void* dout, int ld_dout, void* dgates, int B, int hidden, int ndir,
+                            int act_f32, void* stream) {
+  MMDEER_CHECK(B >= 0 && hidden > 0 && (ndir == 1 || ndir == 2), "lstm_cell_t1_bwd: bad shape B=%d hidden=%d ndir=%d", B, hidden, ndir);
+  if (B == 0) return 0;
+  MMDEER_CHECK(gates && dout && dgates, "lstm_cell_t1_bwd: NULL pointer");
+  MMDEER_CHECK(ld_gates >= ndir * 4 * hidden && ld_dout >= ndir * hidden, "lstm_cell_t1_bwd: leading dimensions too small");
+  const long long total = (long long)B * ndir * hidden;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (act_f32)
+    hipLaunchKernelGGL(lstm_cell_t1_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gates, ld_gates, dout, ld_dout,
+                       dgates, B, hidden, ndir);
+  else
+    hipLaunchKernelGGL(lstm_cell_t1_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gates, ld_gates, dout, ld_dout,
+                       dgates, B, hidden, ndir);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
