@@ -130,6 +130,12 @@ def test_interface_and_error_behaviour():
     assert tuple(o["fused_features"].shape) == (4, 256) and tuple(o["strategy_weights"].shape) == (4, 2)
     with pytest.raises(RuntimeError, match="cannot be multiplied"):
         fusions.AttentionFusion(DIMS, 256).to("cuda:0")([xs[0], xs[0], xs[2]])
+    # empty batch: forward and backward run, gradients are zeros
+    att = fusions.AttentionFusion(DIMS, 256).to("cuda:0")
+    e = att([x[:0] for x in xs])
+    assert tuple(e.shape) == (0, 256)
+    e.sum().backward()
+    assert all(p.grad is not None and not float(p.grad.abs().sum()) for p in att.parameters())
     one = fusions.BilinearFusion([256], 128).to("cuda:0")
     assert tuple(one([xs[1]]).shape) == (4, 128)
     assert isinstance(create_fusion_module("hierarchical", {"audio_dim": 84, "video_dim": 256, "text_dim": 768}), torch.nn.Module)

@@ -21,7 +21,7 @@ for name in ("bench_b4096_bf16.json", "bench_b8192_bf16.json", "bench_b1024_fp32
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
         print("copied", name)
-stats = glob.glob(os.path.join(src, "prof", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "prof", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)   # newest run
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
     line = json.load(open(os.path.join(src, "bench_b4096_bf16.json")))

@@ -70,6 +70,8 @@ class Exec:
 
     def dw(self, dy, ldy_, x, ldx, gw, gb, M, N, K):
         """gw (N, K) fp32 = dy^T x, gb (N,) = column sums of dy; dy: (M, N) view, x: (M, K) view."""
+        if M == 0:                       # empty batch: the sums are the zeros the caller allocated
+            return gw
         if M * min(ldy_, ldx) < 8:       # an operand below the GEMM's 8-element minimum (M = 1, a 4-wide matrix): append a zero row
             d2, x2 = torch.zeros(M + 1, N, dtype=dy.dtype, device=dy.device), torch.zeros(M + 1, K, dtype=x.dtype, device=x.device)
             d2[:M].copy_(dy[:M, :N]); x2[:M].copy_(x[:M, :K])
