@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 11
+#define MMDEER_ABI_VERSION 12
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -183,6 +183,7 @@ typedef struct mmdeer_gemm_args {
   int32_t drop_site, drop_shift, regen_site;
   float dropout_p, mask_scale;
   uint64_t seed, offset;
+  const uint64_t* offset_dev; /* optional device counter added to `offset` when the kernel runs (HIP-graph replays draw fresh masks) */
   /* split-K (weight-gradient shapes: few output tiles, long reduction): splitk > 1 reduces K in slices whose fp32
    * partials go to `slab` (splitk * (M*N + M) floats, rounded up to a multiple of 4 per slice) and are then
    * summed in a fixed order; needs an fp32 C and no epilogue. */
@@ -416,6 +417,7 @@ typedef struct mmdeer_stackb_attn_train_args {
   int32_t training, drop_site;    /* weight_network.2 dropout: keep mask = hash(seed, offset, drop_site, row, col) */
   float dropout_p;
   uint64_t seed, offset;
+  const uint64_t* offset_dev;     /* optional device counter added to `offset` (NULL: offset alone) */
   void* stream;
 } mmdeer_stackb_attn_train_args;
 int mmdeer_stackb_attn_mix_train_fwd(const mmdeer_stackb_attn_train_args* a);

@@ -77,7 +77,7 @@ class GemmArgs(C.Structure):
         ("a_f32", c_int), ("w_f32", c_int), ("c_f32", c_int), ("y_f32", c_int), ("trans_a", c_int), ("trans_w", c_int),
         ("relu", c_int), ("accumulate", c_int), ("compute_f32", c_int), ("tile", c_int),
         ("drop_site", c_int), ("drop_shift", c_int), ("regen_site", c_int),
-        ("dropout_p", c_float), ("mask_scale", c_float), ("seed", c_u64), ("offset", c_u64),
+        ("dropout_p", c_float), ("mask_scale", c_float), ("seed", c_u64), ("offset", c_u64), ("offset_dev", c_void_p),
         ("splitk", c_int), ("slab", c_void_p), ("debug", c_void_p), ("stream", c_void_p),
     ]
 
@@ -110,7 +110,7 @@ class StackBAttnTrainArgs(C.Structure):
         ("d_logits8", c_void_p), ("d_z8", c_void_p), ("d_h2", c_void_p),
         ("ld_w1_unc", c_int), ("ld_av", c_int), ("ld_text", c_int), ("B", c_int), ("act_f32", c_int),
         ("training", c_int), ("drop_site", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
-        ("stream", c_void_p),
+        ("offset_dev", c_void_p), ("stream", c_void_p),
     ]
 
 
@@ -237,7 +237,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 11:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 12:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         _LIB = lib
     return _LIB

@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void add_masked_kernel(void* out, int ld_o, co
   }
 }
 
-DropCtx make_drop_(float p, uint64_t seed, uint64_t offset) {
+DropCtx make_drop_(float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev) {
   DropCtx d{};
-  d.seed = seed; d.offset = offset; d.offset_dev = nullptr;
+  d.seed = seed; d.offset = offset; d.offset_dev = reinterpret_cast<const unsigned long long*>(offset_dev);
   double keep = 1.0 - (double)p;
   if (keep < 0) keep = 0;
   const double t = keep * 4294967296.0;
@@ -238,7 +238,7 @@ extern "C" {
 int mmdeer_stackb_attn_mix_train_fwd(const mmdeer_stackb_attn_train_args* p) {
   if (check_attn(p, false) != 0) return -1;
   if (p->B == 0) return 0;
-  const DropCtx dc = make_drop_(p->dropout_p, p->seed, p->offset);
+  const DropCtx dc = make_drop_(p->dropout_p, p->seed, p->offset, p->offset_dev);
   const int on = (p->training && p->dropout_p > 0.f) ? 1 : 0;
   const dim3 grid((p->B + 3) / 4);
   if (p->act_f32) hipLaunchKernelGGL(attn_mix_train_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)p->stream, *p, dc, on);

@@ -21,6 +21,7 @@ class Exec:
     """One training step's launches.  ``drop``: (p_config, seed, step) or None (no dropout anywhere)."""
 
     def __init__(self, compute_dtype: str, drop=None):
+        """drop: None (no dropout anywhere) or (p_config, seed, step[, device int64 counter tensor added to step on the device])."""
         self.f32 = int(compute_dtype == "fp32")
         self.dt = torch.float32 if self.f32 else torch.bfloat16
         self.drop = drop
@@ -29,7 +30,7 @@ class Exec:
 
     # ---- operator wrappers ------------------------------------------------------------------------------------------
     def gemm(self, A, W, Cm, M, N, K, lda, ldw, ldc, *, bias=None, relu=0, ta=0, tw=0, Y=None, ldy=0, mask_scale=1.0, bias_grad=None,
-             drop_site=-1, drop_shift=0, regen_site=-1, p=0.0):
+             drop_site=-1, drop_shift=0, regen_site=-1, p=0.0, splitk=1):
         if M == 0 or N == 0:
             return Cm
         a = _lib.GemmArgs()
@@ -44,7 +45,13 @@ class Exec:
         a.mask_scale = mask_scale
         if self.drop is not None:
             a.dropout_p, a.seed, a.offset = p, self.drop[1], self.drop[2]
+            if len(self.drop) > 3 and self.drop[3] is not None:
+                a.offset_dev = self.drop[3].data_ptr()          # device counter added to the offset (HIP-graph replays)
         a.stream = self.s
+        slab = None
+        if splitk > 1 and Cm.dtype == torch.float32 and Cm.is_contiguous():
+            slab = torch.empty(splitk * ((M * N + M + 3) // 4 * 4), dtype=torch.float32, device=Cm.device)
+            a.splitk, a.slab = splitk, slab.data_ptr()
         _lib.check(self.lib.mmdeer_gemm(C.byref(a)))
         return Cm
 
@@ -76,7 +83,10 @@ class Exec:
             d2, x2 = torch.zeros(M + 1, N, dtype=dy.dtype, device=dy.device), torch.zeros(M + 1, K, dtype=x.dtype, device=x.device)
             d2[:M].copy_(dy[:M, :N]); x2[:M].copy_(x[:M, :K])
             dy, ldy_, x, ldx, M = d2, N, x2, K, M + 1
-        return self.gemm(dy, x, gw, N, K, M, ldy_, ldx, gw.stride(0), ta=1, tw=1, bias_grad=gb)
+        # few output tiles, deep reduction over the batch: split it into K-slices (fp32 slabs, folded by the library in index order)
+        tiles = ((N + 255) // 256) * ((K + 255) // 256)
+        splitk = max(1, min(16, 256 // tiles, M // 256))
+        return self.gemm(dy, x, gw, N, K, M, ldy_, ldx, gw.stride(0), ta=1, tw=1, bias_grad=gb, splitk=splitk)
 
     def ln_fwd(self, y, gamma, beta):
         M, N = y.shape

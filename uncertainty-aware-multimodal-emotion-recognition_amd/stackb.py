@@ -148,6 +148,7 @@ class CompleteDEERModel(nn.Module):
         self._initialize_weights()
         self._packed = None
         self._train_step = 0          # dropout counter: one tick per training forward
+        self._drop_counter = None     # device-side addend of the counter (int64[1]), created by capture_train_step
 
     def _initialize_weights(self) -> None:
         """Xavier-uniform Linear weights, zero biases, unit LayerNorm (complete_project.py:503-513)."""
@@ -252,7 +253,9 @@ class CompleteDEERModel(nn.Module):
         xs = [x.detach().float().contiguous() for x in xs]
         drop = None
         if dropout:
-            drop = (self.config.dropout, int(self.config.dropout_seed), self._train_step)
+            # mask key = hash(seed, step + *device counter, site, row, column): the host step advances per eager forward, the device
+            # counter per replay of a captured step (capture_train_step)
+            drop = (self.config.dropout, int(self.config.dropout_seed), self._train_step, self._drop_counter)
             self._train_step += 1
         names = [n for n, _ in self.named_parameters()]
         core, tape = _StackBFn.apply(self, xs, drop, names, *[p for _, p in self.named_parameters()])
@@ -282,6 +285,57 @@ class CompleteDEERModel(nn.Module):
         finally:
             self.train(was)
         return loss
+
+    def capture_train_step(self, audio, video, text, targets, optimizer: Optional[torch.optim.Optimizer] = None, max_grad_norm: Optional[float] = None):
+        """Capture forward (dropout live) + ``compute_loss`` + backward (+ ``clip_grad_norm_`` + ``optimizer.step()`` when an optimiser
+        built with ``capturable=True`` is given) for this batch shape as ONE HIP graph: the ~150 operator launches and the autograd
+        bookkeeping replay without host work.  Returns ``replay(audio, video, text, targets) -> loss dict`` (static tensors: clone what
+        must outlive the next replay); ``.grad`` of the parameters are the graph's static gradient buffers.  Every replay draws fresh
+        dropout masks: a device counter, bumped inside the graph, is added to the step the library hashes."""
+        dev = audio.device
+        static = [x.detach().float().contiguous().clone() for x in (audio, video, text, targets)]
+        if self._drop_counter is None or self._drop_counter.device != dev:
+            self._drop_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        was = self.training
+        self.train()
+
+        def step():
+            self._drop_counter.add_(1)
+            loss = self.compute_loss(self(*static[:3]), static[3])
+            loss["total_loss"].backward()
+            if optimizer is not None:
+                if max_grad_norm is not None:
+                    torch.nn.utils.clip_grad_norm_(self.parameters(), max_grad_norm)
+                optimizer.step()
+            return loss
+
+        if optimizer is not None:
+            optimizer.zero_grad(set_to_none=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                                # warm-up: library load, allocator pools, optimiser state
+                for p in self.parameters():
+                    p.grad = None
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        for p in self.parameters():
+            p.grad = None
+        frozen_step = self._train_step                          # the host counter baked into the graph
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = step()
+        self.train(was)
+
+        def replay(a=None, v=None, t=None, y=None):
+            for dst, src in zip(static, (a, v, t, y)):
+                if src is not None:
+                    dst.copy_(src, non_blocking=True)
+            graph.replay()
+            return loss
+
+        replay.graph, replay.static_inputs, replay.loss, replay.frozen_step = graph, static, loss, frozen_step
+        return replay
 
     def _forward_eval(self, audio_features, video_features, text_features) -> Dict[str, torch.Tensor]:
         cfg = self.config

@@ -124,6 +124,8 @@ def forward_train(model, xs: List[torch.Tensor], drop) -> Dict:
     a.training, a.drop_site, a.dropout_p = int(drop is not None), SITE_WN, ex.p_of(pc)
     if drop is not None:
         a.seed, a.offset = drop[1], drop[2]
+        if len(drop) > 3 and drop[3] is not None:
+            a.offset_dev = drop[3].data_ptr()
     a.stream = ex.s
     if B:
         _lib.check(ex.lib.mmdeer_stackb_attn_mix_train_fwd(C.byref(a)))
@@ -174,7 +176,20 @@ def backward(model, T: Dict, g4: torch.Tensor) -> Dict[str, torch.Tensor]:
     pc = cfg.dropout
     dev = g4.device
     new = lambda *s, d=None: torch.empty(*s, dtype=d or dt, device=dev)
-    z32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+    # every fp32 gradient / scratch matrix of the pass is a slice of ONE zeroed buffer (one memset instead of ~100)
+    pool = torch.zeros(sum(p.numel() for p in model.parameters()) + (1 << 20), dtype=torch.float32, device=dev)
+    cursor = [0]
+
+    def z32(*shape):
+        n = 1
+        for d in shape:
+            n *= d
+        lo = cursor[0]
+        cursor[0] = (lo + n + 63) // 64 * 64                       # 256-byte aligned slices
+        if cursor[0] > pool.numel():
+            return torch.zeros(*shape, dtype=torch.float32, device=dev)
+        return pool[lo:lo + n].view(*shape)
+
     G: Dict[str, torch.Tensor] = {}
     sc = ex.scale_of(pc)
 
