@@ -520,12 +520,166 @@ def to_params(state: Dict[str, "torch.Tensor"], dtype=torch.float32, requires_gr
     return P
 
 
-def train_step(P, audio, video, text, targets, masks=None, p=0.3, heads=8):
+# --------------------------------------------------------------------------- bf16 storage emulation
+# The bf16 compute path of the HIP kernels keeps fp32 accumulators and fp32 parameters / vectors but STORES packed weight
+# matrices, activations and activation-gradients as bf16.  The functions below restate the same arithmetic (the
+# reference's, fusion.py / deer.py as cited above) with a round-to-nearest-even to bf16 at exactly those storage points,
+# so a bf16 GPU step can be compared with the oracle at a tolerance set by fp32 summation order instead of by bf16's 8
+# significant bits.  Rounding points (csrc file: what is stored):
+#   * gemm_kernel.inc epilogue_direct: C = bf16(dropout(relu(acc + bias))) forward; dX = bf16(acc * (Y > 0) * 1/(1-p)) or
+#     bf16(acc * regenerated keep factor) backward, i.e. the gradient is rounded AFTER it passed the ReLU / dropout mask of
+#     the layer below;
+#   * rowops.hip ln_fwd / ln_bwd: LayerNorm output bf16; its input gradient (masked like a dX) bf16;
+#   * tri_fused.hip: q, k rounded to bf16 for the score products only (the backward multiplies by the unrounded
+#     accumulators); v stays fp32; the token-pooled context obar and dqkv are stored bf16; probabilities fp32;
+#   * nig.hip: the evidence (64 -> 4 layer output) and everything after it fp32; dz2 bf16;
+#   * api.hip pack: every weight MATRIX bf16 (gradients of the fp32 master parameters are NOT rounded: the weight-gradient
+#     GEMMs accumulate bf16 operands in fp32 slabs); biases and LayerNorm vectors fp32.
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """value rounded to bf16, gradient passed through (a stored activation / a packed weight)."""
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16_round(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """value passed through, gradient rounded to bf16 (a stored activation-gradient)."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16_round(g)
+
+
+class _ScoresBf16(torch.autograd.Function):
+    """q k^T on bf16-rounded q, k (tri_fused.hip MODE 0); the backward multiplies by the UNROUNDED q, k (MODE 1
+    recomputes the fp32 accumulators)."""
+    @staticmethod
+    def forward(ctx, q, k):
+        ctx.save_for_backward(q, k)
+        return _bf16_round(q) @ _bf16_round(k).transpose(-1, -2)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k = ctx.saved_tensors
+        return g @ k, g.transpose(-1, -2) @ q
+
+
+def _qf(x):
+    return _RoundFwd.apply(x)
+
+
+def _qb(x):
+    return _RoundBwd.apply(x)
+
+
+def _qfb(x):
+    return _RoundBwd.apply(_RoundFwd.apply(x))
+
+
+def drop_scale(p):
+    """1 / (1 - p) as api.hip:make_drop forms it: p arrives as a C float, the quotient is rounded to float."""
+    import numpy as np
+    keep = 1.0 - float(np.float32(p))
+    return float(np.float32(1.0 / keep)) if keep > 0 else 0.0
+
+
+def _drop_k(x, mask, p):
+    """keep ? x * scale : 0 -- the kernels' form of inverted dropout (multiplication by the fp32 reciprocal)."""
+    if mask is None:
+        return x
+    return x * (mask.to(x.dtype) * drop_scale(p))
+
+
+def model_forward_bf16(P, audio, video, text, masks=None, p=0.3, heads=8):
+    """model_forward with the bf16 storage points of the HIP path (see the block comment above); fp32 tensors in, fp32 out.
+    Follows the launch plan of csrc/api.hip:mmdeer_forward (F1 .. F18), e.g. the token mean BEFORE the attention out_proj."""
+    masks = masks or {}
+    W = lambda name: _qf(P[name])
+    lin = lambda x, pre: x @ W(pre + ".weight").t() + P[pre + ".bias"]
+
+    def relu_drop_ln(x, pre, mask):          # Linear -> ReLU -> Dropout -> LayerNorm block (F4-5, F10-11, F12-13)
+        y = _qb(lin(x, pre + ".0"))          # d(pre-activation) is what ln_bwd stores
+        z = _qf(_drop_k(torch.relu(y), mask, p))
+        return _qfb(_layer_norm(z, P[pre + ".3.weight"], P[pre + ".3.bias"]))
+
+    a, v, t = _qf(audio), _qf(video), _qf(text)
+    pre = "fusion.audio_visual_fusion."
+    ap = _qfb(lin(a, pre + "audio_projection"))                      # F1
+    vp = _qfb(lin(v, pre + "video_projection"))
+    E = ap.shape[1]
+    hd = E // heads
+    w_v = W(pre + "cross_attention.in_proj_weight")[2 * E:]
+    b_v = P[pre + "cross_attention.in_proj_bias"][2 * E:]
+
+    def attend(kv, mask):                                            # F2, F3
+        B = kv.shape[0]
+        val = _qb(kv @ w_v.t() + b_v)
+        wgt = _drop_k(torch.ones(B, heads, dtype=val.dtype), mask, p)
+        val = _qf((val.view(B, heads, hd) * wgt[:, :, None]).reshape(B, E))
+        return _qfb(lin(val, pre + "cross_attention.out_proj")), wgt.mean(dim=1, keepdim=True)
+
+    audio_att, w_a2v = attend(vp, masks.get("av_attn_a2v"))
+    video_att, w_v2a = attend(ap, masks.get("av_attn_v2a"))
+    av = relu_drop_ln(torch.cat([audio_att, video_att], dim=-1), pre + "fusion_layers", masks.get("av_fuse"))
+
+    pre = "fusion.trimodal_fusion."
+    x0 = _qfb(lin(av, pre + "audiovisual_projection"))               # F6
+    x1 = _qfb(lin(t, pre + "text_projection"))                       # F1
+    x = torch.stack([x0, x1], dim=1)
+    B, T, E = x.shape
+    hd = E // heads
+    qkv = _qb(x @ W(pre + "modality_attention.in_proj_weight").t() + P[pre + "modality_attention.in_proj_bias"])   # F7
+    q, k, vv = (u.view(B, T, heads, hd).transpose(1, 2) for u in qkv.split(E, dim=-1))
+    prob = torch.softmax(_ScoresBf16.apply(q, k) * math.sqrt(1.0 / hd), dim=-1)       # F8 (B, H, 2, 2)
+    probd = _drop_k(prob, masks.get("tri_attn"), p)
+    o = (probd @ vv).transpose(1, 2).reshape(B, T, E)
+    obar = _qfb(o.mean(dim=1))                                       # token mean commutes with out_proj: B rows
+    pooled = _qfb(lin(obar, pre + "modality_attention.out_proj"))    # F9
+    tri = relu_drop_ln(pooled, pre + "final_fusion", masks.get("tri_fuse"))
+    fused = relu_drop_ln(tri, "fusion.output_projection", masks.get("out_proj"))
+    fo = {"fused_features": fused, "audiovisual_features": av, "trimodal_features": tri,
+          "av_attention_weights": {"audio_to_video": w_a2v, "video_to_audio": w_v2a},
+          "trimodal_attention_weights": probd.mean(dim=1), "trimodal_probs": prob, "uncertainty_weights": None}
+
+    layer = lambda x, pre, mask: _qf(_drop_k(torch.relu(_qb(lin(x, pre))), mask, p))
+    h = layer(fused, "head.feature_processor.0", masks.get("fp0"))   # F14
+    h = layer(h, "head.feature_processor.3", masks.get("fp1"))       # F15
+    ho: Dict[str, torch.Tensor] = {}
+    keys = ("mu", "nu", "alpha", "beta", "aleatoric_uncertainty", "epistemic_uncertainty", "uncertainty")
+    m0, m1 = masks.get("ev0"), masks.get("ev1")
+    for i, dim in enumerate(DIM_NAMES):
+        pre = f"head.deer_heads.{i}.evidence_net"
+        e = layer(h, pre + ".0", None if m0 is None else m0[:, i])   # F16
+        e = layer(e, pre + ".3", None if m1 is None else m1[:, i])   # F17
+        e = lin(e, pre + ".6").view(B, 1, 4)                         # F18: evidence stays fp32
+        for key, val in zip(keys, nig_activations(e)):
+            ho[f"{dim}_{key}"] = val
+    ho["mu_all"] = torch.cat([ho[f"{d}_mu"] for d in DIM_NAMES], dim=1)
+    ho["uncertainty_all"] = torch.cat([ho[f"{d}_uncertainty"] for d in DIM_NAMES], dim=1)
+    return fo, ho
+
+
+def train_step(P, audio, video, text, targets, masks=None, p=0.3, heads=8, emulate_bf16=False):
     """forward + MultiTaskDEERLoss + backward over every parameter (the bench 'step').
-    Returns (fusion_out, head_out, loss_dict, grads keyed like P)."""
+    Returns (fusion_out, head_out, loss_dict, grads keyed like P).  emulate_bf16: round to bf16 where the bf16 HIP path
+    stores (model_forward_bf16); P, the inputs and every result stay fp32 tensors."""
     for t in P.values():
         t.grad = None
-    fo, ho = model_forward(P, audio, video, text, masks, p, heads)
+    if emulate_bf16:
+        fo, ho = model_forward_bf16(P, audio, video, text, masks, p, heads)
+    else:
+        fo, ho = model_forward(P, audio, video, text, masks, p, heads)
     ld = multitask_loss(ho, targets)
     ld["total_loss"].backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()}
