@@ -9,7 +9,10 @@
  * Conventions
  *  - Plain pointers and sizes only; every buffer (inputs, outputs, parameters,
  *    workspace, gradients) is DEVICE memory owned by the caller.  The library
- *    allocates nothing and keeps no global state.
+ *    allocates nothing, reads no environment variable and keeps no state between
+ *    calls except the launch-plan option table below (mmdeer_set_option; the
+ *    defaults are the shipped plan) and the communicators a caller creates
+ *    (mmdeer_comm_init).
  *  - Every call only ENQUEUES work on `stream` (a hipStream_t passed as void*)
  *    and never synchronises the device: calls are graph-capturable.
  *  - Return value: 0 = ok, -1 = error; the message is in mmdeer_last_error()
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 12
+#define MMDEER_ABI_VERSION 13
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
 #define MMDEER_AUDIO_DIM 84
@@ -58,6 +61,25 @@ size_t mmdeer_workspace_bytes(int batch, int compute_f32);
  * fp32 vectors, the padded audio weight, the head-major in_proj image).  ONE buffer per model and compute dtype, shared
  * by the workspaces of every batch size; written by mmdeer_forward(repack = 1), mmdeer_pack_weights and mmdeer_adamw_step. */
 size_t mmdeer_weights_bytes(int compute_f32);
+
+/* Launch-plan options (csrc/options.h): integer switches that select between kernel plans with IDENTICAL results up to
+ * rounding (A/B measurements, debugging); read at every call, so a process may change them between calls.
+ *   fused_attn (1)     0: unfused in_proj GEMM + attention kernels also in bf16 mode
+ *   qkv_recompute (1)  0: the fused forward stores q|k|v for the backward instead of recomputing the head tiles
+ *   nig_fused (1)      0: head last layer + loss statistics and the loss gradient as two launches
+ *   xcd, nt128, nt192, glds, nt8 (1), t128 (512), tile (-1), ksteps (0)   GEMM tile selection
+ * mmdeer_set_option / mmdeer_get_option return -1 for an unknown name; mmdeer_option_name(i) enumerates (NULL past the end). */
+int mmdeer_set_option(const char* name, int value);
+int mmdeer_get_option(const char* name, int* value);
+const char* mmdeer_option_name(int i);
+
+/* Byte offset of a named buffer inside the workspace of (batch, compute_f32), -1 for an unknown name: lets a test read the
+ * activations and activation-gradients a step left behind (tests/test_gpu_bf16_layers.py checks every kernel of the bench
+ * configuration on its own stored inputs).  Names (csrc/api.hip Layout; act dtype unless noted): audio_pad [B,128] bf16,
+ * avin avv [2B,256], cat [B,512], y_a2 av [B,256], xtok [2B,512], qkv [2B,1536], obar pool y_t3 tri y_o1 fused [B,512],
+ * h1 h2 [B,256], e1 [B,384], e2 [B,192], probs [B,8,4] f32, evid [B,3,4] f32, mean_* rstd_* [B] f32, and the gradients
+ * dz2 de1 dh2 dh1 dfused dz_o1 dtri dz_t3 dpool dobar dqkv dxtok dav dz_a2 dcats davv davin of the same shapes. */
+long long mmdeer_workspace_offset(int batch, int compute_f32, const char* name);
 
 typedef struct mmdeer_loss_cfg {
   float reg_weight;    /* losses.py:52  0.1  */

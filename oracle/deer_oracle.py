@@ -670,6 +670,104 @@ def model_forward_bf16(P, audio, video, text, masks=None, p=0.3, heads=8):
     return fo, ho
 
 
+# --------------------------------------------------------------------------- kernel-level restatements (bf16 path)
+# One function per launch of csrc/api.hip's plan, each taking the tensors THAT launch reads (as fp32 tensors holding
+# bf16-representable values where the kernel reads bf16) and returning what it stores.  tests/test_gpu_bf16_layers.py feeds
+# every launch of a full-size step its own stored inputs ("teacher forcing"), so the chaotic growth of rounding differences
+# through the chain (see model_forward_bf16's callers) cannot hide an error inside one kernel.
+def k_linear(x, W, b, relu=False, mask=None, p=0.0):
+    """gemm epilogue_direct, forward: bf16(dropout(relu(x W^T + b))); W is rounded as the pack kernels do."""
+    y = x @ _bf16_round(W).t() + b
+    if relu:
+        y = torch.relu(y)
+    return _bf16_round(_drop_k(y, mask, p))
+
+
+def k_dx(dy, W, ymask=None, p=0.0, keep=None):
+    """gemm epilogue_direct, backward: bf16((dy W) * (Y > 0) / (1 - p)) -- Y the stored output of the layer below -- or
+    bf16((dy W) * regenerated keep factor) for the attention-weight dropout."""
+    g = dy @ _bf16_round(W)
+    if ymask is not None:
+        g = g * ((ymask > 0).to(g.dtype) * (drop_scale(p) if p > 0 else 1.0))
+    if keep is not None:
+        g = g * (keep.to(g.dtype) * drop_scale(p))
+    return _bf16_round(g)
+
+
+def k_dw(dy, x):
+    """weight-gradient GEMM + slab fold: dW = dy^T x, db = column sums of dy (fp32 accumulation of bf16 operands;
+    accumulated here in fp64 so the reference does not depend on a summation order)."""
+    return (dy.double().t() @ x.double()).float(), dy.double().sum(dim=0).float()
+
+
+def k_ln_fwd(y, gamma, beta, eps=1e-5):
+    """rowops.hip ln_fwd_kernel: (bf16 out, mean, rstd)."""
+    mu = y.mean(dim=-1, keepdim=True)
+    var = ((y - mu) ** 2).mean(dim=-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    return _bf16_round((y - mu) * rstd * gamma + beta), mu.squeeze(-1), rstd.squeeze(-1)
+
+
+def k_ln_bwd(dout, y, mean, rstd, gamma, p=0.0):
+    """rowops.hip ln_bwd_kernel: gradient of LayerNorm(y) w.r.t. the PRE-activation of the Linear-ReLU-Dropout in front of it
+    (y = stored dropout(relu(.)): mask (y > 0) / (1 - p)), bf16; plus d gamma, d beta."""
+    xhat = (y - mean[:, None]) * rstd[:, None]
+    dxhat = dout * gamma
+    dz = rstd[:, None] * (dxhat - dxhat.mean(dim=-1, keepdim=True) - xhat * (dxhat * xhat).mean(dim=-1, keepdim=True))
+    dz = dz * ((y > 0).to(dz.dtype) * (drop_scale(p) if p > 0 else 1.0))
+    return _bf16_round(dz), (dout.double() * xhat.double()).sum(dim=0).float(), dout.double().sum(dim=0).float()
+
+
+def _tri_split(xtok, w_in, b_in, heads):
+    qkv = xtok @ _bf16_round(w_in).t() + b_in
+    B, T, E3 = qkv.shape
+    E = E3 // 3
+    return [u.view(B, T, heads, E // heads).transpose(1, 2) for u in qkv.split(E, dim=-1)]    # q, k, v: (B, H, T, hd)
+
+
+def k_tri_fwd(xtok, w_in, b_in, mask=None, p=0.0, heads=8, probs=None):
+    """tri_fused_kernel<0>: xtok (B, 2, 512) -> (softmax probabilities (B, H, 2, 2) fp32, bf16 token-pooled context (B, 512)).
+    The scores are products of bf16-ROUNDED q, k (an internal rounding: an element of q or k that rounds the other way moves
+    a probability by up to ~5e-4); with `probs` given, the context is formed from THOSE probabilities, so the second half of
+    the kernel can be checked on its own."""
+    q, k, v = _tri_split(xtok, w_in, b_in, heads)
+    B, H, T, hd = q.shape
+    prob = torch.softmax((_bf16_round(q) @ _bf16_round(k).transpose(-1, -2)) * math.sqrt(1.0 / hd), dim=-1)
+    o = (_drop_k(prob if probs is None else probs, mask, p) @ v).transpose(1, 2).reshape(B, T, H * hd)
+    return prob, _bf16_round(o.mean(dim=1))
+
+
+def k_tri_bwd(xtok, w_in, b_in, dobar, probs, mask=None, p=0.0, heads=8):
+    """tri_fused_kernel<1>: recompute q|k|v (fp32, unrounded), attention backward from the SAVED probabilities -> bf16 dqkv
+    (B, 2, 1536) in the reference's column order [q | k | v]."""
+    q, k, v = _tri_split(xtok, w_in, b_in, heads)
+    B, H, T, hd = q.shape
+    keep = 1.0 if mask is None else mask.to(q.dtype) * drop_scale(p)
+    do = (0.5 * dobar).view(B, 1, H, hd).transpose(1, 2).expand(B, H, T, hd)        # d o_t = d obar / 2 for both tokens
+    pd = probs * keep
+    dv = pd.transpose(-1, -2) @ do
+    dp = (do @ v.transpose(-1, -2)) * keep
+    ds = probs * (dp - (probs * dp).sum(dim=-1, keepdim=True)) * math.sqrt(1.0 / hd)
+    dq, dk = ds @ k, ds.transpose(-1, -2) @ q
+    back = lambda u: u.transpose(1, 2).reshape(B, T, H * hd)
+    return _bf16_round(torch.cat([back(dq), back(dk), back(dv)], dim=-1))
+
+
+def k_nig_bwd(evid, targets, e2, w3, p=0.0):
+    """nig_bwd_kernel in loss mode: d MultiTaskDEERLoss / d evidence (fp32, from the stored evidence (B, 3, 4)) and
+    dz2 = bf16((d evid . W3) * (e2 > 0) / (1 - p)); w3: list of the three (4, 64) last-layer weights."""
+    ev = evid.detach().clone().requires_grad_(True)
+    pred = {}
+    for i, dim in enumerate(DIM_NAMES):
+        mu, nu, alpha, beta = nig_activations(ev[:, i:i + 1, :])[:4]
+        pred.update({f"{dim}_mu": mu, f"{dim}_nu": nu, f"{dim}_alpha": alpha, f"{dim}_beta": beta})
+    multitask_loss(pred, targets)["total_loss"].backward()
+    dev = ev.grad
+    dz = torch.cat([dev[:, i, :] @ _bf16_round(w3[i]) for i in range(3)], dim=1)
+    dz = dz * ((e2 > 0).to(dz.dtype) * (drop_scale(p) if p > 0 else 1.0))
+    return dev, _bf16_round(dz)
+
+
 def train_step(P, audio, video, text, targets, masks=None, p=0.3, heads=8, emulate_bf16=False):
     """forward + MultiTaskDEERLoss + backward over every parameter (the bench 'step').
     Returns (fusion_out, head_out, loss_dict, grads keyed like P).  emulate_bf16: round to bf16 where the bf16 HIP path

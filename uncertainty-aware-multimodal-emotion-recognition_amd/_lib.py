@@ -26,6 +26,7 @@ _LIB: Optional[C.CDLL] = None
 _LOCK = threading.Lock()
 
 c_void_p, c_int, c_float, c_u64, c_size_t, c_ll = C.c_void_p, C.c_int32, C.c_float, C.c_uint64, C.c_size_t, C.c_longlong
+c_char_p = C.c_char_p
 
 
 class LossCfg(C.Structure):
@@ -205,6 +206,10 @@ SYMBOLS = [
     ("mmdeer_comm_destroy", c_int, [c_void_p]),
     ("mmdeer_allreduce", c_int, [c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p]),
     ("mmdeer_convert", c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p]),
+    ("mmdeer_set_option", c_int, [c_char_p, c_int]),
+    ("mmdeer_get_option", c_int, [c_char_p, C.POINTER(c_int)]),
+    ("mmdeer_option_name", c_char_p, [c_int]),
+    ("mmdeer_workspace_offset", c_ll, [c_int, c_int, c_char_p]),
 ]
 
 
@@ -237,10 +242,51 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 12:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 13:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
+        # The library itself reads no environment variable (include/mmdeer.h).  For the A/B tools the host forwards
+        # MMDEER_<OPTION> (e.g. MMDEER_FUSED_ATTN=0) to mmdeer_set_option once, here.
+        i = 0
+        while True:
+            nm = lib.mmdeer_option_name(i)
+            if nm is None:
+                break
+            env = os.environ.get("MMDEER_" + nm.decode().upper())
+            if env is not None:
+                if lib.mmdeer_set_option(nm, int(env)) != 0:
+                    raise RuntimeError("mmdeer: " + lib.mmdeer_last_error().decode())
+            i += 1
         _LIB = lib
     return _LIB
+
+
+def set_option(name: str, value: int) -> None:
+    """mmdeer_set_option: choose a launch plan (include/mmdeer.h lists the names); takes effect from the next call."""
+    check(load().mmdeer_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = c_int(0)
+    check(load().mmdeer_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+class options:
+    """``with _lib.options(fused_attn=0): ...`` -- set launch-plan options for a block and restore them afterwards."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def check(rc: int) -> None:

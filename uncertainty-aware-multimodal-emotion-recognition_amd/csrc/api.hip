@@ -1,6 +1,7 @@
 // libmmdeer_hip.so -- C ABI (include/mmdeer.h) and the host-side executor that strings the gfx950 kernels into
 // the forward / backward of the fusion + DEER path.  Host code only: every function enqueues on the caller's
 // stream and returns; nothing here allocates device memory or synchronises.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include "gemm.h"
 #include "nig.h"
 #include "optim.h"
+#include "options.h"
 #include "rowops.h"
 
 namespace mmdeer {
@@ -147,45 +149,41 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
   return d;
 }
 
-// target number of K-tiles per split-K slice of a weight-gradient problem (MMDEER_KSTEPS overrides)
+// ------------------------------------------------------------------ launch-plan options (options.h)
+struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
+OptEntry g_opts[OPT_COUNT] = {
+    {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
+    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"nig_fused", 1, {1}},
+};
+}  // namespace
+
+int opt(OptId id) { return g_opts[id].value.load(std::memory_order_relaxed); }
+const char* opt_name(int i) { return (i >= 0 && i < OPT_COUNT) ? g_opts[i].name : nullptr; }
+int opt_set(const char* name, int value) {
+  for (auto& o : g_opts)
+    if (name && strcmp(name, o.name) == 0) { o.value.store(value, std::memory_order_relaxed); return 0; }
+  return -1;
+}
+int opt_get(const char* name, int* value) {
+  for (auto& o : g_opts)
+    if (name && strcmp(name, o.name) == 0) { if (value) *value = o.value.load(std::memory_order_relaxed); return 0; }
+  return -1;
+}
+
+namespace {
+// target number of K-tiles per split-K slice of a weight-gradient problem (option "ksteps" overrides)
 // in units of 64 batch rows.  Defaults: bf16 (256x256 LDS-DMA kernel) 16 = 1024 rows per slice -- the slab
 // traffic, 4 B per parameter per slice written and read back, is what limits the slice count; fp32 8.
 int ksteps_target(int f32) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MMDEER_KSTEPS");
-    v = e ? atoi(e) : 0;
-    if (v < 0) v = 0;
-  }
+  const int v = opt(OPT_KSTEPS);
   return v > 0 ? v : (f32 ? 8 : 16);
 }
-
-
-// MMDEER_FUSED_ATTN=0: the unfused pair (in_proj GEMM writing q|k|v + one-wave-per-sample attention kernels) also in bf16
-// mode.  Default 1: tri_fused.hip.  MMDEER_QKV_RECOMPUTE=0 (with the fused forward): the forward also stores q|k|v and
+// option "fused_attn" = 0: the unfused pair (in_proj GEMM writing q|k|v + one-wave-per-sample attention kernels) also in
+// bf16 mode.  Default 1: tri_fused.hip.  "qkv_recompute" = 0 (with the fused forward): the forward also stores q|k|v and
 // the backward runs the unfused attention-backward kernel on it instead of recomputing the head tiles.
-int env_fused_attn() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_FUSED_ATTN"); v = e ? atoi(e) : 1; }
-  return v;
-}
-int env_qkv_recompute() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_QKV_RECOMPUTE"); v = e ? atoi(e) : 1; }
-  return v;
-}
-}  // namespace
-
-namespace {
-int forced_tile() {
-  static int v = -2;
-  if (v == -2) {
-    const char* e = getenv("MMDEER_TILE");
-    v = e ? atoi(e) : -1;
-  }
-  return v;
-}
-
+int env_fused_attn() { return opt(OPT_FUSED_ATTN); }
+int env_qkv_recompute() { return opt(OPT_QKV_RECOMPUTE); }
+int forced_tile() { return opt(OPT_TILE); }
 }  // namespace
 
 // smallest tile that still gives the chip >= ~2 workgroups per CU; otherwise the largest tile count wins
@@ -222,9 +220,7 @@ GemmTile pick_tile(const GemmGroup& g) {
   // ~one 128x64 tile per CU: the 8-wave 128x64 kernel (launcher) moves 25 % fewer operand bytes than two 64x64
   // workgroups per CU, and the K loop of those is bound by the CU's vector-memory path
   if (!f32 && !g.p[0].trans_a && !g.p[0].trans_b && tiles[1] >= 200 && tiles[1] <= 320) return TILE_128x64;
-  static int t128 = -1;   // MMDEER_T128: smallest 128x64 tile count that selects the 128x64 kernel
-  if (t128 < 0) { const char* e = getenv("MMDEER_T128"); t128 = e ? atoi(e) : 512; }
-  if (tiles[1] >= t128) return TILE_128x64;
+  if (tiles[1] >= opt(OPT_T128)) return TILE_128x64;   // option "t128": smallest 128x64 tile count that selects that kernel
   return TILE_64x64;
 }
 
@@ -386,6 +382,29 @@ long long mmdeer_flat_elems(void) { return MMDEER_FLAT_ELEMS; }
 
 size_t mmdeer_workspace_bytes(int batch, int compute_f32) { return make_layout(nullptr, nullptr, batch, compute_f32).bytes; }
 size_t mmdeer_weights_bytes(int compute_f32) { return make_layout(nullptr, nullptr, 0, compute_f32).wbytes; }
+
+int mmdeer_set_option(const char* name, int value) {
+  MMDEER_CHECK(opt_set(name, value) == 0, "set_option: unknown option '%s'", name ? name : "(null)");
+  return 0;
+}
+int mmdeer_get_option(const char* name, int* value) {
+  MMDEER_CHECK(opt_get(name, value) == 0, "get_option: unknown option '%s'", name ? name : "(null)");
+  return 0;
+}
+const char* mmdeer_option_name(int i) { return opt_name(i); }
+
+long long mmdeer_workspace_offset(int batch, int compute_f32, const char* name) {
+  if (!name || batch < 0) return -1;
+  char* const base = reinterpret_cast<char*>(uintptr_t(1) << 40);   // any non-null base: only differences are returned
+  const Layout L = make_layout(base, base, batch, compute_f32 ? 1 : 0);
+#define WS(field) if (strcmp(name, #field) == 0) return reinterpret_cast<const char*>(L.field) - base;
+  WS(audio_pad) WS(avin) WS(avv) WS(cat) WS(y_a2) WS(av) WS(xtok) WS(qkv) WS(obar) WS(pool) WS(y_t3) WS(tri) WS(y_o1) WS(fused)
+  WS(h1) WS(h2) WS(e1) WS(e2) WS(probs) WS(evid) WS(stats) WS(mean_a2) WS(rstd_a2) WS(mean_t3) WS(rstd_t3) WS(mean_o1) WS(rstd_o1)
+  WS(dz2) WS(de1) WS(dh2) WS(dh1) WS(dfused) WS(dz_o1) WS(dtri) WS(dz_t3) WS(dpool) WS(dobar) WS(dqkv) WS(dxtok) WS(dav) WS(dz_a2)
+  WS(dcats) WS(davv) WS(davin) WS(slab)
+#undef WS
+  return -1;
+}
 
 long long mmdeer_bucket_begin(int b) {
   switch (b) { case 0: return kParams[P_FP0_W].off; case 1: return kParams[P_AVP_W].off; case 2: return 0; default: return -1; }

@@ -1,6 +1,7 @@
 // Host side of the grouped GEMM: validation, loader-mode selection, partition of a group by (A mode, B mode)
 // and dispatch to the instantiations in gemm_nt.hip / gemm_nx.hip / gemm_tt.hip.
 #include "gemm.h"
+#include "options.h"
 
 #include <cstdlib>
 
@@ -14,27 +15,13 @@ int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s);
 int gemm_dispatch_nt256(const GemmGroup& g, int total, int bn, hipStream_t s);
 
 namespace {
-int env_xcd() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_XCD"); v = e ? atoi(e) : 1; }
-  return v;
-}
-int env_nt192() {   // MMDEER_NT192=0: the forward 256-row kernel keeps 256-column tiles
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_NT192"); v = e ? atoi(e) : 1; }
-  return v;
-}
-// MMDEER_GLDS=0 forces the register-staged kernel for NT problems (A/B comparison, debugging)
-int env_nt128() {   // MMDEER_NT128=0: never trade two 128x64 workgroups per CU for one 8-wave 128x128 workgroup
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_NT128"); v = e ? atoi(e) : 1; }
-  return v;
-}
-int env_glds() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_GLDS"); v = e ? atoi(e) : 1; }
-  return v;
-}
+// launch-plan options (options.h): "xcd" = 0 no XCD renumbering; "nt192" = 0 the forward 256-row kernel keeps 256-column
+// tiles; "nt128" = 0 never trade two 128x64 workgroups per CU for one 8-wave 128x128 workgroup; "glds" = 0 forces the
+// register-staged kernel for NT problems (A/B comparison, debugging)
+int env_xcd() { return opt(OPT_XCD); }
+int env_nt192() { return opt(OPT_NT192); }
+int env_nt128() { return opt(OPT_NT128); }
+int env_glds() { return opt(OPT_GLDS); }
 }  // namespace
 
 void gemm_problem_defaults(GemmProblem& p) {

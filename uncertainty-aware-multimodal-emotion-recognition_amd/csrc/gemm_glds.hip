@@ -17,6 +17,7 @@
 // finished reading tile t-1 -- and only then re-issues into the stage tile t-1 occupied.  Raw s_barrier, never
 // __syncthreads(): the latter would drain vmcnt to 0.
 #include "gemm_kernel.inc"
+#include "options.h"
 
 namespace mmdeer {
 namespace {
@@ -44,11 +45,7 @@ namespace {
 #define KWGSTAMP(which) do {} while (0)
 #endif
 
-int env_nt8() {   // MMDEER_NT8=0: never use the 8-wave 128x64 form
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MMDEER_NT8"); v = e ? atoi(e) : 1; }
-  return v;
-}
+int env_nt8() { return opt(OPT_NT8); }   // option "nt8" = 0: never use the 8-wave 128x64 form
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

@@ -1,0 +1,30 @@
+// Launch-plan options of libmmdeer_hip.so (include/mmdeer.h: mmdeer_set_option / mmdeer_get_option).
+// The library reads no environment variable: the defaults are the shipped plan, and a host that wants another one says
+// so through the C ABI (mmdeer/_lib.py forwards MMDEER_<NAME> environment variables at load time for the A/B tools).
+// Options are read at every call, so a process can switch plans between calls; the table is the library's only mutable
+// process-wide state besides the communicator handles of comm.hip.
+#pragma once
+
+namespace mmdeer {
+
+enum OptId {
+  OPT_FUSED_ATTN = 0,   // 1: tri_fused.hip (in_proj + attention in one kernel, bf16 mode); 0: unfused pair
+  OPT_QKV_RECOMPUTE,    // 1: the fused backward recomputes the head tiles; 0: the forward also stores q|k|v
+  OPT_XCD,              // 1: XCD-contiguous workgroup renumbering in the GEMM kernels
+  OPT_NT128,            // 1: one 8-wave 128x128 LDS-DMA workgroup per CU where 128x64 tiles would need two
+  OPT_NT192,            // 1: 256x192 tiles in the 256-row forward kernel when they fill the chip in one round
+  OPT_GLDS,             // 1: LDS-DMA GEMM kernels; 0: register-staged kernels everywhere
+  OPT_NT8,              // 1: the 8-wave 128x64 form of the LDS-DMA kernel
+  OPT_T128,             // smallest 128x64 tile count that selects the 128x64 kernel
+  OPT_TILE,             // -1: automatic; 0..3: force a GemmTile
+  OPT_KSTEPS,           // 0: automatic; > 0: K-tiles per split-K slice of a weight-gradient problem
+  OPT_NIG_FUSED,        // 1: head last layer + loss statistics + loss gradient in one launch (nig_fused_kernel)
+  OPT_COUNT
+};
+
+int opt(OptId id);                          // current value
+int opt_set(const char* name, int value);   // 0 = ok, -1 = unknown name
+int opt_get(const char* name, int* value);  // 0 = ok, -1 = unknown name
+const char* opt_name(int i);                // nullptr past the end
+
+}  // namespace mmdeer
