@@ -40,64 +40,78 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
+PROFILE_TAG = "r03"      # profiles/<tag>_* : the committed records of this round (tools/collect_profiles.py writes them)
+
+
+def _file_stamp(path):
+    import hashlib
+    st = os.stat(path)
+    return {"file": os.path.relpath(path, ROOT), "mtime": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(st.st_mtime)),
+            "sha256": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]}
+
+
 def measured_traffic(dtype, batch):
     """HBM-side bytes per launch of the roofline kernel from the committed PMC record (separate rocprofv3 --pmc passes,
-    FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes the record).  null unless
-    the record was taken on exactly these kernel sources, dtype and batch."""
+    FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; tools/pmc_fused_summary.py writes the record).  None
+    unless the record was taken on exactly these kernel sources, dtype and batch."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        rec = json.load(open(path))
         if rec.get("src_sha") == kernel_sources_sha() and rec.get("dtype") == dtype and rec.get("batch") == batch:
-            return float(rec["traffic_bytes"])
+            return float(rec["traffic_bytes"]), _file_stamp(path)
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
-def rocprof_record(batch, dtype, step_ms):
-    """Per-kernel figures from the COMMITTED rocprofv3 --kernel-trace --stats summary of this command
-    (profiles/r02_bench_kernel_stats.csv + .json: which sources / batch it was taken on): average duration of the roofline
-    kernel -> frac_rocprof, and achieved GB/s of the HBM-bound row kernels against their algorithmic bytes.  null when the
-    summary is missing or was taken on other kernel sources."""
+def recorded_profile(batch, dtype):
+    """Figures READ FROM COMMITTED FILES, not measured by this run: the rocprofv3 --kernel-trace --stats summary
+    of this command (profiles/<tag>_bench_kernel_stats.csv + .json naming the sources / batch it was taken on) -> average
+    duration of the roofline kernel and GB/s of the HBM-bound row kernels against their algorithmic bytes; and the MFMA
+    calibration probe of the box the profiles were taken on.  Each part is present only while its record matches the
+    kernel sources of this build, and carries the file's name, mtime and hash."""
     import csv
-    try:
-        meta = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.json")))
-        if meta.get("src_sha") != kernel_sources_sha() or meta.get("batch") != batch or meta.get("dtype") != dtype:
-            return None
-        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", meta["csv"]))))
-    except (OSError, ValueError, KeyError):
-        return None
-    avg = {}
-    for r in rows:
-        n = r["Name"].replace("void ", "").replace("mmdeer::(anonymous namespace)::", "").split("(")[0]
-        avg[n] = float(r["AverageNs"]) * 1e-9
-    B, s = batch, 2     # bf16 activations
-    # algorithmic bytes per launch of the HBM-bound kernels (activations in + out; statistics / parameters are noise)
-    hbm = {"ln_fwd_kernel<false, 2, true>": 2 * B * 512 * s, "ln_fwd_kernel<false, 1, true>": 2 * B * 256 * s,
-           "ln_bwd_kernel<false, 2, true>": 3 * B * 512 * s, "ln_bwd_kernel<false, 1, true>": 3 * B * 256 * s,
-           "nig_fwd_kernel<false>": B * 192 * s + B * 12 * 4 + 7 * B * 3 * 4, "nig_bwd_kernel<false>": 2 * B * 192 * s + B * 12 * 4 + B * 3 * 4,
-           "tri_fused_kernel<1>": 2 * B * 512 * s + 1536 * 512 * s + B * 512 * s + B * 32 * 4 + 2 * B * 1536 * s}
-    if B == 4096:   # the weight-gradient fold: 240 split-K slabs of 256 x 256 fp32 in, the 2,907,212-element gradient out
-        hbm["reduce_partials_kernel"] = 240 * 256 * 256 * 4 + 2907212 * 4
-    out = {"file": "profiles/" + meta["csv"], "hbm_gbps": {}}
-    k = "tri_fused_kernel<0>"
-    if k in avg:
-        out["roofline_kernel_avg_us"] = round(avg[k] * 1e6, 2)
-        out["frac_rocprof"] = round(2.0 * (2 * B) * 512 * 1536 / avg[k] / BF16_MFMA_PEAK, 4)
-    for name, nbytes in hbm.items():
-        if name in avg:
-            out["hbm_gbps"][name] = {"gbps": round(nbytes / avg[name] / 1e9, 1), "frac_of_8TBps": round(nbytes / avg[name] / 8e12, 3),
-                                     "avg_us": round(avg[name] * 1e6, 2), "algorithmic_bytes": nbytes}
-    return out
-
-
-def measured_mfma_peak():
-    """TFLOP/s of back-to-back bf16 MFMAs on the box (tools/probes/calibrate.hip -> profiles/r02_calibration.txt), or None."""
     import re
+    out = {}
     try:
-        m = re.search(r"MFMA bf16 .*?: ([0-9.]+) TFLOP/s", open(os.path.join(ROOT, "profiles", "r02_calibration.txt")).read())
-        return float(m.group(1)) if m else None
+        mpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_bench_kernel_stats.json")
+        meta = json.load(open(mpath))
+        if meta.get("src_sha") == kernel_sources_sha() and meta.get("batch") == batch and meta.get("dtype") == dtype:
+            cpath = os.path.join(ROOT, "profiles", meta["csv"])
+            avg = {}
+            for r in csv.DictReader(open(cpath)):
+                n = r["Name"].replace("void ", "").replace("mmdeer::(anonymous namespace)::", "").split("(")[0]
+                avg[n] = float(r["AverageNs"]) * 1e-9
+            B, s = batch, 2     # bf16 activations
+            # algorithmic bytes per launch of the HBM-bound kernels (activations in + out; statistics / parameters are noise)
+            hbm = {"ln_fwd_kernel<false, 2, true>": 2 * B * 512 * s, "ln_fwd_kernel<false, 1, true>": 2 * B * 256 * s,
+                   "ln_bwd_kernel<false, 2, true>": 3 * B * 512 * s, "ln_bwd_kernel<false, 1, true>": 3 * B * 256 * s,
+                   "nig_fwd_kernel<false>": B * 192 * s + B * 12 * 4 + 7 * B * 3 * 4, "nig_bwd_kernel<false>": 2 * B * 192 * s + B * 12 * 4 + B * 3 * 4,
+                   "nig_fused_kernel<false>": 2 * B * 192 * s + B * 12 * 4 + 7 * B * 3 * 4,
+                   "tri_fused_kernel<1>": 2 * B * 512 * s + 1536 * 512 * s + B * 512 * s + B * 32 * 4 + 2 * B * 1536 * s}
+            if "reduce_bytes" in meta:      # the weight-gradient fold: slabs in + gradient out (tools/collect_profiles.py computes it)
+                hbm["reduce_partials_kernel"] = int(meta["reduce_bytes"])
+            rec = {"source": "committed profile", **_file_stamp(cpath), "src_sha": meta["src_sha"], "hbm_gbps": {}}
+            k = "tri_fused_kernel<0>"
+            if k in avg:
+                rec["roofline_kernel_avg_us"] = round(avg[k] * 1e6, 2)
+                rec["roofline_frac"] = round(2.0 * (2 * B) * 512 * 1536 / avg[k] / BF16_MFMA_PEAK, 4)
+            for name, nbytes in hbm.items():
+                if name in avg:
+                    rec["hbm_gbps"][name] = {"gbps": round(nbytes / avg[name] / 1e9, 1), "frac_of_8TBps": round(nbytes / avg[name] / 8e12, 3),
+                                             "avg_us": round(avg[name] * 1e6, 2), "algorithmic_bytes": nbytes}
+            out["rocprof"] = rec
+    except (OSError, ValueError, KeyError):
+        pass
+    try:
+        cal = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_calibration.txt")
+        m = re.search(r"MFMA bf16 .*?: ([0-9.]+) TFLOP/s", open(cal).read())
+        if m and dtype == "bf16":
+            out["calibration"] = {"source": "committed profile (another box than this run's)", **_file_stamp(cal),
+                                  "mfma_bf16_tflops_back_to_back": float(m.group(1))}
     except OSError:
-        return None
+        pass
+    return out or None
 
 
 def usable_cores():
@@ -229,27 +243,54 @@ def spawn_ranks(n, argv):
 
 def plumbing(args, world, rank):
     """--plumbing: the launch / rendezvous / timing protocol of the N-rank bench on the CPU (gloo), no GPU work: what
-    tests/test_cpu_bench_spawn.py runs.  Same barrier + MAX-over-ranks bracket, same single JSON line from rank 0."""
+    tests/test_cpu_bench_spawn.py runs.  Same barrier + MAX-over-ranks bracket, same single JSON line from rank 0, and the
+    same `data_parallel` diagnostics block as the GPU line (exchange timing, plan, per-rank step times, rank count as the
+    process group reports it, payload bytes) computed on a flat gradient-sized CPU tensor."""
+    from mmdeer.parallel import BucketedAllReduce
+    from mmdeer.spec import param_offsets
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: world size {dist.get_world_size()} != --gpus {args.gpus}")
         dist.barrier()
-    t0 = time.perf_counter()
-    x = torch.full((4,), float(rank + 1))
-    for _ in range(args.steps):
-        if world > 1:
-            dist.all_reduce(x, op=dist.ReduceOp.SUM)
-            x /= world
+    flat = torch.full((param_offsets()[1],), float(rank + 1))
+    comm = BucketedAllReduce(device=torch.device("cpu"), payload="fp32") if world > 1 else None
+    xs = []
+    for _ in range(3):
+        t = time.perf_counter()
+        if comm:
+            comm.launch(flat)
+            comm.wait(flat)
+        xs.append((time.perf_counter() - t) * 1e6)
     if world > 1:
         dist.barrier()
-    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if comm:
+            comm.launch(flat)
+            comm.wait(flat)
+    own = time.perf_counter() - t0
     if world > 1:
+        dist.barrier()
+    tt = torch.tensor([own], dtype=torch.float64)
+    per_rank = [round(own / max(args.steps, 1) * 1e3, 4)]
+    xus = torch.tensor([sorted(xs)[1]], dtype=torch.float64)
+    if world > 1:
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank = [round(float(x) / max(args.steps, 1) * 1e3, 4) for x in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(xus, op=dist.ReduceOp.MAX)
+        assert abs(float(flat[0]) - (world + 1) / 2) < 1e-5 * world, "mean over ranks is preserved by repeated averaging"
     if rank == 0:
-        print(json.dumps({"plumbing": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(float(tt) / max(args.steps, 1) * 1e3, 4)}), flush=True)
+        out = {"plumbing": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(float(tt) / max(args.steps, 1) * 1e3, 4)}
+        if world > 1:
+            out["data_parallel"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(), "payload": "fp32",
+                                    "payload_bytes": flat.numel() * 4, "exchange_us": round(float(xus), 1), "plan": "host-enqueued",
+                                    "why": "CPU plumbing run (gloo): no HIP graph", "per_rank_ms_per_step": per_rank}
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -326,45 +367,106 @@ def main():
     for e0, e1 in prof:
         e0.record(); e1.record()
 
+    from mmdeer import _lib
     from mmdeer.optim import FusedAdamW
     opt = FusedAdamW(model, lr=1e-4, weight_decay=1e-5, eps=1e-8, max_grad_norm=1.0)   # reference trainer settings
 
-    # One step = ~45 kernels of 4-40 us: launched one by one the host needs about as long as the GPU, so the step is
+    def timed(fn, n):
+        """ms per call of `fn` over n calls, bracketed like the metric (barrier + synchronize, MAX over ranks)."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt) / n * 1e3
+
+    # One step = ~35 kernels of 4-40 us: launched one by one the host needs about as long as the GPU, so the step is
     # captured once into a HIP graph (dropout masks advance through a device-side counter) and replayed.
     ev = comm.events if comm else None
     comm_in_graph = False
     comm_mode = "none"
     replay = None
+    dp = None        # diagnostics of the data-parallel exchange (world > 1 or the 1-rank rehearsal)
+    if comm:
+        def exchange():
+            comm.launch(model.flat_grad())
+            comm.wait()
+        # the communicator is set up by one eager step + exchange OUTSIDE any capture; the exchange alone is then timed with
+        # events on the launch stream (max over ranks): what one all-reduce of the flat gradient costs when nothing hides it
+        model.train_step(a, v, t, y, **sc)
+        exchange()
+        torch.cuda.synchronize()
+        xe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        if world > 1:
+            dist.barrier()
+        for e0, e1 in xe:
+            e0.record(); exchange(); e1.record()
+        torch.cuda.synchronize()
+        xus = torch.tensor([sorted(e0.elapsed_time(e1) for e0, e1 in xe)[len(xe) // 2] * 1e3], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(xus, op=dist.ReduceOp.MAX)
+        flat_elems = int(model.flat_grad().numel())
+        dp = {"nranks": dist.get_world_size(), "backend": f"{dist.get_backend()} ({comm.backend} all-reduce)",
+              "payload": args.grad_comm, "payload_bytes": flat_elems * (2 if args.grad_comm == "bf16" else 4),
+              "exchange_us": round(float(xus), 1),
+              "exchange_us_note": "median over 10 host-enqueued exchanges (cast + all-reduce + cast back) timed with HIP events on "
+                                  "the launch stream, max over ranks: includes the host latency of the collective call"}
     if not args.eager:
         if comm and os.environ.get("MMDEER_GRAPH_COMM", "1") == "1":
-            # The gradient exchange is captured into the step's graph: enqueued from the host after every replay it cost
-            # ~85 us per step on a 1-rank group, inside the graph ~25 us (most of an RCCL call is host latency).
-            # Default: one all-reduce after the pass, inside the graph.  MMDEER_DP_OVERLAP=1: the backward pass in two
-            # calls with the all-reduce of buckets 0-1 on a side stream under the audio-visual part (splitting the
-            # weight-gradient launch costs ~45 us per step, so it only pays when the exchange itself is long).  Either
-            # falls back to the host-enqueued exchange if the capture fails.
-            def exchange():
-                comm.launch(model.flat_grad())
-                comm.wait()
-            plans = [("overlapped in-graph", dict(comm=comm))] if os.environ.get("MMDEER_DP_OVERLAP", "0") == "1" else []
-            plans.append(("in-graph", dict(after=exchange)))
-            for name, kw in plans:
+            # The exchange is captured into the step's graph (enqueued from the host after every replay it cost ~85 us per
+            # step on a 1-rank group, inside the graph ~25 us).  Two plans: "in-graph" = ONE all-reduce after the pass;
+            # "overlapped in-graph" = the backward pass in two calls with the all-reduce of buckets 0-1 (89 % of the
+            # gradient) on a side stream under the audio-visual part (splitting the weight-gradient launch costs ~45 us of
+            # compute per step, so it only pays when the exposed exchange is longer than that).  With more than one rank
+            # BOTH are captured and timed over a few steps and the faster one is kept (MMDEER_DP_OVERLAP=0 / 1 forces
+            # one); a plan whose capture fails is skipped, and without any the exchange is enqueued from the host.
+            force_plan = os.environ.get("MMDEER_DP_OVERLAP")
+            cands = []
+            if force_plan != "1":
+                cands.append(("in-graph", dict(after=exchange)))
+            if force_plan == "1" or (force_plan is None and world > 1):
+                cands.append(("overlapped in-graph", dict(comm=comm)))
+            plans, plan_ms = {}, {}
+            for name, kw in cands:
                 try:
-                    model.train_step(a, v, t, y, **sc)
-                    exchange()                       # communicator set up outside the capture
-                    torch.cuda.synchronize()
-                    replay = model.capture_train_step(a, v, t, y, events=ev, **kw, **sc)
-                    comm_in_graph, comm_mode = True, name
-                    break
+                    plans[name] = model.capture_train_step(a, v, t, y, events=ev, **kw, **sc)
                 except Exception as e:               # noqa: BLE001
                     print(f"[bench] {name} exchange not capturable here ({type(e).__name__}: {e})", file=sys.stderr)
                     torch.cuda.synchronize()
-                    replay = None
+            compute_only = model.capture_train_step(a, v, t, y, events=ev, **sc)      # the step without any exchange
+            for name, r in plans.items():
+                r(); r()
+                plan_ms[name] = round(timed(r, 10), 4)
+            compute_only(); compute_only()
+            compute_ms = round(timed(compute_only, 10), 4)
+            dp["compute_only_ms"] = compute_ms
+            dp["plan_ms"] = plan_ms
+            if plans:
+                best = min(plan_ms, key=plan_ms.get)
+                replay, comm_in_graph, comm_mode = plans[best], True, best
+                dp["plan"] = best
+                dp["exposed_exchange_us"] = round((plan_ms[best] - compute_ms) * 1e3, 1)
+                dp["why"] = (f"forced by MMDEER_DP_OVERLAP={force_plan}" if force_plan is not None else
+                             ("only plan tried on one rank" if len(plans) == 1 and world == 1 else
+                              "fastest of the plans timed over 10 steps: " + ", ".join(f"{k} {v} ms" for k, v in plan_ms.items())))
+            else:
+                replay, comm_mode = compute_only, "host-enqueued"
+                dp["plan"], dp["why"] = "host-enqueued", "no plan could be captured into the graph on this stack"
         if replay is None:
             replay = model.capture_train_step(a, v, t, y, events=ev, **sc)
             comm_mode = "host-enqueued" if comm else "none"
+            if dp is not None and "plan" not in dp:
+                dp["plan"], dp["why"] = "host-enqueued", "MMDEER_GRAPH_COMM=0"
     elif comm:
         comm_mode = "host-enqueued"
+        dp["plan"], dp["why"] = "host-enqueued", "--eager"
 
     def one_step(i=None, optimize=False):
         # The metric is forward + loss + backward.  The packed bf16 / transposed weight copies the kernels read are
@@ -392,19 +494,77 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed = time.perf_counter() - t0
+    per_rank_ms = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank_ms = [round(float(x) / K * 1e3, 4) for x in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     loss = float(ld["total_loss"])
     assert loss == loss, "loss is NaN"
-    if replay is not None:
-        # per-launch HIP events cannot ride inside a captured graph: the in_proj launch of the roofline object is
-        # timed over K eager launches of the same step right after the timed region (same kernel, inputs and stream)
+
+    # ---- spread of the step time: every replay between its own pair of events (a separate pass: event records inside the
+    #      timed region would perturb the metric).  min / median / max over K steps.
+    se = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    torch.cuda.synchronize()
+    se[0].record()
+    for i in range(K):
+        one_step()
+        se[i + 1].record()
+    torch.cuda.synchronize()
+    step_ms = sorted(se[i].elapsed_time(se[i + 1]) for i in range(K))
+
+    # ---- the roofline kernel, measured in THIS run.  bf16 fused plan: N back-to-back launches of tri_fused_kernel<0> on the
+    #      step's own operands (xtok / obar / probs of the workspace, the packed head-major weight image and the fp32 bias of
+    #      the weights buffer) captured into one HIP graph; events around a replay / N.  Replayed launches run gap-free (the
+    #      rocprofv3 trace of a replayed graph shows every kernel starting where the previous one ended), so this is the
+    #      same per-launch duration rocprofv3 --stats averages.  Other plans: HIP events around the launch in eager steps.
+    fused = args.dtype == "bf16" and _lib.get_option("fused_attn") == 1
+    roof_us, roof_how = None, None
+    if fused:
+        lib = _lib.load()
+        ws, wb = model._workspace(B, dev), model._weights(dev)
+        wo = lambda n: ws.data_ptr() + lib.mmdeer_workspace_offset(B, 0, n.encode())
+        bias_off = next(lib.mmdeer_param_offset(i) for i in range(lib.mmdeer_num_params())
+                        if lib.mmdeer_param_name(i).decode() == "fusion.trimodal_fusion.modality_attention.in_proj_bias")
+        whm = wb.data_ptr() + lib.mmdeer_weights_offset(0, b"wqkv_hm")
+        bias = wb.data_ptr() + lib.mmdeer_weights_offset(0, b"vpack") + 4 * bias_off
+        NL, NR, NX = 20, 10, 10
+        # In the step X (xtok) was written by the two launches before and is NOT resident in the L2 of the XCD that reads it;
+        # launched back to back on ONE buffer the kernel would find its operands in L2 from the previous launch (measured
+        # 13.3 us against 14.9 us in the step).  The launches therefore rotate over NX copies of the step's X (84 MB in all:
+        # beyond the 32 MB of L2, inside the Infinity Cache, as in the step).
+        nx = 2 * B * 512 * 2
+        xoff = lib.mmdeer_workspace_offset(B, 0, b"xtok")
+        xcopies = ws[xoff:xoff + nx].clone().repeat(NX).contiguous()
+
+        def launch_roof(i=0):
+            _lib.check(lib.mmdeer_trimodal_fused_fwd(xcopies.data_ptr() + (i % NX) * nx, whm, bias, wo("obar"), wo("probs"), None, None, None,
+                                                     B, 1, 0.3, model.dropout_seed, int(model._step), _lib.current_stream()))
+        launch_roof()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(NL):
+                launch_roof(i)
+        g.replay()
+        rev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(NR)]
+        for e0, e1 in rev:
+            e0.record(); g.replay(); e1.record()
+        torch.cuda.synchronize()
+        gemm_ms = sorted(e0.elapsed_time(e1) / NL for e0, e1 in rev)
+        roof_how = (f"HIP events around a HIP graph of {NL} back-to-back launches of the kernel on the step's own operands "
+                    f"(X rotated over {NX} copies so that it is not L2-resident from the previous launch, as in the step), / {NL}; "
+                    f"{NR} replays (this run; no profiler attached)")
+    else:
         for i in range(K):
             model.train_step(a, v, t, y, prof_events=prof[i])
         torch.cuda.synchronize()
+        gemm_ms = sorted(e0.elapsed_time(e1) for e0, e1 in prof)
+        roof_how = "HIP events around the kernel's launch inside K eager steps on the launch stream (includes the event pair and the launch gap)"
     # the same K steps again with the optimiser step inside (reported beside the metric, never as `value`)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -414,13 +574,12 @@ def main():
     full_elapsed = time.perf_counter() - t1
 
     if rank == 0:
-        gemm_ms = sorted(e0.elapsed_time(e1) for e0, e1 in prof)
         avg_ms = sum(gemm_ms) / len(gemm_ms)
         flops = 2.0 * (2 * B) * 512 * 1536                      # algorithmic: SURVEY 8d, 3.146 MFLOP/sample forward
-        fused = args.dtype == "bf16" and os.environ.get("MMDEER_FUSED_ATTN", "1") != "0"
         step_flops = 3 * 2.0 * 3950336 * B                       # 7.90 MFLOP/sample forward, x3 for the train step
         peak = BF16_MFMA_PEAK if args.dtype == "bf16" else F32_MFMA_PEAK
         achieved = flops / (avg_ms * 1e-3)
+        traffic, traffic_src = measured_traffic(args.dtype, B)
         out = {
             "metric": "samples/sec fwd+bwd at B=4096 (84/256/768-dim)",
             "value": round(world * B * K / elapsed, 1),
@@ -429,6 +588,8 @@ def main():
             "steps": K,
             "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 4),
+            "ms_per_step_min": round(step_ms[0], 4), "ms_per_step_median": round(step_ms[len(step_ms) // 2], 4),
+            "ms_per_step_max": round(step_ms[-1], 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -444,7 +605,7 @@ def main():
             "grad_exchange": comm_mode + (", exact-global loss statistics" if exact else ""),
             "final_loss": round(loss, 6),
             "train_step_with_optimizer_ms": round(full_elapsed / K * 1e3, 4),     # fwd + bwd + clip + AdamW + weight pack
-            "optimizer_ms": round((full_elapsed - elapsed) / K * 1e3, 4),
+            "optimizer_ms": round((full_elapsed - own_elapsed) / K * 1e3, 4),
             "roofline": {"bound": "mfma",
                          "kernel": ("tri_fused_kernel<0> (trimodal in_proj M=2B K=512 N=1536 + 2-token attention fused: q|k|v stay on chip)" if fused
                                     else ("gemm_nt256_kernel<192>" if args.dtype == "bf16" else "gemm_group_kernel") + " (trimodal in_proj, M=2B K=512 N=1536)"),
@@ -452,23 +613,22 @@ def main():
                          "frac": round(achieved / peak, 4),
                          # HBM-side bytes of one launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE,
                          # tools/gpu_pmc_fused.sh -> profiles/pmc_traffic.json); null unless taken on exactly these kernel sources
-                         "traffic": measured_traffic(args.dtype, B),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          # fused: X 8.39 + W 1.57 + obar 4.19 + probs 0.52 MB; unfused GEMM: A 8.39 + W 1.57 + C 25.17 MB
                          "algorithmic_bytes": (2 * B * 512 * 2 + 1536 * 512 * 2 + B * 512 * 2 + B * 32 * 4) if fused
                                               else (2 * B * 512 * 2 + 1536 * 512 * 2 + 2 * B * 1536 * 2),
                          "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(gemm_ms[len(gemm_ms) // 2] * 1e3, 2),
-                         "timing": "HIP events around the kernel's launch inside K eager steps on the launch stream (includes the ~3 us the "
-                                   "event pair and the launch gap cost); the rocprofv3 average of the same launches is in `rocprof`",
+                         "min_launch_us": round(gemm_ms[0] * 1e3, 2), "timing": roof_how,
                          # the whole step against the same peak: 97.1 GFLOP (algorithmic) / step time
                          "step_frac": round(step_flops / (elapsed / K) / peak, 4)},
         }
-        rp = rocprof_record(B, args.dtype, elapsed / K * 1e3)
+        if dp is not None:
+            if per_rank_ms is not None:
+                dp["per_rank_ms_per_step"] = per_rank_ms
+            out["data_parallel"] = dp
+        rp = recorded_profile(B, args.dtype)
         if rp is not None:
-            out["roofline"]["frac_rocprof"] = rp.pop("frac_rocprof", None)
-            out["rocprof"] = rp
-        if args.dtype == "bf16" and measured_mfma_peak():
-            # the nominal peak is the 2.4 GHz figure; under MFMA load the chip runs ~2.1 GHz: what a pure MFMA loop reaches here
-            out["roofline"]["peak_measured"] = measured_mfma_peak()
+            out["recorded_profile"] = rp     # read from committed files, NOT measured by this run
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out), flush=True)

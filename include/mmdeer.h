@@ -80,6 +80,10 @@ const char* mmdeer_option_name(int i);
  * h1 h2 [B,256], e1 [B,384], e2 [B,192], probs [B,8,4] f32, evid [B,3,4] f32, mean_* rstd_* [B] f32, and the gradients
  * dz2 de1 dh2 dh1 dfused dz_o1 dtri dz_t3 dpool dobar dqkv dxtok dav dz_a2 dcats davv davin of the same shapes. */
 long long mmdeer_workspace_offset(int batch, int compute_f32, const char* name);
+/* The same for the packed-parameter buffer (`weights`): wpack / wtpack (compute-dtype matrices and their transposes at the
+ * flat element offsets of mmdeer_param_offset), vpack (fp32 vectors, same offsets), wa_pad ([256][128] bf16 audio weight),
+ * wqkv_hm (head-major in_proj image of the fused kernels).  bench.py launches the roofline kernel on the step's operands. */
+long long mmdeer_weights_offset(int compute_f32, const char* name);
 
 typedef struct mmdeer_loss_cfg {
   float reg_weight;    /* losses.py:52  0.1  */

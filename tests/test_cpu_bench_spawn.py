@@ -22,6 +22,14 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["plumbing"] is True and d["steps"] == 3
+    # the diagnostics a first real multi-GPU run needs to be read without a second run: the same keys
+    # as the GPU line's `data_parallel` block
+    dp = d["data_parallel"]
+    assert dp["nranks"] == 2 and dp["backend"] == "gloo"
+    assert dp["payload_bytes"] == 4 * 2909120 or dp["payload_bytes"] % 256 == 0      # the flat gradient buffer, fp32
+    assert dp["exchange_us"] > 0 and dp["plan"] == "host-enqueued" and dp["why"]
+    assert len(dp["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in dp["per_rank_ms_per_step"])
+    assert max(dp["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.5 + 1.0
 
 
 def test_world_size_mismatch_fails_loudly():

@@ -210,6 +210,7 @@ SYMBOLS = [
     ("mmdeer_get_option", c_int, [c_char_p, C.POINTER(c_int)]),
     ("mmdeer_option_name", c_char_p, [c_int]),
     ("mmdeer_workspace_offset", c_ll, [c_int, c_int, c_char_p]),
+    ("mmdeer_weights_offset", c_ll, [c_int, c_char_p]),
 ]
 
 

@@ -406,6 +406,16 @@ long long mmdeer_workspace_offset(int batch, int compute_f32, const char* name) 
   return -1;
 }
 
+long long mmdeer_weights_offset(int compute_f32, const char* name) {
+  if (!name) return -1;
+  char* const base = reinterpret_cast<char*>(uintptr_t(1) << 40);
+  const Layout L = make_layout(base, base, 0, compute_f32 ? 1 : 0);
+#define WT(field) if (strcmp(name, #field) == 0) return reinterpret_cast<const char*>(L.field) - base;
+  WT(wpack) WT(wtpack) WT(vpack) WT(wa_pad) WT(wqkv_hm)
+#undef WT
+  return -1;
+}
+
 long long mmdeer_bucket_begin(int b) {
   switch (b) { case 0: return kParams[P_FP0_W].off; case 1: return kParams[P_AVP_W].off; case 2: return 0; default: return -1; }
 }

@@ -99,6 +99,7 @@ class BucketedAllReduce:
         self._work: List = []
         self._half: Optional[torch.Tensor] = None
         self._side: Optional["torch.cuda.Stream"] = None
+        self._rccl_side: Optional[RcclCommunicator] = None
 
     def _convert(self, src: torch.Tensor, dst: torch.Tensor) -> None:
         from . import _lib
@@ -147,12 +148,22 @@ class BucketedAllReduce:
         return self.cuda and (self.world > 1 or self.force)
 
     def launch_range(self, flat: torch.Tensor, lo: int, hi: int) -> None:
-        """All-reduce ``flat[lo:hi]`` on the side stream, ordered after everything enqueued on the current stream."""
+        """All-reduce ``flat[lo:hi]`` on the side stream, ordered after everything enqueued on the current stream.
+
+        The side-stream exchange always goes through the C-ABI communicator (``mmdeer_allreduce``: enqueue-only on the
+        stream it is given).  torch.distributed's NCCL work objects waited for on a side stream INSIDE a HIP-graph capture
+        crash ``hipStreamEndCapture`` on this stack (torch 2.10 + ROCm 7.0 RCCL 2.26: SIGSEGV in ``capture_end``, found in
+        round 3 with tools/dp_overlap_probe.py; both payloads), while the same plan through ``mmdeer_allreduce`` captures and
+        replays.  The communicator is created at the first (eager, un-captured) call -- collectively, like every rank's
+        first step."""
         if not self.active or hi <= lo:
             return
+        if self._rccl_side is None:
+            self._rccl_side = self._rccl or RcclCommunicator.from_torch_distributed(self.group)
         if self._side is None:
             self._side = torch.cuda.Stream(device=flat.device)
         self._side.wait_stream(torch.cuda.current_stream())
+        avg = not self.exact_global
         with torch.cuda.stream(self._side):
             view = flat[lo:hi]
             if self.payload == "bf16":
@@ -160,14 +171,10 @@ class BucketedAllReduce:
                     self._half = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
                 half = self._half[lo:hi]
                 self._convert(view, half)
-                w = self._reduce(half)
-                if w is not None:
-                    w.wait()
+                self._rccl_side.all_reduce(half, average=avg)
                 self._convert(half, view)
             else:
-                w = self._reduce(view)
-                if w is not None:
-                    w.wait()
+                self._rccl_side.all_reduce(view, average=avg)
 
     def join(self) -> None:
         """The current stream waits for the exchanges launched with ``launch_range``."""
