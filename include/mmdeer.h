@@ -31,7 +31,15 @@ extern "C" {
 
 #define MMDEER_ABI_VERSION 13
 
-/* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20) */
+/* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20).
+ * RESTRICTION: mmdeer_forward / mmdeer_backward / mmdeer_adamw_step (the Stack C entry points) are compiled for exactly this
+ * geometry -- audio 84, video 256, text 768 -> intermediate 256 -> fusion 512 x 8 heads -> head 256 / 128 / 64 / 4 x 3
+ * dimensions: the parameter table (MMDEER_NUM_PARAMS_ABI rows at fixed flat offsets), the workspace layout, the fused
+ * projection + attention kernel (512-wide rows, head dimension 64, two tokens) and the NIG head kernels are sized by these
+ * constants.  The reference's constructor takes other widths (fusion.py:47-50); the host mirror refuses them with
+ * NotImplementedError (mmdeer/model.py) instead of running a slower generic plan.  The single operators below
+ * (mmdeer_gemm, mmdeer_layernorm_*, mmdeer_nig_loss, ...) and the Stack B entry points take any sizes that meet their
+ * alignment rules (stackb.CompleteDEERModel runs other widths and depths: tests/test_gpu_stackb.py). */
 #define MMDEER_AUDIO_DIM 84
 #define MMDEER_VIDEO_DIM 256
 #define MMDEER_TEXT_DIM 768

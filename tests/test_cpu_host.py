@@ -247,3 +247,46 @@ def test_create_fusion_module_factory():
     assert ada.fusion_modules["bilinear"].bilinear.weight.shape == (256, 84, 256) and ada.strategy_selector[0].out_features == 2
     with pytest.raises(RuntimeError, match="no CPU fallback"):         # product path: HIP or nothing
         att([torch.zeros(2, 256)] * 3)
+
+
+def test_compat_modules_resolve_by_bare_name():
+    """SURVEY 8b row 1 / VERDICT r2 missing #5: with compat/ on sys.path the bare-name imports of the reference's script
+    (run_multimodal_deer.py:70-82) resolve to the HIP-backed classes.  A fresh interpreter: names like `metrics`, `losses`,
+    `training` must not leak into this process's sys.modules."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from multi_dataset_framework import MultiDatasetDEERFramework\n"
+        "from complete_project import CompleteDEERModel, ModelConfig\n"
+        "from training import DEERTrainer, TrainingConfig\n"
+        "from preprocessing import create_enhanced_dataloaders\n"
+        "from deer import test_deer_implementation\n"
+        "from encoders import AudioEncoder, VideoEncoder, TextEncoder\n"
+        "from fusion import HierarchicalMultimodalFusion\n"
+        "from evaluation import evaluate_deer_model\n"
+        "from metrics import DEERMetrics\n"
+        "from losses import DEERLoss\n"
+        "from visualization import create_comprehensive_report, test_visualization_components\n"
+        "import mmdeer.model as M, mmdeer.trainer as T, mmdeer.losses as L, mmdeer.metrics as X\n"
+        "assert CompleteDEERModel is M.MultimodalDEER and ModelConfig is M.ModelConfig\n"
+        "assert DEERTrainer is T.DEERTrainer and TrainingConfig is T.TrainingConfig and evaluate_deer_model is T.evaluate_deer_model\n"
+        "assert HierarchicalMultimodalFusion is M.HierarchicalMultimodalFusion and DEERLoss is L.DEERLoss and DEERMetrics is X.DEERMetrics\n"
+        "cfg = ModelConfig(audio_dim=84, video_dim=256, text_dim=768, fusion_dim=512, emotion_dims=3, dropout=0.3, attention_heads=8)\n"
+        "m = CompleteDEERModel(cfg)                      # run_multimodal_deer.py:237-247\n"
+        "assert sum(p.numel() for p in m.parameters()) == 3105711\n"
+        "for stub, args in ((MultiDatasetDEERFramework, ()), (AudioEncoder, ()), (create_enhanced_dataloaders, ())):\n"
+        "    try:\n"
+        "        stub(*args)\n"
+        "    except NotImplementedError as e:\n"
+        "        assert 'SURVEY' in str(e)\n"
+        "    else:\n"
+        "        raise SystemExit('out-of-scope stub did not raise')\n"
+        "print('ok')\n") % (ROOT, os.path.join(ROOT, "compat"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+    env = dict(os.environ, MMDEER_STACK="b")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                        "from complete_project import CompleteDEERModel\nimport mmdeer.stackb as S\nassert CompleteDEERModel is S.CompleteDEERModel"
+                        % (ROOT, os.path.join(ROOT, "compat"))], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -53,6 +53,23 @@ def _worker(rank, world, port, q):
         ok = ok and np.array_equal(torch.cat(gathered).numpy(), whole)
         b, e = shard_rows(world * B, rank, world)
         ok = ok and (b, e) == (rank * B, (rank + 1) * B)
+        # data-parallel training through DEERTrainer must not draw the same dropout masks on every rank:
+        # identical parameters (seed), a dropout stream of its own per rank unless the caller chose one
+        import tempfile
+
+        from mmdeer.model import ModelConfig, MultimodalDEER
+        from mmdeer.trainer import DEERTrainer, TrainingConfig
+        tmp = tempfile.mkdtemp()
+        dirs = dict(output_dir=tmp + "/o", log_dir=tmp + "/l", checkpoint_dir=tmp + "/c")
+        m = MultimodalDEER(ModelConfig(seed=42))
+        ok = ok and m.config.dropout_seed is None
+        DEERTrainer(m, TrainingConfig(fused_optimizer=False, **dirs), device="cpu", comm=comm)
+        seeds = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(seeds, torch.tensor([m.dropout_seed], dtype=torch.int64))
+        ok = ok and [int(x) for x in seeds] == [42 + 1000003 * r for r in range(world)]
+        m2 = MultimodalDEER(ModelConfig(seed=42, dropout_seed=7))           # an explicit choice is kept
+        DEERTrainer(m2, TrainingConfig(fused_optimizer=False, **dirs), device="cpu", comm=comm)
+        ok = ok and m2.dropout_seed == 7
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

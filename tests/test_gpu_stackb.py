@@ -338,9 +338,10 @@ def test_stackb_captured_train_step_equals_eager_and_draws_fresh_masks():
         torch.cuda.synchronize()
         losses.append(float(ld["total_loss"]))
         g1 = {n: p.grad.clone() for n, p in m1.named_parameters() if p.grad is not None}
-        # the eager twin at the same effective dropout step = host step frozen into the graph + device counter
+        # the eager twin at the same dropout step: the replay used the step the device counter now holds
         m2.train()
-        m2._train_step = replay.frozen_step + int(m1._drop_counter.item())
+        assert int(replay.counter.item()) == m1._train_step - 1
+        m2._train_step = int(replay.counter.item())
         for p in m2.parameters():
             p.grad = None
         l2 = m2.compute_loss(m2(*xs), y)
@@ -354,6 +355,14 @@ def test_stackb_captured_train_step_equals_eager_and_draws_fresh_masks():
     b2 = synth.make_batch(128, seed=22)
     xs2, y2 = _batch_dev(b2)
     assert float(replay(*xs2, y2)["total_loss"]) != losses[-1]
+    # replay -> eager step (e.g. a ragged tail batch) -> replay must draw three DIFFERENT masks: the steps they hash
+    steps = []
+    replay(*xs, y); steps.append(int(replay.counter.item()))
+    steps.append(m1._train_step)                             # what the eager forward below hashes
+    m1.train(); l_e = m1.compute_loss(m1(*xs), y); l_e["total_loss"].backward()
+    replay(*xs, y); steps.append(int(replay.counter.item()))
+    torch.cuda.synchronize()
+    assert steps[1] == steps[0] + 1 and steps[2] == steps[1] + 1, steps
     # optimiser inside the graph
     m3, _ = _train_model("bf16")
     opt = torch.optim.AdamW(m3.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True)

@@ -75,6 +75,28 @@ def test_trainer_validation_frequency_patience_and_resume(tmp_path):
         assert torch.equal(p1, p2), n1
 
 
+def test_trainer_resume_with_dropout_continues_the_mask_stream(tmp_path):
+    """a checkpoint carries the dropout stream position (model._step) and train() continues after the saved
+    epoch -- a run resumed from the epoch-1 checkpoint of a 4-epoch run ends bit for bit where the uninterrupted run ended,
+    with dropout 0.3 live and without the test touching _step."""
+    mk = lambda: MultimodalDEER(ModelConfig(compute_dtype="fp32", dropout=0.3, seed=3))
+    cfg = dict(learning_rate=3e-4, batch_size=32, num_epochs=4, val_frequency=100, save_frequency=1, output_dir=str(tmp_path / "o"),
+               log_dir=str(tmp_path / "l"))
+    tr = DEERTrainer(mk(), TrainingConfig(checkpoint_dir=str(tmp_path / "c1"), **cfg), "cuda:0")
+    tr.train(loaders(64, 32, 1, False), {})
+    ck_path = str(tmp_path / "c1" / "checkpoint_epoch_1.pt")
+    ck = torch.load(ck_path, weights_only=False)
+    assert ck["dropout_state"]["_step"] == 4 and ck["epoch"] == 1          # 2 epochs x 2 batches
+    tr2 = DEERTrainer(mk(), TrainingConfig(checkpoint_dir=str(tmp_path / "c2"), **cfg), "cuda:0")
+    tr2.load_checkpoint(ck_path)
+    assert tr2.model._step == 4
+    h2 = tr2.train(loaders(64, 32, 1, False), {})
+    assert tr2.current_epoch == 3 and tr2.model._step == tr.model._step == 8
+    assert len(h2["learning_rate"]) == 4                                   # 2 from the checkpoint's history + 2 resumed epochs
+    for (n1, p1), (_, p2) in zip(tr.model.named_parameters(), tr2.model.named_parameters()):
+        assert torch.equal(p1, p2), n1
+
+
 def test_clip_matches_torch_clip_grad_norm():
     model = MultimodalDEER(ModelConfig(dropout=0.0)).to("cuda:0").train()
     b = {k: torch.from_numpy(v).to("cuda:0") for k, v in synth.make_batch(16, seed=4).items()}

@@ -634,8 +634,14 @@ class HierarchicalMultimodalFusion(nn.Module):
 
     def forward(self, audio_features, video_features, text_features, uncertainties=None) -> Dict[str, torch.Tensor]:
         if uncertainties is not None:
-            # the reference's own path for this argument raises a TypeError (fusion.py:148-150 against :384)
-            raise NotImplementedError("uncertainty weighting is unreachable in the reference and not built")
+            # Same failure as the reference: with `uncertainties` given and use_uncertainty_weighting=True its forward calls
+            # self.uncertainty_gate(audio, video, text, uncertainties) positionally (fusion.py:148-150) against
+            # forward(self, *modality_features, uncertainties) (:384) and dies with exactly this TypeError.  Algebraically the
+            # branch would scale the features by (1 + 0.1 / 3) (the mean of a softmax over three is 1/3, :173-185); it has no
+            # working caller anywhere in the reference, so it is not built and parity stays unpinned.
+            raise TypeError("forward() missing 1 required keyword-only argument: 'uncertainties' "
+                            "[UncertaintyAwareGating is unreachable in the reference (fusion.py:148-150 vs :384); "
+                            "call with uncertainties=None]")
         out = self._core(audio_features, video_features, text_features)
         return {k: out[k] for k in self.KEYS}
 

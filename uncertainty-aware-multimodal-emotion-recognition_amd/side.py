@@ -191,10 +191,16 @@ class ModalityEncoders(nn.Module):
         self.video_encoder = nn.Linear(video_dim, hidden_dim)
         self.text_encoder = nn.Linear(text_dim, hidden_dim)
 
-    @torch.no_grad()
     def forward(self, audio, video, text):
+        """Differentiable when gradients are enabled (forward GEMM with the ReLU in its epilogue; backward = the (Y > 0) mask,
+        dX = dY W and dW = dY^T X + bias gradient as three more ``mmdeer_gemm`` calls per encoder), else the plain operator."""
         c = self.compute_dtype
-        enc = lambda x, m: ops.linear(x, m.weight, m.bias, relu=True, compute=c)   # noqa: E731
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                        any(torch.is_tensor(x) and x.requires_grad for x in (audio, video, text))):
+            from .fusions import linear
+            enc = lambda x, m: linear(x, m, c, relu=True)                              # noqa: E731
+        else:
+            enc = lambda x, m: ops.linear(x, m.weight, m.bias, relu=True, compute=c)   # noqa: E731
         return enc(audio, self.audio_encoder), enc(video, self.video_encoder), enc(text, self.text_encoder)
 
 

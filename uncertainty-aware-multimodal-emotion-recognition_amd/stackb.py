@@ -253,10 +253,15 @@ class CompleteDEERModel(nn.Module):
         xs = [x.detach().float().contiguous() for x in xs]
         drop = None
         if dropout:
-            # mask key = hash(seed, step + *device counter, site, row, column): the host step advances per eager forward, the device
-            # counter per replay of a captured step (capture_train_step)
-            drop = (self.config.dropout, int(self.config.dropout_seed), self._train_step, self._drop_counter)
-            self._train_step += 1
+            # mask key = hash(seed, step, site, row, column).  Eager forwards hash the host-side step (and advance it); inside a
+            # captured step (capture_train_step) the step lives in a device counter the graph bumps itself, with 0 frozen in
+            # as the host part -- replay() keeps the two in line, so a replay / eager / replay sequence draws three
+            # different masks (the old scheme added host + device and could repeat an offset)
+            if getattr(self, "_in_graph_step", False):
+                drop = (self.config.dropout, int(self.config.dropout_seed), 0, self._drop_counter)
+            else:
+                drop = (self.config.dropout, int(self.config.dropout_seed), self._train_step, None)
+                self._train_step += 1
         names = [n for n, _ in self.named_parameters()]
         core, tape = _StackBFn.apply(self, xs, drop, names, *[p for _, p in self.named_parameters()])
         planes = tape["planes"]
@@ -294,14 +299,19 @@ class CompleteDEERModel(nn.Module):
         dropout masks: a device counter, bumped inside the graph, is added to the step the library hashes."""
         dev = audio.device
         static = [x.detach().float().contiguous().clone() for x in (audio, video, text, targets)]
-        if self._drop_counter is None or self._drop_counter.device != dev:
-            self._drop_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        # the device counter holds the step the LAST graph-side forward used; host invariant: _train_step == counter + 1
+        self._drop_counter = torch.full((1,), int(self._train_step) - 1, dtype=torch.int64, device=dev)
+        counter = self._drop_counter
         was = self.training
         self.train()
 
         def step():
-            self._drop_counter.add_(1)
-            loss = self.compute_loss(self(*static[:3]), static[3])
+            counter.add_(1)
+            self._drop_counter, self._in_graph_step = counter, True
+            try:
+                loss = self.compute_loss(self(*static[:3]), static[3])
+            finally:
+                self._in_graph_step = False
             loss["total_loss"].backward()
             if optimizer is not None:
                 if max_grad_norm is not None:
@@ -318,23 +328,28 @@ class CompleteDEERModel(nn.Module):
                 for p in self.parameters():
                     p.grad = None
                 step()
+                self._train_step += 1                         # each warm-up step used one step of the stream
         torch.cuda.current_stream().wait_stream(side)
         for p in self.parameters():
             p.grad = None
-        frozen_step = self._train_step                          # the host counter baked into the graph
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            loss = step()
+            loss = step()                                     # recorded, not executed: the counter is not advanced here
         self.train(was)
+        shadow = [int(self._train_step) - 1]                  # what the device counter holds
 
         def replay(a=None, v=None, t=None, y=None):
             for dst, src in zip(static, (a, v, t, y)):
                 if src is not None:
                     dst.copy_(src, non_blocking=True)
-            graph.replay()
+            if int(self._train_step) - 1 != shadow[0]:        # eager forwards in between advanced the host step only
+                counter.fill_(int(self._train_step) - 1)
+            graph.replay()                                    # uses step == _train_step (counter + 1)
+            self._train_step += 1
+            shadow[0] = int(self._train_step) - 1
             return loss
 
-        replay.graph, replay.static_inputs, replay.loss, replay.frozen_step = graph, static, loss, frozen_step
+        replay.graph, replay.static_inputs, replay.loss, replay.counter = graph, static, loss, counter
         return replay
 
     def _forward_eval(self, audio_features, video_features, text_features) -> Dict[str, torch.Tensor]:

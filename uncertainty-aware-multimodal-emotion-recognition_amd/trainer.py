@@ -64,6 +64,14 @@ class DEERTrainer:
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         self.model = model.to(self.device)
         self.comm = comm                     # optional mmdeer.parallel.BucketedAllReduce (data parallel)
+        # Data parallel: the ranks hold identical parameters (same `seed`) but must not draw identical dropout masks for their
+        # local rows -- the mask hash is a function of (dropout_seed, step, site, LOCAL row, column).  Unless the caller chose
+        # a dropout_seed, rank r gets seed + 1000003 r (what bench.py does for its ranks).
+        world = int(getattr(comm, "world", 1) or 1) if comm is not None else 1
+        if world > 1 and hasattr(model, "config") and getattr(model.config, "dropout_seed", None) is None:
+            import torch.distributed as dist
+            rank = int(getattr(comm, "rank", dist.get_rank(getattr(comm, "group", None)) if dist.is_initialized() else 0))
+            model.config.dropout_seed = int(model.config.seed) + 1000003 * rank
         # Stack B (stackb.CompleteDEERModel) trains through autograd: forward -> compute_loss -> backward into .grad, then
         # clip_grad_norm_ + torch.optim.AdamW exactly as training.py:205-224; Stack C has the fused step + flat buffer
         self.generic = not hasattr(model, "flat_grad")
@@ -72,6 +80,7 @@ class DEERTrainer:
         self.optimizer = self._create_optimizer()
         self.scheduler = self._create_scheduler()
         self.current_epoch = 0
+        self._resumed = False                # load_checkpoint() sets it: train() then continues after `current_epoch`
         self.history = {"train_loss": [], "val_loss": [], "train_ccc": [], "val_ccc": [], "learning_rate": [], "grad_norm": []}
         for d in (self.config.output_dir, self.config.log_dir, self.config.checkpoint_dir):
             os.makedirs(d, exist_ok=True)
@@ -194,9 +203,13 @@ class DEERTrainer:
         (run_multimodal_deer.py:503-509)."""
         t0 = time.time()
         c = self.config
-        self.best_ccc, self.best_val_loss, self.patience_counter = -float("inf"), float("inf"), 0
+        first = 0
+        if self._resumed:          # continue a checkpointed run: next epoch, best model / patience as they were
+            first, self._resumed = self.current_epoch + 1, False
+        else:
+            self.best_ccc, self.best_val_loss, self.patience_counter = -float("inf"), float("inf"), 0
         vf, sf = max(1, int(c.val_frequency)), max(1, int(c.save_frequency))
-        for epoch in range(c.num_epochs):
+        for epoch in range(first, c.num_epochs):
             self.current_epoch = epoch
             tr = self.train_epoch(train_loaders)
             va, stop = None, False
@@ -240,11 +253,16 @@ class DEERTrainer:
     def save_checkpoint(self, path: str, training_time: float = 0.0, epoch: Optional[int] = None, loss: Optional[float] = None) -> None:
         """Checkpoint layout of run_multimodal_deer.py:512-517 (model_state_dict / training_config / training_history /
         training_time) plus what a resume needs and the reference's ModelCheckpoint calls pass (training.py:415-418):
-        optimiser state (FusedAdamW: step count and the flat moment buffers), scheduler state, epoch, loss."""
+        optimiser state (FusedAdamW: step count and the flat moment buffers), scheduler state, epoch, loss, the model's
+        dropout stream position (masks are a hash of (seed, step): without it a resumed run would replay the masks of steps
+        0..N instead of continuing the stream) and the best-model / early-stopping bookkeeping of ``train``."""
         torch.save({"model_state_dict": self.model.state_dict(), "training_config": asdict(self.config),
                     "training_history": self.history, "training_time": training_time,
                     "optimizer_state_dict": self.optimizer.state_dict(), "scheduler_state_dict": self.scheduler.state_dict(),
-                    "epoch": epoch, "loss": loss}, path)
+                    "epoch": epoch, "loss": loss, "dropout_state": dropout_state(self.model),
+                    "trainer_state": {"best_ccc": getattr(self, "best_ccc", -float("inf")),
+                                      "best_val_loss": getattr(self, "best_val_loss", float("inf")),
+                                      "patience_counter": getattr(self, "patience_counter", 0)}}, path)
 
     def load_checkpoint(self, path: str) -> Dict:
         """Resume from ``save_checkpoint``: parameters, optimiser moments / step, scheduler, history."""
@@ -255,9 +273,28 @@ class DEERTrainer:
         if ck.get("scheduler_state_dict") is not None:
             self.scheduler.load_state_dict(ck["scheduler_state_dict"])
         self.history = ck.get("training_history", self.history)
+        if ck.get("dropout_state") is not None:
+            load_dropout_state(self.model, ck["dropout_state"])
+        ts = ck.get("trainer_state") or {}
+        self.best_ccc = ts.get("best_ccc", -float("inf"))
+        self.best_val_loss = ts.get("best_val_loss", float("inf"))
+        self.patience_counter = ts.get("patience_counter", 0)
         if ck.get("epoch") is not None:
             self.current_epoch = int(ck["epoch"])
+            self._resumed = True             # train() continues with epoch + 1
         return ck
+
+
+def dropout_state(model) -> Dict[str, int]:
+    """Position of the model's dropout stream: Stack C counts training forwards in ``_step``, Stack B in ``_train_step``
+    (their device-side counters are re-aligned to it by the captured steps' ``replay``)."""
+    return {k: int(getattr(model, k)) for k in ("_step", "_train_step") if hasattr(model, k)}
+
+
+def load_dropout_state(model, state: Dict[str, int]) -> None:
+    for k, v in state.items():
+        if hasattr(model, k):
+            setattr(model, k, int(v))
 
 
 @torch.no_grad()
