@@ -153,7 +153,7 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
 struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
 OptEntry g_opts[OPT_COUNT] = {
     {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
-    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"nig_fused", 1, {1}},
+    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"splitk_max", 8, {8}},
 };
 }  // namespace
 
@@ -283,7 +283,8 @@ struct Exec {
     const int nk = gemm_ktiles(p.K, f32);
     const int kst = ksteps_target(f32);
     int sk = (nk + kst - 1) / kst;
-    if (sk > SPLITK_MAX) sk = SPLITK_MAX;
+    const int cap = opt(OPT_SPLITK_MAX) < SPLITK_MAX ? opt(OPT_SPLITK_MAX) : SPLITK_MAX;
+    if (sk > cap) sk = cap;
     if (sk < 1) sk = 1;
     p.splitk = sk;
     p.slab_stride = MMDEER_FLAT_ELEMS;

@@ -8,13 +8,16 @@
 // One workgroup = 8 waves (4 along M x 2 along N), each a 64x128 sub-tile = 4x8 MFMA 16x16x32 accumulators
 // (128 VGPRs).  K advances in 32-row stages (one MFMA k-step): a stage is two images of 32 rows x 512 B, copied AS
 // STORED by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB = 2 rows per instruction, 4 instructions per wave per
-// stage) into a 4-stage ring (128 KiB), two to three stages in flight.  The two waves of a SIMD work in opposite
-// phases (one issues MFMAs while the other reads fragments / issues DMA), see the loop.  Fragments are read with ds_read_b64_tr_b16 (the
+// stage) into a 5-stage ring (160 KiB: the whole LDS of the CU), three to four stages in flight.  The two waves of a SIMD
+// work in opposite phases (one issues MFMAs, interleaved with the fragment reads of its NEXT tile, while the other issues
+// DMA and waits), see the loop.  Fragments are read with ds_read_b64_tr_b16 (the
 // hardware transposes a 4-row x 16-column block), two reads per fragment.  Swizzle: the 16-byte chunk at slot p of
 // image row r holds logical chunk p ^ f(r), f(r) = (((r >> 3) & 1) << 3) | ((r & 3) << 1), applied to the DMA source
 // address and to the read address alike: the 8 rows a half-wave reads in one LDS cycle land on 8 distinct 32-byte
 // bank groups.  Counted vmcnt + raw s_barrier as in gemm_glds.hip.
 #include "gemm_kernel.inc"
+
+#include <type_traits>
 
 namespace mmdeer {
 namespace {
@@ -54,7 +57,7 @@ __device__ __forceinline__ void wait_lgkm(u32x2& a, u32x2& b, u32x2& c, u32x2& d
 }
 
 __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
-  constexpr int BM = 256, BN = 256, KT = 32, NST = 4;
+  constexpr int BM = 256, BN = 256, KT = 32, NST = 5;
   constexpr int TM = 4, TN = 8;                 // 16x16 accumulators per wave: 64 x 128
   constexpr int ROWB = 512;                     // bytes per image row
   constexpr int OPER = KT * ROWB, STAGE = 2 * OPER;
@@ -149,48 +152,61 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) offb[j] = lds_base + lane_off + (((wn * 8 + j) ^ h) * 32) + OPER;
 
-  // ---- ring + ping-pong.  A wave alternates a LOAD phase L(t) (DMA issue of tile t+3, fragment reads of tile t)
-  //      and an MFMA phase M(t), with a workgroup barrier after every phase.  Waves 4-7 run one phase behind waves
-  //      0-3, so while one half of the workgroup (one wave per SIMD) issues MFMAs the other half uses the LDS and
-  //      the DMA path.  Data validity: every wave ends L(t-1) by waiting for ITS pieces of tile t, so after the
-  //      barriers that separate it from any L(t) all pieces of tile t have landed; slot reuse: L(t) overwrites the
-  //      slot of tile t-1, which both halves finished reading at least one barrier earlier.
+  // ---- ring (5 slots) + ping-pong, the schedule of tri_fused.hip.  A wave alternates
+  //        L(t): DMA issue of tile t+4 | wait: fragments of tile t in registers, own pieces of tile t+2 landed | barrier
+  //        M(t): 32 (+4) MFMAs on the fragments of tile t, interleaved with the 24 fragment reads of tile t+1 (second
+  //              register set) | barrier
+  //      and waves 4-7 run one phase behind waves 0-3: on every SIMD one wave is in M (matrix pipe + LDS reads) while the
+  //      other is in L (vector-memory issue: four LDS-DMA instructions cost a wave ~500 cycles of issue).  Round 2 read the
+  //      fragments in L, which made L (24 reads + 4 DMA issues + their waits, ~800 cycles) the longer phase against 576
+  //      cycles of MFMAs in M: 1630 cycles per tile where the matrix pipe needs 1150.
+  //      Validity: tile t+1 is read in M(t); every wave waited for ITS pieces of it in L(t-1), which for either half ends
+  //      at least one barrier before any M(t) begins (the 4-slot ring of round 2 could not give that guarantee to a
+  //      prefetching M phase: the leading half read tile t+1 one barrier before the trailing half had waited for its
+  //      pieces -- caught by the bit-identical-rerun test).  Slot reuse: L(t) overwrites the slot of tile t-1, whose reads
+  //      (issued in M(t-2)) every wave retired in ITS L(t-1), again at least one barrier earlier.
   const bool second = wave >= 4;
   TSTAMP(0);
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
     if (t < nk) issue(t);
-  if (nk > 2) wait_vm<LPT>();   // tiles 0 and 1 landed (tile 2 may be in flight)
-  else wait_vm<0>();
+  {   // tiles 0 and 1 landed (those issued after them may be in flight)
+    const int younger = (nk < NST - 1 ? nk : NST - 1) - 2;
+    if (younger >= 2) wait_vm<2 * LPT>();
+    else if (younger == 1) wait_vm<LPT>();
+    else wait_vm<0>();
+  }
   __builtin_amdgcn_s_barrier();
   TSTAMP(1);
-  if (second) __builtin_amdgcn_s_barrier();
-  int stage = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    TSTAMP(8 + kt * 5);
-    // ---- L(kt): fragment reads of tile kt first (they only need the LDS), then the DMA of tile kt+3 into the slot
-    //      of tile kt-1 while the reads return
-    const unsigned so = stage * STAGE;
-    u32x2 al[TM], ah[TM], bl[TN], bh[TN];
+  u32x2 al0[TM], ah0[TM], bl0[TN], bh0[TN], al1[TM], ah1[TM], bl1[TN], bh1[TN];
+  auto read_frags = [&](unsigned so, u32x2 (&al)[TM], u32x2 (&ah)[TM], u32x2 (&bl)[TN], u32x2 (&bh)[TN]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) { al[i] = lds_tr_read<0>(offa[i] + so); ah[i] = lds_tr_read<4 * ROWB>(offa[i] + so); }
 #pragma unroll
     for (int j = 0; j < TN; ++j) { bl[j] = lds_tr_read<0>(offb[j] + so); bh[j] = lds_tr_read<4 * ROWB>(offb[j] + so); }
-    TSTAMP(8 + kt * 5 + 1);
-    if (kt + NST - 1 < nk) issue((stage + NST - 1) & (NST - 1));
+  };
+  read_frags(0u, al0, ah0, bl0, bh0);
+  if (second) __builtin_amdgcn_s_barrier();     // waves 4-7: one phase behind
+  unsigned rd = STAGE;                          // byte offset of the slot the next M phase reads (tile kt + 1)
+  int wr = NST - 1;                             // slot the next L phase fills (tile kt + 4)
+  auto phase_l = [&](int kt, u32x2 (&al)[TM], u32x2 (&ah)[TM], u32x2 (&bl)[TN], u32x2 (&bh)[TN]) __attribute__((always_inline)) {
+    if (kt + NST - 1 < nk) { issue(wr); wr = wr + 1 == NST ? 0 : wr + 1; }
     wait_lgkm<0>(al[0], ah[0], al[1], ah[1], al[2], ah[2], al[3], ah[3]);
     wait_lgkm<0>(bl[0], bh[0], bl[1], bh[1], bl[2], bh[2], bl[3], bh[3]);
     wait_lgkm<0>(bl[4], bh[4], bl[5], bh[5], bl[6], bh[6], bl[7], bh[7]);
-    // own pieces of tile kt+1 landed; the tiles issued after it (kt+2, kt+3, where they exist) may be in flight
-    {
-      const int younger = nk - 2 - kt;   // tiles after kt+1
-      if (younger >= 2) wait_vm<2 * LPT>();
-      else if (younger == 1) wait_vm<LPT>();
-      else wait_vm<0>();
-    }
+    // own pieces of tile kt+2 landed; the tiles issued after it (kt+3, kt+4, where they exist) may be in flight
+    int younger = (nk - 1 < kt + NST - 1 ? nk - 1 : kt + NST - 1) - (kt + 2);
+    if (younger >= 2) wait_vm<2 * LPT>();
+    else if (younger == 1) wait_vm<LPT>();
+    else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    TSTAMP(8 + kt * 5 + 2);
-    // ---- M(kt): D[n][m] += X-fragment (rows n) x dY-fragment (cols m): a lane ends up with 4 consecutive n of one m
+  };
+  // M phase: MFMA column block j (4 MFMAs, all row blocks) behind three fragment reads of the next tile -- reads 3 j .. 3 j + 2
+  // of the order al[0..3], ah[0..3], bl[0..7], bh[0..7].  The last tile's phase reads a slot nobody needs (unconditional:
+  // no branch in the MFMA stream); those registers are retired after the loop.
+  auto phase_m = [&](bool last, const u32x2 (&al)[TM], const u32x2 (&ah)[TM], const u32x2 (&bl)[TN], const u32x2 (&bh)[TN],
+                     u32x2 (&nal)[TM], u32x2 (&nah)[TM], u32x2 (&nbl)[TN], u32x2 (&nbh)[TN]) __attribute__((always_inline)) {
+    const unsigned so = rd;
     u32x4 fa[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[i] = u32x4{al[i].x, al[i].y, ah[i].x, ah[i].y};
@@ -198,16 +214,45 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) bsum[i] = mma_chunk<bf16_t>(ones, fa[i], bsum[i]);
     }
+    auto nread = [&](auto rtag) __attribute__((always_inline)) {
+      constexpr int R = decltype(rtag)::value;
+      if constexpr (R < 4) nal[R] = lds_tr_read<0>(offa[R] + so);
+      else if constexpr (R < 8) nah[R - 4] = lds_tr_read<4 * ROWB>(offa[R - 4] + so);
+      else if constexpr (R < 16) nbl[R - 8] = lds_tr_read<0>(offb[R - 8] + so);
+      else nbh[R - 16] = lds_tr_read<4 * ROWB>(offb[R - 16] + so);
+    };
+    auto group = [&](auto jtag) __attribute__((always_inline)) {
+      constexpr int J = decltype(jtag)::value;
+      nread(std::integral_constant<int, 3 * J>{}); nread(std::integral_constant<int, 3 * J + 1>{}); nread(std::integral_constant<int, 3 * J + 2>{});
+      const u32x4 fb{bl[J].x, bl[J].y, bh[J].x, bh[J].y};
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const u32x4 fb{bl[j].x, bl[j].y, bh[j].x, bh[j].y};
-#pragma unroll
-      for (int i = 0; i < TM; ++i) acc[i][j] = mma_chunk<bf16_t>(fb, fa[i], acc[i][j]);
-    }
-    TSTAMP(8 + kt * 5 + 3);
-    if (kt + 1 < nk) __builtin_amdgcn_s_barrier();
-    TSTAMP(8 + kt * 5 + 4);
-    stage = (stage + 1) & (NST - 1);
+      for (int i = 0; i < TM; ++i) acc[i][J] = mma_chunk<bf16_t>(fb, fa[i], acc[i][J]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{});
+    group(std::integral_constant<int, 3>{}); group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+    group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+    rd = rd + STAGE == NST * STAGE ? 0 : rd + STAGE;
+    if (!last) __builtin_amdgcn_s_barrier();
+  };
+  int kt = 0;
+#pragma nounroll
+  for (; kt + 1 < nk; kt += 2) {
+    phase_l(kt, al0, ah0, bl0, bh0);
+    phase_m(false, al0, ah0, bl0, bh0, al1, ah1, bl1, bh1);
+    phase_l(kt + 1, al1, ah1, bl1, bh1);
+    phase_m(kt + 2 >= nk, al1, ah1, bl1, bh1, al0, ah0, bl0, bh0);
+  }
+  if (kt < nk) {      // odd tile count: the last tile's fragments sit in set 0
+    phase_l(kt, al0, ah0, bl0, bh0);
+    phase_m(true, al0, ah0, bl0, bh0, al1, ah1, bl1, bh1);
+    wait_lgkm<0>(al1[0], ah1[0], al1[1], ah1[1], al1[2], ah1[2], al1[3], ah1[3]);
+    wait_lgkm<0>(bl1[0], bh1[0], bl1[1], bh1[1], bl1[2], bh1[2], bl1[3], bh1[3]);
+    wait_lgkm<0>(bl1[4], bh1[4], bl1[5], bh1[5], bl1[6], bh1[6], bl1[7], bh1[7]);
+  } else {            // the dummy reads of the last phase: dead values, but their registers must not be reused before they land
+    wait_lgkm<0>(al0[0], ah0[0], al0[1], ah0[1], al0[2], ah0[2], al0[3], ah0[3]);
+    wait_lgkm<0>(bl0[0], bh0[0], bl0[1], bh0[1], bl0[2], bh0[2], bl0[3], bh0[3]);
+    wait_lgkm<0>(bl0[4], bh0[4], bl0[5], bh0[5], bl0[6], bh0[6], bl0[7], bh0[7]);
   }
   if (!second) __builtin_amdgcn_s_barrier();   // pairs with the extra barrier of waves 4-7
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

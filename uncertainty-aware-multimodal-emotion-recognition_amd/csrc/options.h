@@ -18,7 +18,7 @@ enum OptId {
   OPT_T128,             // smallest 128x64 tile count that selects the 128x64 kernel
   OPT_TILE,             // -1: automatic; 0..3: force a GemmTile
   OPT_KSTEPS,           // 0: automatic; > 0: K-tiles per split-K slice of a weight-gradient problem
-  OPT_NIG_FUSED,        // 1: head last layer + loss statistics + loss gradient in one launch (nig_fused_kernel)
+  OPT_SPLITK_MAX,       // largest number of split-K slices of a weight-gradient problem (slabs: 4 B per parameter per slice)
   OPT_COUNT
 };
 
