@@ -227,13 +227,35 @@ typedef struct mmdeer_gemm_args {
 } mmdeer_gemm_args;
 int mmdeer_gemm(const mmdeer_gemm_args* a);
 
+/* n weight-gradient problems (every one trans_a = trans_w = 1, fp32 C, no epilogue; the same compute dtype) as grouped
+ * launches of up to 16 problems each + one deterministic fold of their split-K slabs per group -- the form in which
+ * mmdeer_backward runs all its weight gradients in ONE launch, for operator sequences built outside the library (Stack B
+ * training, mmdeer/stackb_train.py).  `splitk` / `slab` of the individual problems are ignored: the slices are carved out of
+ * `slab` (slab_elems floats; mmdeer_gemm_batch_slab_elems gives the need) with the library's own split policy. */
+long long mmdeer_gemm_batch_slab_elems(const mmdeer_gemm_args* a, int n);
+int mmdeer_gemm_batch(const mmdeer_gemm_args* a, int n, float* slab, long long slab_elems, void* stream);
+
+/* n folds in ONE launch: dst[i][j] = sum over p < nparts[i] of src[i][p * stride[i] + j], j < count[i] (count and stride
+ * multiples of 4, 16-byte aligned pointers; fixed order: deterministic).  nparts = 1 is a copy.  Operator sequences collect
+ * the LayerNorm gamma / beta partials of mmdeer_layernorm_bwd(dgamma = NULL) and their gradient slices here instead of
+ * paying one small launch each (up to 48 segments per launch; more are split over several). */
+int mmdeer_reduce_batch(int n, const float* const* src, float* const* dst, const int32_t* nparts, const int32_t* count,
+                        const long long* stride, void* stream);
+
+/* n transposed compute-dtype copies in ONE launch: for matrix i (fp32, rows[i] x cols[i], row-major, dense) W^T[c][r] is
+ * written to dst + dst_off[i] + c * ld_dst[i] + dst_col[i] + r (elements of the compute dtype; ld_dst 0 = rows[i]): dX = dY W
+ * then runs as an NT GEMM on the LDS-DMA kernels.  Up to 32 matrices per launch (more are split). */
+int mmdeer_pack_transposed_batch(int n, const float* const* src, const int32_t* rows, const int32_t* cols, void* dst,
+                                 const long long* dst_off, const int32_t* ld_dst, const int32_t* dst_col, int dst_f32, void* stream);
+
 /* nn.LayerNorm(N), eps 1e-5 (fusion.py:102, 220, 305) */
 int mmdeer_layernorm_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,
                          const float* beta, int M, int N, int act_f32, void* stream);
 int mmdeer_layernorm_bwd_nparts(int M);
 /* dz = (y > 0) * mask_scale * LayerNorm'(dout): the ReLU (+ dropout, mask_scale = 1 / (1 - p)) of the Linear-ReLU-Dropout-LayerNorm
  * blocks folded in; mask_scale <= 0: no mask (a LayerNorm behind a plain Linear, encoders.py:113-114).  partial: scratch of
- * mmdeer_layernorm_bwd_nparts(M) * 2 * N floats. */
+ * mmdeer_layernorm_bwd_nparts(M) * 2 * N floats ([part][d gamma row | d beta row]); with dgamma = dbeta = NULL the fold of
+ * the partials is left to the caller (mmdeer_reduce_batch: nparts = mmdeer_layernorm_bwd_nparts(M), stride = 2 N). */
 int mmdeer_layernorm_bwd(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
                          void* dz, float* dgamma, float* dbeta, float* partial, int M, int N, int act_f32,
                          float mask_scale, void* stream);
@@ -321,6 +343,24 @@ typedef struct {
   void* stream;
 } mmdeer_adamw_args;
 int mmdeer_adamw_step(const mmdeer_adamw_args* a);
+
+/* The same update (clip_grad_norm_ + torch.optim.AdamW, training.py:121-150, 219-224) for ANY model whose parameters,
+ * gradients and moments live in flat fp32 buffers with common offsets (Stack B: mmdeer/stackb.py): up to 56 learning-rate
+ * segments [seg_begin[i], seg_begin[i] + seg_elems[i]) (multiples of 4 elements; elements outside every segment are not
+ * touched), global norm over all flat_elems gradients.  `packed` (optional): compute-dtype copy of the updated
+ * parameters at the same offsets (packed_f32 = 0: bf16), what the operator sequence's GEMMs read. */
+typedef struct mmdeer_adamw_flat_args {
+  float* params; const float* grads; float* exp_avg; float* exp_avg_sq;
+  void* packed; int32_t packed_f32;
+  long long flat_elems;
+  int32_t nseg; const long long* seg_begin; const long long* seg_elems; const float* seg_lr;
+  float* scratch;            /* 256 floats */
+  float* grad_norm;          /* optional device scalar: global norm before clipping */
+  int32_t step;              /* 1-based */
+  float beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale;
+  void* stream;
+} mmdeer_adamw_flat_args;
+int mmdeer_adamw_flat(const mmdeer_adamw_flat_args* a);
 
 /* Refresh every packed copy of the parameters in `weights` (the compute-dtype matrices, their W^T copies, the padded
  * audio weight, the head-major in_proj image) without running a pass -- what mmdeer_forward does when repack = 1.  For a

@@ -370,3 +370,90 @@ def test_stackb_captured_train_step_equals_eager_and_draws_fresh_masks():
     w0 = m3.fusion_module.fusion_gate[0].weight.detach().clone()
     ls = [float(rep()["total_loss"]) for _ in range(15)]
     assert ls[-1] < ls[0] and not torch.equal(w0, m3.fusion_module.fusion_gate[0].weight)
+
+
+@pytest.mark.parametrize("compute,B", [("fp32", 96), ("bf16", 1024)])
+def test_fused_train_step_equals_the_autograd_path(compute, B):
+    """train_step_fused (flat buffers, grouped weight-gradient launches, no autograd) runs the same
+    operator sequence as compute_loss(model(...)).backward(): same loss bit for bit (the forward is the same launches), the
+    same gradients up to the summation order of the split-K weight-gradient slices; FlatAdamW = clip_grad_norm_ +
+    torch.optim.AdamW with the trainer's parameter groups (training.py:121-150, 219-224)."""
+    import copy
+
+    from mmdeer.optim import FlatAdamW
+    m1, _ = _train_model(compute)
+    m2 = copy.deepcopy(m1)
+    b = synth.make_batch(B, seed=33)
+    xs, y = _batch_dev(b)
+    m1.train(); m2.train()
+    m1._train_step = m2._train_step = 17
+    l1 = m1.compute_loss(m1(*xs), y)
+    l1["total_loss"].backward()
+    l2 = m2.train_step_fused(*xs, y)
+    torch.cuda.synchronize()
+    assert float(l1["total_loss"]) == float(l2["total_loss"])
+    assert torch.equal(l1["ece_bin_counts"], l2["ece_bin_counts"])
+    g1 = {n: p.grad for n, p in m1.named_parameters()}
+    seen = 0
+    for n, p in m2.named_parameters():
+        if g1[n] is None:                                   # the calibration layer: off the path
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        scale = max(float(g1[n].abs().max()), 1e-12)
+        tol = 2e-5 if compute == "fp32" else 2e-4           # fp32 sums of the same products in another order
+        assert float((p.grad - g1[n]).abs().max()) <= tol * scale + 1e-9, (n, float((p.grad - g1[n]).abs().max()), scale)
+        seen += 1
+    assert seen >= 100
+    # optimiser: one step against torch's clip + AdamW on the autograd twin (encoder-named parameters at half the rate)
+    enc = [p for n, p in m1.named_parameters() if "encoder" in n and p.grad is not None]
+    rest = [p for n, p in m1.named_parameters() if "encoder" not in n and p.grad is not None]
+    ref = torch.optim.AdamW([{"params": enc, "lr": 5e-4}, {"params": rest, "lr": 1e-3}], weight_decay=1e-2, eps=1e-8)
+    for n, p in m1.named_parameters():                      # same gradients on both sides: isolate the update rule
+        if p.grad is not None:
+            p.grad.copy_(dict(m2.named_parameters())[n].grad)
+    torch.nn.utils.clip_grad_norm_([p for p in m1.parameters() if p.grad is not None], 1.0)
+    ref.step()
+    opt = FlatAdamW(m2, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0)
+    opt.step()
+    torch.cuda.synchronize()
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.allclose(p1, p2, rtol=2e-6, atol=2e-7), (n, float((p1 - p2).abs().max()))
+    # the compute-dtype copy followed the update: the next fused step sees the new parameters without any cast
+    m1._train_step = m2._train_step = 40
+    for p in m1.parameters():
+        p.grad = None
+    l1b = m1.compute_loss(m1(*xs), y)
+    l2b = m2.train_step_fused(*xs, y)
+    assert float(l1b["total_loss"]) == pytest.approx(float(l2b["total_loss"]), rel=1e-5 if compute == "fp32" else 2e-3)
+    assert float(l2b["total_loss"]) != float(l2["total_loss"])
+
+
+def test_fused_train_step_graph_replay_trains_and_matches_eager():
+    import copy
+
+    from mmdeer.optim import FlatAdamW
+    m1, _ = _train_model("bf16")
+    m2 = copy.deepcopy(m1)
+    b = synth.make_batch(256, seed=34)
+    xs, y = _batch_dev(b)
+    rep = m1.capture_train_step_fused(*xs, y)
+    m2.train()
+    for r in range(3):                                      # replays are bit-identical to eager fused steps at the same dropout step
+        lg = rep()
+        torch.cuda.synchronize()
+        m2._train_step = int(rep.counter.item())
+        le = m2.train_step_fused(*xs, y)
+        assert float(lg["total_loss"]) == float(le["total_loss"]), r
+        for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert torch.equal(p1.grad, p2.grad), (r, n)
+    opt = FlatAdamW(m1, lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
+    losses = []
+    for _ in range(15):
+        losses.append(float(rep()["total_loss"]))
+        opt.step()
+    assert losses[-1] < losses[0] - 0.05 and all(np.isfinite(losses))
+    # the trained parameters serve the inference path too (the operand image is rebuilt from the flat buffer)
+    m1.eval()
+    with torch.no_grad():
+        out = m1(*xs)
+    assert torch.isfinite(out["mu_all"]).all()

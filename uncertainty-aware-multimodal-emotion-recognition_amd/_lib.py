@@ -83,6 +83,17 @@ class GemmArgs(C.Structure):
     ]
 
 
+class AdamWFlatArgs(C.Structure):
+    _fields_ = [
+        ("params", c_void_p), ("grads", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+        ("packed", c_void_p), ("packed_f32", c_int), ("flat_elems", c_ll),
+        ("nseg", c_int), ("seg_begin", C.POINTER(c_ll)), ("seg_elems", C.POINTER(c_ll)), ("seg_lr", C.POINTER(c_float)),
+        ("scratch", c_void_p), ("grad_norm", c_void_p), ("step", c_int),
+        ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float), ("max_grad_norm", c_float),
+        ("grad_scale", c_float), ("stream", c_void_p),
+    ]
+
+
 class StackBAttnArgs(C.Structure):
     _fields_ = [
         ("h2", c_void_p), ("pre", c_void_p), ("self_out", c_void_p), ("cross_out", c_void_p),
@@ -161,6 +172,12 @@ SYMBOLS = [
     ("mmdeer_bucket_begin", c_ll, [c_int]),
     ("mmdeer_bucket_end", c_ll, [c_int]),
     ("mmdeer_gemm", c_int, [C.POINTER(GemmArgs)]),
+    ("mmdeer_gemm_batch_slab_elems", c_ll, [C.POINTER(GemmArgs), c_int]),
+    ("mmdeer_gemm_batch", c_int, [C.POINTER(GemmArgs), c_int, c_void_p, c_ll, c_void_p]),
+    ("mmdeer_adamw_flat", c_int, [C.POINTER(AdamWFlatArgs)]),
+    ("mmdeer_reduce_batch", c_int, [c_int, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_ll), c_void_p]),
+    ("mmdeer_pack_transposed_batch", c_int, [c_int, C.POINTER(c_void_p), C.POINTER(c_int), C.POINTER(c_int), c_void_p, C.POINTER(c_ll),
+                                             C.POINTER(c_int), C.POINTER(c_int), c_int, c_void_p]),
     ("mmdeer_layernorm_fwd", c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     ("mmdeer_layernorm_bwd_nparts", c_int, [c_int]),
     ("mmdeer_layernorm_bwd", c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_void_p]),

@@ -833,6 +833,147 @@ int mmdeer_gemm(const mmdeer_gemm_args* a) {
   return 0;
 }
 
+namespace {
+// weight-gradient batch: split policy of Exec::set_split (ksteps_target K-tiles per slice, capped)
+// `boost` multiplies the slice count of every problem of a group whose tiles would leave most of the chip idle (Stack B: a
+// group is 16 matrices of 256 x 256 = 16 tiles; at the default 4 slices that is 64 workgroups, each a chain of 32 K-steps)
+constexpr int BATCH_SPLITK_MAX = 16;
+int batch_splitk(int K, int f32, int boost) {
+  const int nk = gemm_ktiles(K, f32), kst = ksteps_target(f32);
+  int sk = ((nk + kst - 1) / kst) * boost;
+  if (sk > BATCH_SPLITK_MAX) sk = BATCH_SPLITK_MAX;
+  if (sk > nk / 2) sk = nk / 2;          // at least two K-tiles per slice
+  return sk < 1 ? 1 : sk;
+}
+int batch_boost(const mmdeer_gemm_args* a, int n, int f32) {
+  long long wgs = 0;
+  for (int i = 0; i < n; ++i)
+    wgs += (long long)((a[i].M + 255) / 256) * ((a[i].N + 255) / 256) * batch_splitk(a[i].K, f32, 1);
+  int boost = 1;
+  while (boost < 4 && wgs * boost * 2 <= 256) boost *= 2;
+  return boost;
+}
+long long batch_slice_elems(const mmdeer_gemm_args& a) { return ((long long)a.M * a.N + a.M + 63) / 64 * 64; }
+}  // namespace
+
+long long mmdeer_gemm_batch_slab_elems(const mmdeer_gemm_args* a, int n) {
+  if (!a || n <= 0) return 0;
+  long long tot = 0;
+  for (int i0 = 0; i0 < n; i0 += GEMM_MAX_PROBLEMS) {
+    const int cnt = (n - i0) < GEMM_MAX_PROBLEMS ? (n - i0) : GEMM_MAX_PROBLEMS, f32 = a[i0].compute_f32 ? 1 : 0;
+    const int boost = batch_boost(a + i0, cnt, f32);
+    for (int i = i0; i < i0 + cnt; ++i) {
+      const int sk = batch_splitk(a[i].K, f32, boost);
+      if (sk > 1) tot += sk * batch_slice_elems(a[i]);
+    }
+  }
+  return tot;
+}
+
+int mmdeer_gemm_batch(const mmdeer_gemm_args* a, int n, float* slab, long long slab_elems, void* stream) {
+  MMDEER_CHECK(a != nullptr && n >= 0, "gemm_batch: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  long long used = 0;
+  for (int i0 = 0; i0 < n; i0 += GEMM_MAX_PROBLEMS) {
+    GemmGroup g{};
+    ReduceTable rt{};
+    const int f32 = a[i0].compute_f32 ? 1 : 0;
+    const int boost = batch_boost(a + i0, (n - i0) < GEMM_MAX_PROBLEMS ? (n - i0) : GEMM_MAX_PROBLEMS, f32);
+    for (int i = i0; i < n && i < i0 + GEMM_MAX_PROBLEMS; ++i) {
+      const mmdeer_gemm_args& q = a[i];
+      MMDEER_CHECK(q.trans_a && q.trans_w && q.c_f32 && !q.bias && !q.relu && !q.Y && q.drop_site < 0 && q.regen_site < 0 && !q.accumulate,
+                   "gemm_batch[%d]: weight-gradient problems only (both operands transposed, fp32 C, no epilogue)", i);
+      MMDEER_CHECK((q.compute_f32 ? 1 : 0) == f32, "gemm_batch[%d]: all problems must share the compute dtype", i);
+      MMDEER_CHECK(q.A && q.W && q.C, "gemm_batch[%d]: A / W / C must be non-NULL", i);
+      GemmProblem& p = g.p[g.nprob++];
+      gemm_problem_defaults(p);
+      p.A = q.A; p.B = q.W; p.C = q.C; p.bias_grad = q.bias_grad;
+      p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldw; p.ldc = q.ldc;
+      p.a_f32 = q.a_f32; p.b_f32 = q.w_f32; p.c_f32 = 1; p.trans_a = 1; p.trans_b = 1;
+      const int sk = batch_splitk(q.K, f32, boost);
+      if (sk > 1) {
+        const long long per = batch_slice_elems(q);
+        MMDEER_CHECK(slab != nullptr && used + sk * per <= slab_elems, "gemm_batch: slab too small (%lld floats given)", slab_elems);
+        p.splitk = sk; p.slab_stride = per; p.slab_c = slab + used; p.slab_b = slab + used + (long long)q.M * q.N;
+        used += sk * per;
+        MMDEER_CHECK(rt.nseg + 2 <= REDUCE_MAX_SEGMENTS, "gemm_batch: too many fold segments");
+        int k = rt.nseg;
+        rt.src[k] = p.slab_c; rt.dst[k] = reinterpret_cast<float*>(p.C); rt.nparts[k] = sk;
+        rt.n[k] = (int)(((long long)(q.M - 1) * q.ldc + q.N + 3) / 4 * 4); rt.stride[k] = per; ++k;
+        // the fold of C is one contiguous run only when ldc == N; otherwise fold row by row is not available: require it
+        MMDEER_CHECK(q.ldc == q.N, "gemm_batch[%d]: split-K needs a dense C (ldc == N)", i);
+        if (p.bias_grad) { rt.src[k] = p.slab_b; rt.dst[k] = p.bias_grad; rt.nparts[k] = sk; rt.n[k] = (q.M + 3) / 4 * 4; rt.stride[k] = per; ++k; }
+        rt.nseg = k;
+      }
+    }
+    g.drop = make_drop(0.f, 0, 0);
+    TRY(launch_gemm_group(g, f32, pick_tile(g), s));
+    if (rt.nseg > 0) TRY(launch_reduce_partials(rt, s));
+  }
+  return 0;
+}
+
+int mmdeer_reduce_batch(int n, const float* const* src, float* const* dst, const int32_t* nparts, const int32_t* count,
+                        const long long* stride, void* stream) {
+  MMDEER_CHECK(n >= 0 && (n == 0 || (src && dst && nparts && count && stride)), "reduce_batch: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += REDUCE_MAX_SEGMENTS) {
+    ReduceTable t{};
+    for (int i = i0; i < n && i < i0 + REDUCE_MAX_SEGMENTS; ++i) {
+      MMDEER_CHECK(src[i] && dst[i] && nparts[i] >= 1 && count[i] >= 0 && count[i] % 4 == 0 && stride[i] % 4 == 0 &&
+                       ((uintptr_t)src[i] % 16) == 0 && ((uintptr_t)dst[i] % 16) == 0,
+                   "reduce_batch[%d]: 16-byte aligned pointers, count and stride multiples of 4", i);
+      const int k = t.nseg++;
+      t.src[k] = src[i]; t.dst[k] = dst[i]; t.nparts[k] = nparts[i]; t.n[k] = count[i]; t.stride[k] = stride[i];
+    }
+    TRY(launch_reduce_partials(t, (hipStream_t)stream));
+  }
+  return 0;
+}
+
+int mmdeer_pack_transposed_batch(int n, const float* const* src, const int32_t* rows, const int32_t* cols, void* dst,
+                                 const long long* dst_off, const int32_t* ld_dst, const int32_t* dst_col, int dst_f32, void* stream) {
+  MMDEER_CHECK(n >= 0 && (n == 0 || (src && rows && cols && dst && dst_off && ld_dst && dst_col)), "pack_transposed_batch: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += PACKT_MAX) {
+    PackTTable t{};
+    for (int i = i0; i < n && i < i0 + PACKT_MAX; ++i) {
+      MMDEER_CHECK(src[i] && rows[i] > 0 && cols[i] > 0 && dst_off[i] >= 0, "pack_transposed_batch[%d]: bad matrix", i);
+      const int k = t.nmat++;
+      t.src[k] = src[i]; t.rows[k] = rows[i]; t.cols[k] = cols[i]; t.dst_off[k] = dst_off[i]; t.ld_dst[k] = ld_dst[i]; t.dst_col[k] = dst_col[i];
+    }
+    TRY(launch_pack_transposed(t, dst, dst_f32 ? 1 : 0, (hipStream_t)stream));
+  }
+  return 0;
+}
+
+int mmdeer_adamw_flat(const mmdeer_adamw_flat_args* a) {
+  MMDEER_CHECK(a != nullptr, "args is NULL");
+  MMDEER_CHECK(a->params && a->grads && a->exp_avg && a->exp_avg_sq && a->scratch, "adamw_flat: params / grads / moments / scratch must be non-NULL");
+  MMDEER_CHECK(a->nseg >= 1 && a->nseg <= ADAM_MAX_SEGMENTS && a->seg_begin && a->seg_elems && a->seg_lr, "adamw_flat: 1..%d segments", ADAM_MAX_SEGMENTS);
+  MMDEER_CHECK(a->step >= 1, "adamw_flat: step must be >= 1 (got %d)", a->step);
+  MMDEER_CHECK(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps > 0.f, "adamw_flat: bad betas / eps");
+  MMDEER_CHECK(a->flat_elems > 0 && a->flat_elems % 4 == 0, "adamw_flat: flat_elems must be a positive multiple of 4");
+  AdamTable t{};
+  t.nseg = a->nseg;
+  for (int i = 0; i < a->nseg; ++i) {
+    MMDEER_CHECK(a->seg_begin[i] >= 0 && a->seg_elems[i] >= 0 && a->seg_begin[i] + a->seg_elems[i] <= a->flat_elems && a->seg_elems[i] < (1ll << 31),
+                 "adamw_flat: segment %d out of range", i);
+    t.param[i] = a->params + a->seg_begin[i];
+    t.off[i] = a->seg_begin[i];
+    t.n[i] = (int)a->seg_elems[i];
+    t.is_vec[i] = 0;
+    t.lr[i] = a->seg_lr[i];
+  }
+  t.grads = a->grads; t.exp_avg = a->exp_avg; t.exp_avg_sq = a->exp_avg_sq;
+  t.partials = a->scratch; t.norm_out = a->grad_norm; t.flat_elems = a->flat_elems;
+  t.beta1 = a->beta1; t.beta2 = a->beta2; t.eps = a->eps; t.weight_decay = a->weight_decay;
+  t.bias_corr1 = 1.f - powf(a->beta1, (float)a->step);
+  t.bias_corr2 = 1.f - powf(a->beta2, (float)a->step);
+  t.max_norm = a->max_grad_norm; t.grad_scale = a->grad_scale;
+  // without a packed copy the kernel still needs a destination: the fp32 parameters themselves (a second store of p)
+  if (a->packed) return launch_adamw_pack(t, a->packed, a->packed_f32 ? 1 : 0, nullptr, (hipStream_t)a->stream);
+  return launch_adamw_pack(t, a->params, 1, nullptr, (hipStream_t)a->stream);
+}
+
 int mmdeer_layernorm_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,
                          const float* beta, int M, int N, int act_f32, void* stream) {
   return launch_ln_fwd(y, out, out32, mean, rstd, gamma, beta, M, N, act_f32, (hipStream_t)stream);
@@ -843,6 +984,8 @@ int mmdeer_layernorm_bwd(const void* dout, const void* y, const float* mean, con
                          float mask_scale, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   TRY(launch_ln_bwd(dout, y, mean, rstd, gamma, dz, partial, M, N, act_f32, mask_scale, s));
+  if (!dgamma && !dbeta) return 0;      // the caller folds the partials (mmdeer_reduce_batch)
+  MMDEER_CHECK(dgamma && dbeta, "layernorm_bwd: pass both dgamma and dbeta, or neither");
   ReduceTable t{};
   t.nseg = 2;
   t.src[0] = partial; t.dst[0] = dgamma; t.nparts[0] = ln_bwd_nparts(M); t.n[0] = N; t.stride[0] = 2 * N;

@@ -30,51 +30,72 @@ ENC, FUS, HID = 256, 512, 256
 SITE_RES, SITE_ATTN_S, SITE_ATTN_C, SITE_EST, SITE_WN, SITE_AV, SITE_TRI, SITE_H0, SITE_H3 = 32, 64, 65, 66, 67, 68, 69, 70, 71     # H3: 71..73
 
 
-def _params(model, dt):
-    """Compute-dtype copies of the matrices (a cast per step: torch here is memory plumbing, the casts carry no arithmetic
-    of the path) and fp32 vectors, keyed like the module tree."""
-    W = lambda t: t.detach().to(dt).contiguous()
+def _params(model, dt, flat=None):
+    """Compute-dtype matrices and fp32 vectors, keyed like the module tree.  Default: a cast per matrix per step (torch here
+    is memory plumbing, the casts carry no arithmetic of the path).  With ``flat`` (CompleteDEERModel._flat: the fused
+    training step) the matrices are VIEWS of the flat compute-dtype copy the optimiser step maintains -- no cast at all; only
+    the few operands that are concatenations / column slices of parameters still cost a small copy."""
+    if flat is None:
+        Wp = lambda t: t.detach().to(dt).contiguous()
+    else:
+        def Wp(t):
+            off, n = flat["by_id"][id(t)]
+            return flat["packed"][off:off + n].view(t.shape)
     V = lambda t: t.detach().float().contiguous()
+    catW = lambda ts: torch.cat([Wp(t) for t in ts], 0)
+    catV = lambda ts: torch.cat([V(t) for t in ts], 0)
     P = {"enc": []}
     cfg = model.config
     for e in (model.audio_encoder, model.video_encoder, model.text_encoder):
-        d = {"w0": e.input_projection[0].weight, "b0": V(e.input_projection[0].bias), "g0": V(e.input_projection[2].weight),
-             "be0": V(e.input_projection[2].bias), "res": [], "wo": W(e.output_projection.weight), "bo": V(e.output_projection.bias)}
-        d["w0"] = W(d["w0"])
+        d = {"w0": Wp(e.input_projection[0].weight), "b0": V(e.input_projection[0].bias), "g0": V(e.input_projection[2].weight),
+             "be0": V(e.input_projection[2].bias), "res": [], "wo": Wp(e.output_projection.weight), "bo": V(e.output_projection.bias)}
         for blk in e.encoder_layers:
-            d["res"].append({"w": W(blk.layers[0].weight), "b": V(blk.layers[0].bias), "g": V(blk.layers[3].weight), "be": V(blk.layers[3].bias)})
+            d["res"].append({"w": Wp(blk.layers[0].weight), "b": V(blk.layers[0].bias), "g": V(blk.layers[3].weight), "be": V(blk.layers[3].bias)})
         P["enc"].append(d)
     att = model.attention_module
     sa, ca, est, wn = att.self_attention, att.cross_attention, att.uncertainty_estimator.estimator, att.weight_network
-    P["wv"] = W(torch.cat([sa.value_proj.weight, ca.value_proj.weight], 0))                # (512, 256)
-    P["bv"] = V(torch.cat([sa.value_proj.bias, ca.value_proj.bias], 0))
-    P["wos"], P["bos"], P["woc"], P["boc"] = W(sa.output_proj.weight), V(sa.output_proj.bias), W(ca.output_proj.weight), V(ca.output_proj.bias)
-    P["we1"], P["be1"], P["we2"], P["be2"] = W(est[0].weight), V(est[0].bias), W(est[3].weight), V(est[3].bias)
+    P["wv"] = catW([sa.value_proj.weight, ca.value_proj.weight])                           # (512, 256)
+    P["bv"] = catV([sa.value_proj.bias, ca.value_proj.bias])
+    P["wos"], P["bos"], P["woc"], P["boc"] = Wp(sa.output_proj.weight), V(sa.output_proj.bias), Wp(ca.output_proj.weight), V(ca.output_proj.bias)
+    P["we1"], P["be1"], P["we2"], P["be2"] = Wp(est[0].weight), V(est[0].bias), Wp(est[3].weight), V(est[3].bias)
     P["we3"], P["be3"] = V(est[5].weight).reshape(-1), V(est[5].bias)
     D3 = 3 * cfg.encoder_dim
-    P["wn1"], P["bn1"] = W(wn[0].weight[:, :D3]), V(wn[0].bias)
-    P["wn1u"] = V(wn[0].weight[:, D3:])                                                     # (256, 3) fp32
+    P["wn1"], P["bn1"] = Wp(wn[0].weight)[:, :D3].contiguous(), V(wn[0].bias)
+    P["wn1u"] = wn[0].weight.detach()[:, D3:].float().contiguous()                          # (256, 3) fp32
     P["wn2"], P["bn2"] = V(wn[3].weight), V(wn[3].bias)
     fu = model.fusion_module
     for name, seq in (("av", fu.av_fusion), ("tri", fu.trimodal_fusion)):
-        P[name] = {"w0": W(seq[0].weight), "b0": V(seq[0].bias), "g": V(seq[3].weight), "be": V(seq[3].bias), "w4": W(seq[4].weight), "b4": V(seq[4].bias)}
-    P["wg"], P["bg"] = W(fu.fusion_gate[0].weight), V(fu.fusion_gate[0].bias)
+        P[name] = {"w0": Wp(seq[0].weight), "b0": V(seq[0].bias), "g": V(seq[3].weight), "be": V(seq[3].bias), "w4": Wp(seq[4].weight), "b4": V(seq[4].bias)}
+    P["wg"], P["bg"] = Wp(fu.fusion_gate[0].weight), V(fu.fusion_gate[0].bias)
     nets = [model.prediction_heads[n].evidence_network for n in ("valence", "arousal", "dominance")]
-    P["wh0"], P["bh0"] = W(torch.cat([n[0].weight for n in nets], 0)), V(torch.cat([n[0].bias for n in nets], 0))      # (768, 512)
-    P["wh3"], P["bh3"] = [W(n[3].weight) for n in nets], [V(n[3].bias) for n in nets]
-    P["wh6"], P["bh6"] = [W(n[6].weight) for n in nets], [V(n[6].bias) for n in nets]
+    P["wh0"], P["bh0"] = catW([n[0].weight for n in nets]), catV([n[0].bias for n in nets])                            # (768, 512)
+    P["wh3"], P["bh3"] = [Wp(n[3].weight) for n in nets], [V(n[3].bias) for n in nets]
+    P["wh6"], P["bh6"] = [Wp(n[6].weight) for n in nets], [V(n[6].bias) for n in nets]
     P["wh6p"] = [torch.nn.functional.pad(w, (0, 0, 0, 4)) for w in P["wh6"]]              # (8, 128): rows 4..7 zero (8-column gradient blocks)
+    if flat is not None and flat.get("packed_t") is not None:
+        # transposed copies (maintained with the compute-dtype copy): dX = dY W runs as an NT GEMM on the LDS-DMA kernel
+        def Wt(t):
+            off, n = flat["by_id"][id(t)]
+            return flat["packed_t"][off:off + n].view(t.shape[1], t.shape[0])
+        X = lambda key, r, c: flat["packed_t"][flat["extra_t"][key]:flat["extra_t"][key] + r * c].view(r, c)
+        encs = (model.audio_encoder, model.video_encoder, model.text_encoder)
+        P["t"] = {"enc": [{"wo": Wt(e.output_projection.weight), "res": [Wt(blk.layers[0].weight) for blk in e.encoder_layers]} for e in encs],
+                  "wv": X("wv", cfg.encoder_dim, 2 * cfg.encoder_dim), "wos": Wt(sa.output_proj.weight), "woc": Wt(ca.output_proj.weight),
+                  "we1": Wt(est[0].weight), "we2": Wt(est[3].weight), "wn1": X("wn1", D3 + 3, cfg.encoder_dim)[:D3],
+                  "av": {"w0": Wt(fu.av_fusion[0].weight), "w4": Wt(fu.av_fusion[4].weight)},
+                  "tri": {"w0": Wt(fu.trimodal_fusion[0].weight), "w4": Wt(fu.trimodal_fusion[4].weight)},
+                  "wg": Wt(fu.fusion_gate[0].weight), "wh0": X("wh0", cfg.fusion_dim, 3 * HID), "wh3": [Wt(n[3].weight) for n in nets]}
     return P
 
 
-def forward_train(model, xs: List[torch.Tensor], drop) -> Dict:
+def forward_train(model, xs: List[torch.Tensor], drop, flat=None) -> Dict:
     """Forward with every intermediate the backward needs kept on a tape.  Returns the tape (incl. planes (8, B, 3))."""
     ex = Exec(model.compute_dtype, drop)
     dt, f32, dev = ex.dt, ex.f32, xs[0].device
     cfg = model.config
     pc = cfg.dropout
     B = xs[0].shape[0]
-    P = _params(model, dt)
+    P = _params(model, dt, flat)
     new = lambda *s, d=None: torch.empty(*s, dtype=d or dt, device=dev)
     T: Dict = {"P": P, "B": B, "xs": xs, "ex": ex}
     E = new(B, 3 * ENC)
@@ -167,9 +188,14 @@ def forward_train(model, xs: List[torch.Tensor], drop) -> Dict:
     return T
 
 
-def backward(model, T: Dict, g4: torch.Tensor) -> Dict[str, torch.Tensor]:
+def backward(model, T: Dict, g4: torch.Tensor, flat=None) -> Dict[str, torch.Tensor]:
     """Gradients of every parameter on the path from d (mu, nu, alpha, beta) = g4 (4, B, 3) fp32.  Returns
-    {state_dict key: fp32 gradient}; the calibration layer (not on the path of mu / nu / alpha / beta) gets none."""
+    {state_dict key: fp32 gradient}; the calibration layer (not on the path of mu / nu / alpha / beta) gets none.
+
+    With ``flat`` (the fused training step) every gradient is written straight into its slice of the model's flat gradient
+    buffer (``.grad`` of each parameter is a view of it), the weight-gradient GEMMs are recorded and run as grouped launches
+    with one slab fold per group at the end (``Exec.flush_dw`` -> ``mmdeer_gemm_batch``), and nothing is returned through
+    autograd; the query / key projections keep the zeros the buffer was created with."""
     ex: Exec = T["ex"]
     P, B, dt, f32 = T["P"], T["B"], ex.dt, ex.f32
     cfg = model.config
@@ -177,7 +203,7 @@ def backward(model, T: Dict, g4: torch.Tensor) -> Dict[str, torch.Tensor]:
     dev = g4.device
     new = lambda *s, d=None: torch.empty(*s, dtype=d or dt, device=dev)
     # every fp32 gradient / scratch matrix of the pass is a slice of ONE zeroed buffer (one memset instead of ~100)
-    pool = torch.zeros(sum(p.numel() for p in model.parameters()) + (1 << 20), dtype=torch.float32, device=dev)
+    pool = torch.zeros((0 if flat is not None else sum(p.numel() for p in model.parameters())) + (1 << 20), dtype=torch.float32, device=dev)
     cursor = [0]
 
     def z32(*shape):
@@ -192,10 +218,29 @@ def backward(model, T: Dict, g4: torch.Tensor) -> Dict[str, torch.Tensor]:
 
     G: Dict[str, torch.Tensor] = {}
     sc = ex.scale_of(pc)
+    late = []                      # flat mode: (destination view, source) copies that must wait for the grouped dW launches
+    PT = P.get("t")                # transposed weight copies (flat mode) or None
+    if flat is not None:
+        ex.deferred, ex.folds = [], []
+        fview = lambda name: flat["gview"][name]
 
     def grads(prefix, N, K):
+        if flat is not None:
+            return fview(prefix + ".weight"), fview(prefix + ".bias")
         G[prefix + ".weight"], G[prefix + ".bias"] = z32(N, K), z32(N)
         return G[prefix + ".weight"], G[prefix + ".bias"]
+
+    def vec(name, n):              # a vector gradient the row kernels write directly (LayerNorm gamma / beta)
+        if flat is not None:
+            return fview(name)
+        G[name] = z32(n)
+        return G[name]
+
+    def put(name, src):            # a gradient that is a slice of a wider scratch matrix
+        if flat is not None:
+            late.append((fview(name), src))
+        else:
+            G[name] = src
 
     # ---- heads
     dev_ = new(B, 24)                                                   # head d in columns 8 d .. 8 d + 3, zeros in 8 d + 4 .. 8 d + 7
@@ -209,17 +254,17 @@ def backward(model, T: Dict, g4: torch.Tensor) -> Dict[str, torch.Tensor]:
         ex.dx(ev_d, 24, P["wh6p"][d], dh3, 3 * HID // 2, B, mask=h3, ldm=3 * HID // 2, mask_scale=sc)
         w8, b8 = z32(8, 128), z32(8)
         ex.dw(ev_d, 24, h3, 3 * HID // 2, w8, b8, B, 8, 128)
-        G[pre + ".6.weight"], G[pre + ".6.bias"] = w8[:4], b8[:4]
+        put(pre + ".6.weight", w8[:4]); put(pre + ".6.bias", b8[:4])
         h0, dh0 = H0[:, d * HID:(d + 1) * HID], dH0[:, d * HID:(d + 1) * HID]
-        ex.dx(dh3, 3 * HID // 2, P["wh3"][d], dh0, 3 * HID, B, mask=h0, ldm=3 * HID, mask_scale=sc)
+        ex.dx(dh3, 3 * HID // 2, P["wh3"][d], dh0, 3 * HID, B, mask=h0, ldm=3 * HID, mask_scale=sc, wt=PT and PT["wh3"][d])
         ex.dw(dh3, 3 * HID // 2, h0, 3 * HID, *grads(pre + ".3", 128, HID), B, 128, HID)
     dfused = new(B, FUS)
-    ex.dx(dH0, 3 * HID, P["wh0"], dfused, FUS, B)
+    ex.dx(dH0, 3 * HID, P["wh0"], dfused, FUS, B, wt=PT and PT["wh0"])
     gw0, gb0 = z32(3 * HID, FUS), z32(3 * HID)
     ex.dw(dH0, 3 * HID, T["fused"], FUS, gw0, gb0, B, 3 * HID, FUS)
     for d, nm in enumerate(names):
-        G[f"prediction_heads.{nm}.evidence_network.0.weight"] = gw0[d * HID:(d + 1) * HID]
-        G[f"prediction_heads.{nm}.evidence_network.0.bias"] = gb0[d * HID:(d + 1) * HID]
+        put(f"prediction_heads.{nm}.evidence_network.0.weight", gw0[d * HID:(d + 1) * HID])
+        put(f"prediction_heads.{nm}.evidence_network.0.bias", gb0[d * HID:(d + 1) * HID])
     # ---- fusion: gate mix, trimodal stage, gate, audio-visual stage
     Tt, R2, Gt = T["T"], T["R2"], T["G"]
     dG, dZ4, dav_a = new(B, FUS), new(B, FUS), new(B, FUS)
@@ -230,23 +275,22 @@ def backward(model, T: Dict, g4: torch.Tensor) -> Dict[str, torch.Tensor]:
         a1, n1, mean, rstd = st
         pp = P[name]
         pre = f"fusion_module.{'av_fusion' if name == 'av' else 'trimodal_fusion'}"
-        dn1 = ex.dx(dz4, FUS, pp["w4"], new(B, FUS), FUS, B)
+        dn1 = ex.dx(dz4, FUS, pp["w4"], new(B, FUS), FUS, B, wt=PT and PT[name]["w4"])
         ex.dw(dz4, FUS, n1, FUS, *grads(pre + ".4", FUS, FUS), B, FUS, FUS)
-        G[pre + ".3.weight"], G[pre + ".3.bias"] = z32(FUS), z32(FUS)
-        dz0 = ex.ln_bwd(dn1, a1, mean, rstd, pp["g"], G[pre + ".3.weight"], G[pre + ".3.bias"], sc)
+        dz0 = ex.ln_bwd(dn1, a1, mean, rstd, pp["g"], vec(pre + ".3.weight", FUS), vec(pre + ".3.bias", FUS), sc)
         ex.dw(dz0, FUS, inp, ldi, *grads(pre + ".0", FUS, K), B, FUS, K)
         return dz0
 
     dz0_tri = stage_bwd("tri", dZ4, T["tri"], Tt, FUS + ENC, FUS + ENC)
-    dT = ex.dx(dz0_tri, FUS, P["tri"]["w0"], new(B, FUS + ENC), FUS + ENC, B)
-    dT2 = ex.dx(dG, FUS, P["wg"], new(B, FUS + ENC), FUS + ENC, B)
+    dT = ex.dx(dz0_tri, FUS, P["tri"]["w0"], new(B, FUS + ENC), FUS + ENC, B, wt=PT and PT["tri"]["w0"])
+    dT2 = ex.dx(dG, FUS, P["wg"], new(B, FUS + ENC), FUS + ENC, B, wt=PT and PT["wg"])
     ex.dw(dG, FUS, Tt, FUS + ENC, *grads("fusion_module.fusion_gate.0", FUS, FUS + ENC), B, FUS, FUS + ENC)
     dtext = ex.add(new(B, ENC), dT[:, FUS:], dT2[:, FUS:])
     # d av_fused: through the trimodal input, the gate input and the gate mix; av_fused = relu(.)
     tmp = ex.add(new(B, FUS), dT[:, :FUS], dT2[:, :FUS])
     dz4_av = ex.add(new(B, FUS), tmp, dav_a, mask=Tt[:, :FUS], scale=1.0)
     dz0_av = stage_bwd("av", dz4_av, T["av"], T["AV"], 2 * ENC, 2 * ENC)
-    dAV = ex.dx(dz0_av, FUS, P["av"]["w0"], new(B, 2 * ENC), 2 * ENC, B)
+    dAV = ex.dx(dz0_av, FUS, P["av"]["w0"], new(B, 2 * ENC), 2 * ENC, B, wt=PT and PT["av"]["w0"])
     # ---- attention tail
     a = T["attn_args"]
     dS, dX, dpre = new(3 * B, ENC), new(3 * B, ENC), new(B, ENC)
@@ -260,11 +304,15 @@ def backward(model, T: Dict, g4: torch.Tensor) -> Dict[str, torch.Tensor]:
     att = "attention_module"
     t4w, t4b = z32(8, ENC), z32(8)
     ex.dw(dlog8, 8, T["r"], ENC, t4w, t4b, B, 8, ENC)                                      # weight_network.3 (3 x 256)
-    G[att + ".weight_network.3.weight"], G[att + ".weight_network.3.bias"] = t4w[:3], t4b[:3]
-    gwn = z32(ENC, 3 * ENC + 3)
-    G[att + ".weight_network.0.weight"], G[att + ".weight_network.0.bias"] = gwn, z32(ENC)
+    put(att + ".weight_network.3.weight", t4w[:3]); put(att + ".weight_network.3.bias", t4b[:3])
+    if flat is not None:
+        gwn, gbn = fview(att + ".weight_network.0.weight"), fview(att + ".weight_network.0.bias")
+    else:
+        gwn = z32(ENC, 3 * ENC + 3)
+        G[att + ".weight_network.0.weight"], G[att + ".weight_network.0.bias"] = gwn, z32(ENC)
+        gbn = G[att + ".weight_network.0.bias"]
     feat = z32(ENC, 3 * ENC)
-    ex.dw(dpre, ENC, T["S"].view(B, 3 * ENC), 3 * ENC, feat, G[att + ".weight_network.0.bias"], B, ENC, 3 * ENC)
+    ex.dw(dpre, ENC, T["S"].view(B, 3 * ENC), 3 * ENC, feat, gbn, B, ENC, 3 * ENC)
     unc = z32(ENC, 4)
     if B >= 2:
         ex.dw(dpre, ENC, T["u4"], 4, unc, None, B, ENC, 4)
@@ -272,50 +320,60 @@ def backward(model, T: Dict, g4: torch.Tensor) -> Dict[str, torch.Tensor]:
         d2, u2 = torch.zeros(2, ENC, dtype=dt, device=dev), z32(2, 4)
         d2[:1].copy_(dpre); u2[:1].copy_(T["u4"])
         ex.dw(d2, ENC, u2, 4, unc, None, 2, ENC, 4)
-    gwn[:, :3 * ENC].copy_(feat); gwn[:, 3 * ENC:].copy_(unc[:, :3])                       # (memory plumbing: two column blocks of one parameter)
-    dS_b = ex.dx(dpre, ENC, P["wn1"], new(B, 3 * ENC), 3 * ENC, B)
+    if flat is not None:
+        late.append((gwn[:, :3 * ENC], feat)); late.append((gwn[:, 3 * ENC:], unc[:, :3]))
+    else:
+        gwn[:, :3 * ENC].copy_(feat); gwn[:, 3 * ENC:].copy_(unc[:, :3])                   # (memory plumbing: two column blocks of one parameter)
+    dS_b = ex.dx(dpre, ENC, P["wn1"], new(B, 3 * ENC), 3 * ENC, B, wt=PT and PT["wn1"])
     dS = ex.add(new(3 * B, ENC), dS, dS_b.view(3 * B, ENC))
     # uncertainty estimator
     est = att + ".uncertainty_estimator.estimator"
     t4w2, t4b2 = z32(8, ENC // 4), z32(8)
     ex.dw(dz8e, 8, T["H2"], ENC // 4, t4w2, t4b2, 3 * B, 8, ENC // 4)
-    G[est + ".5.weight"], G[est + ".5.bias"] = t4w2[:1], t4b2[:1]
-    dH1 = ex.dx(dh2, ENC // 4, P["we2"], new(3 * B, ENC // 2), ENC // 2, 3 * B, mask=T["H1"], ldm=ENC // 2, mask_scale=ex.scale_of(0.2))
+    put(est + ".5.weight", t4w2[:1]); put(est + ".5.bias", t4b2[:1])
+    dH1 = ex.dx(dh2, ENC // 4, P["we2"], new(3 * B, ENC // 2), ENC // 2, 3 * B, mask=T["H1"], ldm=ENC // 2, mask_scale=ex.scale_of(0.2), wt=PT and PT["we2"])
     ex.dw(dh2, ENC // 4, T["H1"], ENC // 2, *grads(est + ".3", ENC // 4, ENC // 2), 3 * B, ENC // 4, ENC // 2)
     E3 = T["E"].view(3 * B, ENC)
-    dE_est = ex.dx(dH1, ENC // 2, P["we1"], new(3 * B, ENC), ENC, 3 * B)
+    dE_est = ex.dx(dH1, ENC // 2, P["we1"], new(3 * B, ENC), ENC, 3 * B, wt=PT and PT["we1"])
     ex.dw(dH1, ENC // 2, E3, ENC, *grads(est + ".0", ENC // 2, ENC), 3 * B, ENC // 2, ENC)
     # the two attention blocks: output_proj, then the value projections (attention-dropout factor regenerated)
     VV = T["VV"]
     dVV = new(3 * B, 2 * ENC)
-    ex.dx(dS, ENC, P["wos"], dVV[:, :ENC], 2 * ENC, 3 * B, regen_site=SITE_ATTN_S, shift=5, p=pc)
-    ex.dx(dX, ENC, P["woc"], dVV[:, ENC:], 2 * ENC, 3 * B, regen_site=SITE_ATTN_C, shift=5, p=pc)
+    ex.dx(dS, ENC, P["wos"], dVV[:, :ENC], 2 * ENC, 3 * B, regen_site=SITE_ATTN_S, shift=5, p=pc, wt=PT and PT["wos"])
+    ex.dx(dX, ENC, P["woc"], dVV[:, ENC:], 2 * ENC, 3 * B, regen_site=SITE_ATTN_C, shift=5, p=pc, wt=PT and PT["woc"])
     ex.dw(dS, ENC, VV[:, :ENC], 2 * ENC, *grads(att + ".self_attention.output_proj", ENC, ENC), 3 * B, ENC, ENC)
     ex.dw(dX, ENC, VV[:, ENC:], 2 * ENC, *grads(att + ".cross_attention.output_proj", ENC, ENC), 3 * B, ENC, ENC)
     gwv, gbv = z32(2 * ENC, ENC), z32(2 * ENC)
     ex.dw(dVV, 2 * ENC, E3, ENC, gwv, gbv, 3 * B, 2 * ENC, ENC)
     for i, blk in enumerate(("self_attention", "cross_attention")):
-        G[f"{att}.{blk}.value_proj.weight"], G[f"{att}.{blk}.value_proj.bias"] = gwv[i * ENC:(i + 1) * ENC], gbv[i * ENC:(i + 1) * ENC]
-        # one key per query: the softmax is the constant 1, so query / key projections get exact zeros (as autograd gives)
-        for q in ("query_proj", "key_proj"):
-            G[f"{att}.{blk}.{q}.weight"], G[f"{att}.{blk}.{q}.bias"] = z32(ENC, ENC), z32(ENC)
-    dE_v = ex.dx(dVV, 2 * ENC, P["wv"], new(3 * B, ENC), ENC, 3 * B)
+        put(f"{att}.{blk}.value_proj.weight", gwv[i * ENC:(i + 1) * ENC]); put(f"{att}.{blk}.value_proj.bias", gbv[i * ENC:(i + 1) * ENC])
+        # one key per query: the softmax is the constant 1, so query / key projections get exact zeros (as autograd gives;
+        # in flat mode their slices of the gradient buffer are never written and keep the zeros it was created with)
+        if flat is None:
+            for q in ("query_proj", "key_proj"):
+                G[f"{att}.{blk}.{q}.weight"], G[f"{att}.{blk}.{q}.bias"] = z32(ENC, ENC), z32(ENC)
+    dE_v = ex.dx(dVV, 2 * ENC, P["wv"], new(3 * B, ENC), ENC, 3 * B, wt=PT and PT["wv"])
     dE = ex.add(new(3 * B, ENC), dE_v, dE_est).view(B, 3 * ENC)
     # ---- encoders
     for m, (t, pe, ename) in enumerate(zip(T["enc"], P["enc"], ("audio_encoder", "video_encoder", "text_encoder"))):
         dEm = dE[:, m * ENC:(m + 1) * ENC]
         hs = t["h"]
-        dh = ex.dx(dEm, 3 * ENC, pe["wo"], new(B, ENC), ENC, B)
+        dh = ex.dx(dEm, 3 * ENC, pe["wo"], new(B, ENC), ENC, B, wt=PT and PT["enc"][m]["wo"])
         ex.dw(dEm, 3 * ENC, hs[-1], ENC, *grads(ename + ".output_projection", ENC, ENC), B, ENC, ENC)
         for l in reversed(range(len(pe["res"]))):
             pr, pre = pe["res"][l], f"{ename}.encoder_layers.{l}.layers"
-            G[pre + ".3.weight"], G[pre + ".3.bias"] = z32(ENC), z32(ENC)
-            dz = ex.ln_bwd(dh, t["y"][l], *t["st"][l], pr["g"], G[pre + ".3.weight"], G[pre + ".3.bias"], sc)
+            dz = ex.ln_bwd(dh, t["y"][l], *t["st"][l], pr["g"], vec(pre + ".3.weight", ENC), vec(pre + ".3.bias", ENC), sc)
             ex.dw(dz, ENC, hs[l], ENC, *grads(pre + ".0", ENC, ENC), B, ENC, ENC)
-            dh = ex.add(new(B, ENC), dh, ex.dx(dz, ENC, pr["w"], new(B, ENC), ENC, B))
+            dh = ex.add(new(B, ENC), dh, ex.dx(dz, ENC, pr["w"], new(B, ENC), ENC, B, wt=PT and PT["enc"][m]["res"][l]))
         pre = ename + ".input_projection"
-        G[pre + ".2.weight"], G[pre + ".2.bias"] = z32(ENC), z32(ENC)
-        dz0 = ex.ln_bwd(dh, t["y0"], t["m0"], t["r0"], pe["g0"], G[pre + ".2.weight"], G[pre + ".2.bias"], 1.0)
+        dz0 = ex.ln_bwd(dh, t["y0"], t["m0"], t["r0"], pe["g0"], vec(pre + ".2.weight", ENC), vec(pre + ".2.bias", ENC), 1.0)
         K = t["xin"].shape[1]
         ex.dw(dz0, ENC, t["xin"], t["xin"].stride(0), *grads(pre + ".0", ENC, K), B, ENC, K)
+    if flat is not None:
+        ex.flush_dw()
+        ex.deferred = None
+        for dst, src in late:      # after the weight-gradient launches; dense runs ride in the one fold launch below
+            ex.copy1d(dst, src)
+        ex.flush_folds()
+        ex.folds = None
     return G
