@@ -74,6 +74,7 @@ size_t mmdeer_weights_bytes(int compute_f32);
  * rounding (A/B measurements, debugging); read at every call, so a process may change them between calls.
  *   fused_attn (1)     0: unfused in_proj GEMM + attention kernels also in bf16 mode
  *   qkv_recompute (1)  0: the fused forward stores q|k|v for the backward instead of recomputing the head tiles
+ *   ln_fused (1)       0: the LayerNorms of the forward as stand-alone launches instead of inside the consuming GEMM (bf16)
  *   xcd, nt128, nt192, glds, nt8 (1), t128 (512), tile (-1), ksteps (0), splitk_max (8)   GEMM tile / split-K selection
  * mmdeer_set_option / mmdeer_get_option return -1 for an unknown name; mmdeer_option_name(i) enumerates (NULL past the end). */
 int mmdeer_set_option(const char* name, int value);

@@ -153,7 +153,7 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
 struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
 OptEntry g_opts[OPT_COUNT] = {
     {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
-    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"splitk_max", 8, {8}},
+    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"splitk_max", 8, {8}},
 };
 }  // namespace
 
@@ -512,9 +512,25 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   }
   // F4-F5: fusion_layers = Linear -> ReLU -> Dropout -> LayerNorm (fusion.py:263)
   TRY(X.run1(X.fwd(L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, L.y_a2, INTER, B, 1, SITE_AV_FUSE)));
-  TRY(launch_ln_fwd(L.y_a2, L.av, a->audiovisual_features, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), X.V(P_AVF_BT), B, INTER, f32, s));
-  // F6: audiovisual_projection -> token 0 (fusion.py:321, 325)
-  TRY(X.run1(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1)));
+  // bf16 mode: each LayerNorm runs inside the GEMM that consumes it (gemm_ln.hip: the workgroup of a 64-row tile owns whole
+  // rows of its A operand, K = the LayerNorm width) -- three launches fewer in the forward; option "ln_fused" = 0 restores
+  // the stand-alone LayerNorm kernel
+  const bool lnf = !f32 && opt(OPT_LN_FUSED);
+  auto ln_gemm = [&](const GemmProblem& q, const void* Y, int pidG, int pidBt, void* xln, float* out32, float* mean, float* rstd) -> int {
+    GemmGroup g{};
+    g.nprob = 1;
+    g.p[0] = q;
+    g.drop = X.dc;
+    return launch_gemm_ln(g, Y, X.V(pidG), X.V(pidBt), xln, out32, mean, rstd, s);
+  };
+  // F5-F6: LayerNorm + audiovisual_projection -> token 0 (fusion.py:263, 321, 325)
+  if (lnf) {
+    TRY(ln_gemm(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1), L.y_a2, P_AVF_G, P_AVF_BT, L.av, a->audiovisual_features,
+                L.mean_a2, L.rstd_a2));
+  } else {
+    TRY(launch_ln_fwd(L.y_a2, L.av, a->audiovisual_features, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), X.V(P_AVF_BT), B, INTER, f32, s));
+    TRY(X.run1(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1)));
+  }
   // F7: packed q|k|v in_proj of the 2-token self-attention (fusion.py:328)
   //     + F8: 2x2 softmax attention, token-pooled context.  bf16: ONE kernel, q|k|v stay in its accumulators
   if (a->prof_events[0]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[0], s));
@@ -532,13 +548,20 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   TRY(X.run1(X.fwd(L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, L.pool, FUS, B, 0, -1)));
   // F10-F11: final_fusion (fusion.py:338)
   TRY(X.run1(X.fwd(L.pool, f32, FUS, P_TFF_W, P_TFF_B, L.y_t3, FUS, B, 1, SITE_TRI_FUSE)));
-  TRY(launch_ln_fwd(L.y_t3, L.tri, a->trimodal_features, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), X.V(P_TFF_BT), B, FUS, f32, s));
-  // F12-F13: output_projection (fusion.py:162)
-  TRY(X.run1(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ)));
-  TRY(launch_ln_fwd(L.y_o1, L.fused, a->fused_features, L.mean_o1, L.rstd_o1, X.V(P_OP_G), X.V(P_OP_BT), B, FUS, f32, s));
+  // F11-F12: LayerNorm of final_fusion + output_projection (fusion.py:338, 162); F13-F14: its LayerNorm + feature_processor.0
+  if (lnf) {
+    TRY(ln_gemm(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ), L.y_t3, P_TFF_G, P_TFF_BT, L.tri, a->trimodal_features,
+                L.mean_t3, L.rstd_t3));
+    TRY(ln_gemm(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0), L.y_o1, P_OP_G, P_OP_BT, L.fused, a->fused_features,
+                L.mean_o1, L.rstd_o1));
+  } else {
+    TRY(launch_ln_fwd(L.y_t3, L.tri, a->trimodal_features, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), X.V(P_TFF_BT), B, FUS, f32, s));
+    TRY(X.run1(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ)));
+    TRY(launch_ln_fwd(L.y_o1, L.fused, a->fused_features, L.mean_o1, L.rstd_o1, X.V(P_OP_G), X.V(P_OP_BT), B, FUS, f32, s));
+  }
   {
     // F14-F15: feature_processor (deer.py:246)
-    TRY(X.run1(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0)));
+    if (!lnf) TRY(X.run1(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0)));
     TRY(X.run1(X.fwd(L.h1, f32, HID, P_FP1_W, P_FP1_B, L.h2, HID, B, 1, SITE_FP1)));
     // F16: the three DEERLayer first layers stacked into one N = 384 GEMM (deer.py:49)
     {

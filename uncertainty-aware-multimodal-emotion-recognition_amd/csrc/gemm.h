@@ -63,6 +63,11 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile, hipStream_t 
 
 void gemm_problem_defaults(GemmProblem& p);
 
+// gemm_ln.hip: C = epilogue(LayerNorm(Y) W^T + bias) in one launch (bf16, K = LayerNorm width in {256, 512}); `g` holds the
+// one GEMM problem (A ignored); the normalised rows, mean and rstd (and an optional fp32 copy) are written for the backward.
+int launch_gemm_ln(GemmGroup& g, const void* Y, const float* gamma, const float* beta, void* xln, float* out32, float* mean,
+                   float* rstd, hipStream_t s);
+
 // tile policy of the executors (api.hip): the MMDEER_TILE override, else by tile count and operand layout
 GemmTile pick_tile(const GemmGroup& g);
 

@@ -18,6 +18,7 @@ enum OptId {
   OPT_T128,             // smallest 128x64 tile count that selects the 128x64 kernel
   OPT_TILE,             // -1: automatic; 0..3: force a GemmTile
   OPT_KSTEPS,           // 0: automatic; > 0: K-tiles per split-K slice of a weight-gradient problem
+  OPT_LN_FUSED,         // 1: every LayerNorm of the forward runs inside the GEMM that consumes it (gemm_ln.hip, bf16 mode)
   OPT_SPLITK_MAX,       // largest number of split-K slices of a weight-gradient problem (slabs: 4 B per parameter per slice)
   OPT_COUNT
 };
