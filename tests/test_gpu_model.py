@@ -321,6 +321,27 @@ def test_attention_launch_plans_match_each_other():
         assert float(g.abs().sum()) == pytest.approx(float(g0.abs().sum()), rel=2e-2), mode
 
 
+@pytest.mark.parametrize("B", [300, 4096, 8200 + 13])
+def test_layer_chain_launch_is_bit_identical_to_the_separate_launches(B):
+    """chain.hip walks F9..F17 (five Linear+ReLU+Dropout layers, two LayerNorms, the stacked evidence heads) in ONE launch with
+    the rows resident in LDS.  Same accumulation order, same rounding points, same dropout decisions as the stand-alone
+    GEMM / fused-LayerNorm launches: the training step must come out bit for bit (B = 300: ragged 16-sample blocks;
+    8213: the 32-sample form of the kernel, ragged too)."""
+    b = synth.make_batch(B, seed=21)
+    a, v, t, y = (torch.from_numpy(b[k]).to(DEV) for k in ("audio", "video", "text", "targets"))
+    res = {}
+    for chain in (1, 0):
+        m = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=6)).to(DEV).train()
+        with _lib.options(chain=chain):
+            d = m.train_step(a, v, t, y)
+            torch.cuda.synchronize()
+        res[chain] = (float(d["total_loss"]), m.flat_grad().clone(), {k: d[k].clone() for k in ("gamma", "nu", "alpha", "beta") if k in d})
+    assert res[1][0] == res[0][0]
+    assert torch.equal(res[1][1], res[0][1])
+    for k in res[1][2]:
+        assert torch.equal(res[1][2][k], res[0][2][k]), k
+
+
 def test_two_phase_backward_equals_single_call():
     """mmdeer_backward with phase = 1 then 2 (the data-parallel overlap plan) fills the flat gradient buffer with
     exactly what the single call produces; after phase 1 buckets 0-1 are final and bucket 2 is still untouched."""

@@ -16,7 +16,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(PKG_DIR, "libmmdeer_hip.so")
-SOURCES = ["gemm_nt.hip", "gemm_nx.hip", "gemm_tt.hip", "gemm_glds.hip", "gemm_ln.hip", "gemm_tt256.hip", "gemm_nt256.hip", "gemm.hip", "rowops.hip", "attention.hip", "tri_fused.hip", "nig.hip", "optim.hip", "side.hip", "stackb.hip", "stackb_train.hip", "fusions.hip", "comm.hip", "api.hip"]
+SOURCES = ["gemm_nt.hip", "gemm_nx.hip", "gemm_tt.hip", "gemm_glds.hip", "gemm_ln.hip", "chain.hip", "gemm_tt256.hip", "gemm_nt256.hip", "gemm.hip", "rowops.hip", "attention.hip", "tri_fused.hip", "nig.hip", "optim.hip", "side.hip", "stackb.hip", "stackb_train.hip", "fusions.hip", "comm.hip", "api.hip"]
 ARCH = "gfx950"
 # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs at wave start (gemm_glds.hip)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

@@ -14,6 +14,7 @@
 #include "nig.h"
 #include "optim.h"
 #include "options.h"
+#include "chain.h"
 #include "rowops.h"
 
 namespace mmdeer {
@@ -153,7 +154,7 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
 struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
 OptEntry g_opts[OPT_COUNT] = {
     {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
-    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"splitk_max", 8, {8}},
+    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"splitk_max", 8, {8}},
 };
 }  // namespace
 
@@ -544,36 +545,78 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     if (a->prof_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[1], s));
     TRY(launch_tri_attn_fwd(L.qkv, L.obar, L.probs, a->trimodal_attention, a->av_attention, B, f32, X.drop_on ? 1 : 0, X.dc, s));
   }
-  // F9: out_proj on the pooled context (mean over tokens commutes with the linear map; fusion.py:335)
-  TRY(X.run1(X.fwd(L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, L.pool, FUS, B, 0, -1)));
-  // F10-F11: final_fusion (fusion.py:338)
-  TRY(X.run1(X.fwd(L.pool, f32, FUS, P_TFF_W, P_TFF_B, L.y_t3, FUS, B, 1, SITE_TRI_FUSE)));
-  // F11-F12: LayerNorm of final_fusion + output_projection (fusion.py:338, 162); F13-F14: its LayerNorm + feature_processor.0
-  if (lnf) {
-    TRY(ln_gemm(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ), L.y_t3, P_TFF_G, P_TFF_BT, L.tri, a->trimodal_features,
-                L.mean_t3, L.rstd_t3));
-    TRY(ln_gemm(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0), L.y_o1, P_OP_G, P_OP_BT, L.fused, a->fused_features,
-                L.mean_o1, L.rstd_o1));
-  } else {
-    TRY(launch_ln_fwd(L.y_t3, L.tri, a->trimodal_features, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), X.V(P_TFF_BT), B, FUS, f32, s));
-    TRY(X.run1(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ)));
-    TRY(launch_ln_fwd(L.y_o1, L.fused, a->fused_features, L.mean_o1, L.rstd_o1, X.V(P_OP_G), X.V(P_OP_BT), B, FUS, f32, s));
-  }
-  {
-    // F14-F15: feature_processor (deer.py:246)
-    if (!lnf) TRY(X.run1(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0)));
-    TRY(X.run1(X.fwd(L.h1, f32, HID, P_FP1_W, P_FP1_B, L.h2, HID, B, 1, SITE_FP1)));
-    // F16: the three DEERLayer first layers stacked into one N = 384 GEMM (deer.py:49)
-    {
-      GemmProblem p = X.fwd(L.h2, f32, HID, P_EV0_W, P_EV0_B, L.e1, 3 * EV1, B, 1, SITE_EV0);
-      p.N = 3 * EV1;
-      TRY(X.run1(p));
+  // F9-F17 are local to a sample (Linear / ReLU / Dropout / LayerNorm): in bf16 mode ONE launch walks the chain with the rows
+  // resident in LDS (chain.hip) and writes the same workspace buffers; option "chain" = 0 restores the separate launches
+  if (!f32 && opt(OPT_CHAIN)) {
+    ChainArgs c{};
+    c.X = reinterpret_cast<const bf16_t*>(L.obar); c.ldx = FUS; c.K0 = FUS; c.B = B; c.groups = 1; c.group_stride = 0;
+    c.drop = X.dc;
+    auto lin = [&](int pidW, int pidB, int N, int K, int relu, int site, void* stash) {
+      ChainSeg q;
+      chain_seg_defaults(q);
+      q.W = reinterpret_cast<const bf16_t*>(X.W(pidW)); q.bias = X.V(pidB); q.N = N; q.K = K; q.ldw = K;
+      q.relu = relu; q.drop_site = X.drop_on ? site : -1;
+      q.end_layer = 1; q.nout = N; q.stash = reinterpret_cast<bf16_t*>(stash); q.ld_stash = N;
+      return q;
+    };
+    auto with_ln = [&](ChainSeg q, int pidG, int pidBt, void* xln, float* out32, float* mean, float* rstd) {
+      q.gamma = X.V(pidG); q.beta = X.V(pidBt); q.xln = reinterpret_cast<bf16_t*>(xln); q.out32 = out32; q.mean = mean; q.rstd = rstd;
+      return q;
+    };
+    int k = 0;
+    c.seg[k++] = lin(P_TOUT_W, P_TOUT_B, FUS, FUS, 0, -1, L.pool);                                                    // F9
+    c.seg[k++] = with_ln(lin(P_TFF_W, P_TFF_B, FUS, FUS, 1, SITE_TRI_FUSE, L.y_t3), P_TFF_G, P_TFF_BT, L.tri,        // F10-F11
+                         a->trimodal_features, L.mean_t3, L.rstd_t3);
+    c.seg[k++] = with_ln(lin(P_OP_W, P_OP_B, FUS, FUS, 1, SITE_OUT_PROJ, L.y_o1), P_OP_G, P_OP_BT, L.fused,           // F12-F13
+                         a->fused_features, L.mean_o1, L.rstd_o1);
+    c.seg[k++] = lin(P_FP0_W, P_FP0_B, HID, FUS, 1, SITE_FP0, L.h1);                                                   // F14
+    c.seg[k++] = lin(P_FP1_W, P_FP1_B, HID, HID, 1, SITE_FP1, L.h2);                                                   // F15
+    c.seg[k++] = lin(P_EV0_W, P_EV0_B, 3 * EV1, HID, 1, SITE_EV0, L.e1);                                               // F16
+    for (int z = 0; z < 3; ++z) {                                                                                      // F17
+      ChainSeg q = lin(P_EV1_W, P_EV1_B, EV2, EV1, 1, SITE_EV1, nullptr);
+      q.W += (size_t)z * EV2 * EV1; q.bias += z * EV2;
+      q.kin_off = z * EV1; q.nout_off = z * EV2; q.dcol_off = z * EV2;
+      q.end_layer = z == 2; q.nout = 3 * EV2;
+      if (z == 2) { q.stash = reinterpret_cast<bf16_t*>(L.e2); q.ld_stash = 3 * EV2; }
+      c.seg[k++] = q;
     }
-    // F17: second layers, strided-batched over the heads (deer.py:52)
+    c.nseg = k;
+#ifdef MMDEER_STAMPS
+    c.stamps = reinterpret_cast<unsigned long long*>(L.slab);   // diagnostic library: cycle samples of workgroup 0 (tools/chain_stamps.py)
+#endif
+    TRY(launch_chain(c, s));
+  } else {
+    // F9: out_proj on the pooled context (mean over tokens commutes with the linear map; fusion.py:335)
+    TRY(X.run1(X.fwd(L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, L.pool, FUS, B, 0, -1)));
+    // F10-F11: final_fusion (fusion.py:338)
+    TRY(X.run1(X.fwd(L.pool, f32, FUS, P_TFF_W, P_TFF_B, L.y_t3, FUS, B, 1, SITE_TRI_FUSE)));
+    // F11-F12: LayerNorm of final_fusion + output_projection (fusion.py:338, 162); F13-F14: its LayerNorm + feature_processor.0
+    if (lnf) {
+      TRY(ln_gemm(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ), L.y_t3, P_TFF_G, P_TFF_BT, L.tri, a->trimodal_features,
+                  L.mean_t3, L.rstd_t3));
+      TRY(ln_gemm(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0), L.y_o1, P_OP_G, P_OP_BT, L.fused, a->fused_features,
+                  L.mean_o1, L.rstd_o1));
+    } else {
+      TRY(launch_ln_fwd(L.y_t3, L.tri, a->trimodal_features, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), X.V(P_TFF_BT), B, FUS, f32, s));
+      TRY(X.run1(X.fwd(L.tri, f32, FUS, P_OP_W, P_OP_B, L.y_o1, FUS, B, 1, SITE_OUT_PROJ)));
+      TRY(launch_ln_fwd(L.y_o1, L.fused, a->fused_features, L.mean_o1, L.rstd_o1, X.V(P_OP_G), X.V(P_OP_BT), B, FUS, f32, s));
+    }
     {
-      GemmProblem p = X.fwd(L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, L.e2, 3 * EV2, B, 1, SITE_EV1);
-      p.batch = 3; p.sA = EV1; p.sB = (long long)EV2 * EV1; p.sC = EV2; p.sBias = EV2;
-      TRY(X.run1(p));
+      // F14-F15: feature_processor (deer.py:246)
+      if (!lnf) TRY(X.run1(X.fwd(L.fused, f32, FUS, P_FP0_W, P_FP0_B, L.h1, HID, B, 1, SITE_FP0)));
+      TRY(X.run1(X.fwd(L.h1, f32, HID, P_FP1_W, P_FP1_B, L.h2, HID, B, 1, SITE_FP1)));
+      // F16: the three DEERLayer first layers stacked into one N = 384 GEMM (deer.py:49)
+      {
+        GemmProblem p = X.fwd(L.h2, f32, HID, P_EV0_W, P_EV0_B, L.e1, 3 * EV1, B, 1, SITE_EV0);
+        p.N = 3 * EV1;
+        TRY(X.run1(p));
+      }
+      // F17: second layers, strided-batched over the heads (deer.py:52)
+      {
+        GemmProblem p = X.fwd(L.e1, f32, 3 * EV1, P_EV1_W, P_EV1_B, L.e2, 3 * EV2, B, 1, SITE_EV1);
+        p.batch = 3; p.sA = EV1; p.sB = (long long)EV2 * EV1; p.sC = EV2; p.sBias = EV2;
+        TRY(X.run1(p));
+      }
     }
   }
   // F18: last layer (64 -> 4), NIG activations, uncertainties and -- with targets -- the loss statistics

@@ -1,0 +1,55 @@
+// Row-local layer chains in ONE launch (chain.hip): a workgroup owns 16 samples and carries them through a sequence of
+// Linear (+ReLU +Dropout) (+LayerNorm) layers with the activations resident in LDS; only the weights stream.
+#pragma once
+#include "common.h"
+
+namespace mmdeer {
+
+constexpr int CHAIN_MAX_SEGS = 12;
+constexpr int CHAIN_MAX_TILES = 24;      // output-column tiles of all segments
+constexpr int CHAIN_MAX_ENDS = 8;        // layers
+constexpr int CHAIN_MAX_VECS = 16;       // bias / gamma / beta vectors
+constexpr int CHAIN_VEC_FLOATS = 4864;   // LDS floats for every bias / gamma / beta of a chain
+
+// One GEMM segment:  out[:, nout_off + [0,N)) = act( in[:, kin_off + [0,K)) W^T + bias ).
+// A layer is one or more segments writing disjoint column ranges of the same output panel (the three evidence heads
+// of deer.py:52 are three segments); the last one carries end_layer = 1 and the fields that say what happens to the
+// finished panel: stored for the backward pass (`stash`), LayerNorm'ed in place (`gamma`), then it becomes the input
+// panel of the next layer.
+struct ChainSeg {
+  const bf16_t* W;       // [N][ldw] bf16 (K contiguous)
+  const float* bias;     // [N] or null
+  bf16_t* stash;         // end_layer: the finished (pre-LayerNorm) rows -> [row][ld_stash], or null
+  const float* gamma;    // end_layer: LayerNorm over the finished panel (width nout), or null
+  const float* beta;
+  bf16_t* xln;           // LayerNorm outputs: normalised rows [row][nout], fp32 copy (optional), statistics
+  float* out32;
+  float* mean;
+  float* rstd;
+  int N, K, ldw;
+  int kin_off, nout_off;   // first input / output panel column (multiples of 64)
+  int dcol_off;            // dropout column index of this segment's column 0 (head * N for the stacked heads)
+  int ld_stash, nout;      // end_layer: leading dimension of stash, width of the finished panel
+  int relu, drop_site, drop_shift, end_layer;
+  int mblocks;             // 16-row blocks of the input panel this segment multiplies (0: all of them)
+  int fold_groups;         // 1: rows of group z land in rows of group 0, columns + z * N (torch.cat of the two AV calls)
+};
+
+// Host-side description of a chain (api.hip fills it; launch_chain() validates it and derives the kernel's tables).
+struct ChainArgs {
+  const bf16_t* X;         // chain input [rows][ldx]
+  int ldx, K0;             // leading dimension, width (<= 512, multiple of 64)
+  int B;                   // samples
+  int groups;              // 1, or 2: the input holds rows [0,B) and [group_stride, group_stride + B) of every sample block
+  long long group_stride;  // rows between the groups
+  int nseg;
+  DropCtx drop;
+  unsigned long long* stamps;   // diagnostic builds (-DMMDEER_STAMPS) only: cycle-counter samples of workgroup 0; else null
+  ChainSeg seg[CHAIN_MAX_SEGS];
+};
+
+void chain_seg_defaults(ChainSeg& s);
+// Validates shapes / alignment, derives the kernel's tables and enqueues the chain on `stream`.
+int launch_chain(const ChainArgs& a, hipStream_t stream);
+
+}  // namespace mmdeer

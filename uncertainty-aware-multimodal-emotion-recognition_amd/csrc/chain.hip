@@ -1,0 +1,540 @@
+// Row-local layer chains in ONE launch.
+//
+// Every layer of the path between the attention blocks and the NIG head is local to a sample: Linear, ReLU, Dropout and
+// LayerNorm act on one row (reference fusion.py:98-103, 216-221, 301-306; deer.py:215-221, 49-55).  As separate launches
+// each of them is a 5-7 us GEMM of 2-4 GFLOP whose time is the fixed cost of a dependent launch plus one fill / drain of
+// the chip (the small GEMMs are bound by LDS-DMA issue, not by MFMA), and each writes its rows to HBM only for
+// the next launch to read them back.  Here a workgroup owns MS = 16 or 32 samples and walks the whole chain: the input
+// rows are DMA-copied into an LDS panel once, every layer multiplies the resident panel by its weight matrix -- streamed
+// through a ring of 16-KiB LDS slots by `global_load_lds`, NST - 1 stages ahead, ACROSS tile and layer boundaries, so the
+// weight stream never drains -- and writes bias / ReLU / dropout'ed bf16 rows into the second panel, which is then the
+// input of the next layer.  A finished panel is also copied to the workspace buffer the separate launches wrote (the
+// backward pass and the teacher-forced tests read the same buffers), and a LayerNorm runs on it in place.
+//
+// Layout.  A panel holds `rows` x 64-column images, image = rows x 128 B, 16-byte chunk c of row r at chunk slot
+// c ^ (r & 7) (the bank-conflict-free layout of gemm_glds.hip).  A weight stage is 16 KiB = sixteen 1-KiB DMA pieces,
+// two per wave: 128 output columns x 64 k (N % 128 == 0) or 64 output columns x 128 k (the three 128 -> 64 heads).
+// MFMA roles: A = weights, B = activations, so a lane ends up with four consecutive output columns of one sample row --
+// one 8-byte LDS write into the next panel.  Accumulation order over k is that of the stand-alone GEMM kernels: the
+// chain reproduces their outputs bit for bit.
+//
+// vmcnt bookkeeping: every wave issues exactly two DMA instructions per stage and the stream runs four stages ahead of
+// the one being multiplied, so "stages j and j+1 have landed" is a counted `s_waitcnt vmcnt(4)` (two stages are consumed
+// per barrier; `vmcnt(6)` for a lone stage); global stores issued in between (stash copies, LayerNorm outputs) only make
+// the count conservative (loads and stores retire in order on gfx9).  Past the last stage the stream wraps around to the first
+// segment, so the count is the same at every stage of the chain and the tail needs no special case.  All bias / gamma /
+// beta vectors are staged into LDS once at kernel start: a tracked global load in the steady state would make the compiler drain the ring with vmcnt(0).
+#include <type_traits>
+#include "gemm_kernel.inc"
+#include "chain.h"
+#include "options.h"
+
+namespace mmdeer {
+namespace {
+
+template <int N>
+__device__ __forceinline__ void ch_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void dma16(const void* src, void* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned chain_drop_key(unsigned long long seed, unsigned long long off, int site) {
+  unsigned k = mix32((unsigned)seed ^ 0x9E3779B9u);   // == drop_key() with the device counter already added to `off`
+  k = mix32(k ^ (unsigned)(seed >> 32));
+  k = mix32(k ^ (unsigned)off);
+  k = mix32(k ^ (unsigned)(off >> 32) ^ ((unsigned)site * 0x85EBCA6Bu));
+  return k;
+}
+
+// ---- kernel-side tables (derived by launch_chain).  They are copied into LDS by one parallel vector load at kernel start
+// and read from there: the kernel walks them record after record, and as dependent scalar loads from the kernarg segment
+// each record was a ~1000-cycle round trip.  All fields are dwords (a sub-dword field would be a vector load).
+struct ChainSegK {           // one GEMM segment = ntiles column tiles of `nkt` weight stages each; 96 bytes
+  const bf16_t* W;
+  int ldw, nkt;              // stages per tile: K / 64 (128-column stages) or K / 128 (64-column stages)
+  int ntiles, kindb;         // column tiles (<= 4); 1: 64 columns x 128 k per stage
+  int end;                   // index into ChainKArgs::end when this segment finishes a layer, else -1
+  int N;
+  int vec_off, dcol_off, nout_off, site;
+  int shift, relu, fold, mblocks;
+  int rows_out, kin_off, pad0, pad1;
+  int pad2[4];
+};
+struct ChainEndK {           // what happens to a finished panel; 64 bytes
+  bf16_t* stash; bf16_t* xln; float* out32; float* mean; float* rstd;
+  int ld_stash, nout, gb_off, has_ln;
+  int pad[2];
+};
+struct ChainVecK {           // one bias / gamma / beta vector to stage into LDS; 16 bytes
+  const float* src;
+  int off, n4;               // LDS float offset, 16-byte chunks
+};
+static_assert(sizeof(ChainSegK) == 96 && sizeof(ChainEndK) == 64 && sizeof(ChainVecK) == 16, "table record sizes");
+
+struct ChainKArgs {
+  const bf16_t* X;
+  int ldx, K0;
+  int B, groups;
+  long long group_stride;
+  int nseg, nvec;
+  DropCtx drop;
+  unsigned long long* stamps;
+  ChainSegK seg[CHAIN_MAX_SEGS];
+  ChainEndK end[CHAIN_MAX_ENDS];
+  ChainVecK vec[CHAIN_MAX_VECS];
+};
+static_assert(__builtin_offsetof(ChainKArgs, seg) % 16 == 0, "tables must be 16-byte aligned");
+static_assert(sizeof(ChainKArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+struct ChainLnOut {
+  bf16_t* stash; bf16_t* xln; float* out32; float* mean; float* rstd;
+  int ld_stash, gb_off;
+};
+
+// sum over the 32 lanes of a wave half, result in every lane of the half
+__device__ __forceinline__ float half_sum(float v, int lane) {
+  v = row_sum(v);
+  v += dpp_read<0x142, 0xA>(v);    // row_bcast:15 -> rows 1 and 3 add the total of the row below
+  const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+  const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return lane < 32 ? lo : hi;
+}
+
+// LayerNorm of a finished panel in place, plus everything the backward pass wants of it: raw rows, normalised rows, fp32
+// copy, mean, rstd.  32 lanes per row (a wave takes two rows, the eight waves of the workgroup 16): lane l of a half owns
+// the 16-byte chunks l, l + 32 of its row.
+template <int NKT>
+__device__ __forceinline__ void chain_ln(unsigned char* pan, int img, int r, bool valid, long long grow, int lane, const float* vec,
+                                         const ChainLnOut& o_) {
+#pragma clang fp contract(off)   // the same arithmetic, operation by operation, as the LayerNorm block of gemm_ln.hip
+  constexpr int KD = NKT * 64, NC = NKT / 4;   // chunks per lane
+  constexpr float inv_k = 1.0f / (float)KD;
+  const f32x4* gam = reinterpret_cast<const f32x4*>(vec + o_.gb_off);
+  const f32x4* bet = gam + KD / 4;
+  const int l32 = lane & 31;
+  bf16_t* stash = o_.stash;
+  bf16_t* xln = o_.xln;
+  float* out32 = o_.out32;
+  const int lds_ = o_.ld_stash;
+  float x[NC * 8];
+  unsigned char* cell[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int c = l32 + 32 * j;               // chunk of the row: image c >> 3, slot (c & 7) ^ (r & 7)
+    cell[j] = pan + (c >> 3) * img + r * 128 + (((c & 7) ^ (r & 7)) * 16);
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(cell[j]);
+    if (valid && stash) store_wt16(stash + grow * lds_ + c * 8, raw);
+    x[8 * j + 0] = __uint_as_float(raw.x << 16); x[8 * j + 1] = __uint_as_float(raw.x & 0xFFFF0000u);
+    x[8 * j + 2] = __uint_as_float(raw.y << 16); x[8 * j + 3] = __uint_as_float(raw.y & 0xFFFF0000u);
+    x[8 * j + 4] = __uint_as_float(raw.z << 16); x[8 * j + 5] = __uint_as_float(raw.z & 0xFFFF0000u);
+    x[8 * j + 6] = __uint_as_float(raw.w << 16); x[8 * j + 7] = __uint_as_float(raw.w & 0xFFFF0000u);
+  }
+  // Row statistics in the order gemm_ln.hip uses (so both launch plans give the same bits): per 8-element chunk a fixed tree,
+  // q[g] = chunk of image g + chunk of image g + 4, t[g] = sum of q[g] over the 8 chunk positions (DPP), (t0 + t1) + (t2 + t3).
+  // Here lane (g = l32 >> 3, position l32 & 7) owns exactly the two chunks of q[g].
+  auto chunk_sum = [](const float* v) -> float { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); };
+  float q = chunk_sum(x);
+  if constexpr (NC == 2) q += chunk_sum(x + 8);
+  const float mu = half_sum(q, lane) * inv_k;
+  float d[NC * 8];
+#pragma unroll
+  for (int e = 0; e < NC * 8; ++e) { const float t = x[e] - mu; d[e] = t * t; }
+  float qv = chunk_sum(d);
+  if constexpr (NC == 2) qv += chunk_sum(d + 8);
+  const float var = half_sum(qv, lane) * inv_k;
+  const float rs = 1.0f / __builtin_sqrtf(var + 1e-5f);
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int c = l32 + 32 * j;
+    const f32x4 ga = gam[2 * c], gb2 = gam[2 * c + 1], ba = bet[2 * c], bb = bet[2 * c + 1];
+    float o[8];
+    o[0] = (x[8 * j + 0] - mu) * rs * ga.x + ba.x; o[1] = (x[8 * j + 1] - mu) * rs * ga.y + ba.y;
+    o[2] = (x[8 * j + 2] - mu) * rs * ga.z + ba.z; o[3] = (x[8 * j + 3] - mu) * rs * ga.w + ba.w;
+    o[4] = (x[8 * j + 4] - mu) * rs * gb2.x + bb.x; o[5] = (x[8 * j + 5] - mu) * rs * gb2.y + bb.y;
+    o[6] = (x[8 * j + 6] - mu) * rs * gb2.z + bb.z; o[7] = (x[8 * j + 7] - mu) * rs * gb2.w + bb.w;
+    const u32x4 packed{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(cell[j]) = packed;
+    if (valid) {
+      const long long col = grow * KD + c * 8;
+      store_wt16(xln + col, packed);
+      if (out32) {
+        store_wt16(out32 + col, f32x4{o[0], o[1], o[2], o[3]});
+        store_wt16(out32 + col + 4, f32x4{o[4], o[5], o[6], o[7]});
+      }
+    }
+  }
+  if (valid && l32 == 0) { o_.mean[grow] = mu; o_.rstd[grow] = rs; }
+}
+
+__global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
+  constexpr int MS = 16, LOG_MS = 4, NST = 6;
+  constexpr int PAN = MS * 1024;           // 16 rows x 512 columns (or 32 x 256) of bf16
+  constexpr int SLOT = 16384;
+  constexpr int RING = 2 * PAN, VEC = RING + NST * SLOT, TAB = VEC + CHAIN_VEC_FLOATS * 4;
+  constexpr int SEG_BYTES = (int)sizeof(ChainSegK);
+  constexpr int END0 = CHAIN_MAX_SEGS * SEG_BYTES, VEC0 = END0 + CHAIN_MAX_ENDS * (int)sizeof(ChainEndK);
+  constexpr int TAB_BYTES = VEC0 + CHAIN_MAX_VECS * (int)sizeof(ChainVecK);
+  static_assert(TAB_BYTES % 16 == 0 && TAB_BYTES / 16 <= 512, "one 16-byte chunk of the tables per thread");
+  static_assert(TAB + TAB_BYTES <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[TAB + TAB_BYTES];
+  float* const vec = reinterpret_cast<float*>(lds + VEC);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int r8 = lane >> 3, kchunk = ((lane & 7) ^ r8) * 8;
+  const int row0 = blockIdx.x * MS;
+  const int B = a.B;
+  const long long gstride = a.group_stride;
+  const int nseg = a.nseg, nvec = a.nvec;
+#ifdef MMDEER_STAMPS
+  unsigned long long* const stamps = a.stamps;
+  auto stamp = [&](int i) { if (stamps && blockIdx.x == 0 && tid == 0 && i < 128) stamps[i] = __builtin_readcyclecounter(); };
+#else
+  auto stamp = [&](int) {};
+#endif
+  stamp(0);
+
+  // dropout: the step counter is read ONCE, before any DMA is in flight (a tracked load later would drain the ring)
+  const unsigned long long dseed = a.drop.seed;
+  const unsigned long long doff = a.drop.offset + (a.drop.offset_dev ? *a.drop.offset_dev : 0ull);
+  const unsigned dthresh = a.drop.thresh;
+  const float dscale = a.drop.scale;
+
+  // global row of panel row r (two row groups: the audio->video and video->audio calls of the shared AV attention)
+  auto grow_of = [&](int r) -> long long { return (long long)(r >> LOG_MS) * gstride + row0 + (r & (MS - 1)); };
+  auto valid_of = [&](int r) -> bool { return row0 + (r & (MS - 1)) < B; };
+
+  // ---- input panel
+  int rows_in = a.groups * MS;
+  {
+    const int rg = rows_in >> 3, np = (a.K0 >> 6) * rg;
+    const int img = rows_in * 128;
+    for (int q = wave; q < np; q += 8) {
+      const int image = q / rg, g8 = q - image * rg;
+      const int r = g8 * 8 + r8;
+      const long long gr = valid_of(r) ? grow_of(r) : (long long)(r >> LOG_MS) * gstride;
+      dma16(a.X + gr * a.ldx + image * 64 + kchunk, lds + image * img + g8 * 1024);
+    }
+  }
+  // ---- the tables into LDS: one parallel vector load
+  {
+    const unsigned char* src = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ChainKArgs, seg);
+    if (tid < TAB_BYTES / 16) *reinterpret_cast<u32x4*>(lds + TAB + 16 * tid) = *reinterpret_cast<const u32x4*>(src + 16 * tid);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  stamp(1);
+  const unsigned char* const tab = lds + TAB;
+  auto sc = [](unsigned v) -> int { return __builtin_amdgcn_readfirstlane((int)v); };
+  auto sp = [](unsigned lo, unsigned hi) -> unsigned long long {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+  };
+
+  // Column tiles of a segment are walked in an order rotated by the workgroup's index inside its XCD: all workgroups
+  // stream the SAME weights, and in lockstep 32 CUs of an XCD would ask one L2 channel for the same line at the same moment
+  const int rot = blockIdx.x >> 3;
+  const int rot2 = rot & 1, rot3 = rot % 3, rot4 = rot & 3;
+  auto phys_tile = [&](int nt, int ntl) -> int {
+    const int ph = nt + (ntl == 4 ? rot4 : ntl == 3 ? rot3 : ntl == 2 ? rot2 : 0);
+    return ph >= ntl ? ph - ntl : ph;
+  };
+
+  // ---- weight stream: a cursor over (segment, column tile, stage); two DMA pieces per wave per stage
+  int p_si = 0, p_nt = 0, p_kt = 0, p_nkt = 0, p_ntiles = 0, p_step = 0, p_ldw = 0, p_kb = 0;
+  const bf16_t* p_W = nullptr;
+  const bf16_t* p0 = nullptr;
+  const bf16_t* p1 = nullptr;
+  auto p_tile = [&]() __attribute__((always_inline)) {
+    const int ph = phys_tile(p_nt, p_ntiles);
+    p0 = p_W + (long long)(ph * (p_kb ? 64 : 128) + wave * 8 + r8) * p_ldw + kchunk;
+    p1 = p0 + (p_kb ? 64ll : 64ll * p_ldw);    // 64-column stages: the next 64 k; 128-column stages: 64 rows further down
+  };
+  auto p_load = [&]() __attribute__((always_inline)) {
+    const u32x4* rec = reinterpret_cast<const u32x4*>(tab + p_si * SEG_BYTES);
+    const u32x4 q0 = rec[0], q1 = rec[1];
+    p_W = reinterpret_cast<const bf16_t*>(sp(q0.x, q0.y));
+    p_ldw = sc(q0.z); p_nkt = sc(q0.w); p_ntiles = sc(q1.x); p_kb = sc(q1.y);
+    p_step = p_kb ? 128 : 64;
+    p_nt = 0;
+    p_tile();
+  };
+  auto issue = [&](int slot) __attribute__((always_inline)) {
+    unsigned char* d = lds + RING + slot * SLOT + wave * 1024;
+    dma16(p0, d);
+    dma16(p1, d + 8192);
+    p0 += p_step; p1 += p_step;
+    if (++p_kt == p_nkt) {
+      p_kt = 0;
+      if (++p_nt == p_ntiles) {
+        if (++p_si == nseg) p_si = 0;   // past the end the stream wraps around: four stages nobody reads, but every
+        p_load();                       // stage of the chain sees the same number of younger DMAs (constant waits)
+      } else {
+        p_tile();
+      }
+    }
+  };
+  p_load();
+#pragma unroll
+  for (int t = 0; t < NST - 2; ++t) issue(t);
+
+  // ---- every bias / gamma / beta of the chain into LDS, by DMA as well (vector e is wave e % 8's job)
+  for (int e = wave; e < nvec; e += 8) {
+    const u32x4 q = *reinterpret_cast<const u32x4*>(tab + VEC0 + e * 16);
+    const float* src = reinterpret_cast<const float*>(sp(q.x, q.y));
+    unsigned char* dst = lds + VEC + sc(q.z) * 4;
+    const int n4 = sc(q.w);
+    for (int j = 0; j * 64 < n4; ++j) {
+      if (src) { if (j * 64 + lane < n4) dma16(src + 4 * (j * 64 + lane), dst + j * 1024); }
+      else if (j * 64 + lane < n4) *reinterpret_cast<f32x4*>(dst + j * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  stamp(2);
+
+  // ---- the chain
+  unsigned char* pin = lds;
+  unsigned char* pout = lds + PAN;
+  int slot = 0;
+  const int swz0 = (lg ^ (li & 7)) * 16, swz1 = ((4 + lg) ^ (li & 7)) * 16;
+  auto wrap = [](int s_) -> int { return s_ >= NST ? s_ - NST : s_; };
+
+  struct SegCtl { int N, ntiles, vec_off, dcol_off, nout_off, site, shift, relu, fold, kin_off, rows_out; };
+
+  // One segment.  The activation fragments of its 16 (or 32) rows stay in REGISTERS for all its column tiles: re-read from the
+  // panel at every stage they were half of the LDS traffic of the stage loop, and the loop is LDS-bandwidth-bound (8 waves x
+  // (2 KiB of weights + 2 KiB of activations) + 16 KiB written by the DMA per stage = 48 KiB at 128 B/clk).
+  // MB row blocks; KB: 64-column stages of 128 k, else 128 columns x 64 k; NKT stages per tile.
+  auto seg_body = [&](auto mbc, auto kbc, auto nktc, const SegCtl& sg) __attribute__((always_inline)) {
+    constexpr int MB = decltype(mbc)::value;
+    constexpr bool KB = decltype(kbc)::value;
+    constexpr int NKT = decltype(nktc)::value;
+    constexpr int NCH = KB ? 4 : 2;               // 32-wide k-chunks per stage
+    const bool active = !KB || wave < 4;          // 64-column stages: four column blocks
+    const int img_in = rows_in * 128, img_out = sg.rows_out * 128;
+    u32x4 afr[NKT * NCH][MB];
+    {
+      const unsigned char* sa = pin + (sg.kin_off >> 6) * img_in + li * 128;
+#pragma unroll
+      for (int c = 0; c < NKT * NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) afr[c][i] = *reinterpret_cast<const u32x4*>(sa + (c >> 1) * img_in + i * 2048 + ((c & 1) ? swz1 : swz0));
+    }
+    const int site = sg.site, shift = sg.shift, relu = sg.relu, fold = sg.fold, N = sg.N;
+    const unsigned dkey = site >= 0 ? chain_drop_key(dseed, doff, site) : 0u;
+    for (int nti = 0; nti < sg.ntiles; ++nti) {
+      const int nt = phys_tile(nti, sg.ntiles);
+      f32x4 acc[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto wfrag = [&](u32x4 (&fw)[NCH], int sl) __attribute__((always_inline)) {
+        const unsigned char* sw = lds + RING + sl * SLOT + (16 * wave + li) * 128;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) fw[c] = *reinterpret_cast<const u32x4*>(sw + (c >> 1) * 8192 + ((c & 1) ? swz1 : swz0));
+      };
+#pragma unroll
+      for (int kt = 0; kt + 2 <= NKT; kt += 2) {
+        ch_wait_vm<4>();                            // this wave's pieces of both stages have landed: two younger stages in flight
+        __builtin_amdgcn_s_barrier();               // ... for every wave; and the two slots refilled below have been read by everyone
+        u32x4 fw0[NCH], fw1[NCH];
+        if (active) { wfrag(fw0, slot); wfrag(fw1, wrap(slot + 1)); }
+        issue(wrap(slot + 4));
+        issue(wrap(slot + 5));
+        if (active) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(fw0[c], afr[kt * NCH + c][i], acc[i]);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(fw1[c], afr[(kt + 1) * NCH + c][i], acc[i]);
+        }
+        slot = wrap(slot + 2);
+      }
+      if constexpr (NKT & 1) {
+        ch_wait_vm<6>();                            // a lone stage: three younger stages in flight
+        __builtin_amdgcn_s_barrier();
+        u32x4 fw0[NCH];
+        if (active) wfrag(fw0, slot);
+        issue(wrap(slot + 4));
+        if (active) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(fw0[c], afr[(NKT - 1) * NCH + c][i], acc[i]);
+        }
+        slot = wrap(slot + 1);
+      }
+      // ---- bias, ReLU, dropout, bf16 -> output panel
+      if (active) {
+        const int n0 = (KB ? nt * 64 : nt * 128) + 16 * wave + 4 * lg;
+        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(vec + sg.vec_off + n0);
+        const unsigned dcol = (unsigned)(sg.dcol_off + n0);
+        const int colb = sg.nout_off + n0;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const int r = 16 * i + li;
+          f32x4 v = acc[i] + bias4;
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (site >= 0) {
+            const unsigned rk = ((unsigned)grow_of(r) * 0x9E3779B1u) ^ dkey;
+            if (shift == 0) {
+              v.x = mix32(rk ^ (dcol * 0x85EBCA77u)) < dthresh ? v.x * dscale : 0.f;
+              v.y = mix32(rk ^ ((dcol + 1) * 0x85EBCA77u)) < dthresh ? v.y * dscale : 0.f;
+              v.z = mix32(rk ^ ((dcol + 2) * 0x85EBCA77u)) < dthresh ? v.z * dscale : 0.f;
+              v.w = mix32(rk ^ ((dcol + 3) * 0x85EBCA77u)) < dthresh ? v.w * dscale : 0.f;
+            } else {
+              const float f = mix32(rk ^ ((dcol >> shift) * 0x85EBCA77u)) < dthresh ? dscale : 0.f;
+              v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+            }
+          }
+          int col = colb, orow = r;
+          if (fold) { col += (r >> LOG_MS) * N; orow = r & (MS - 1); }
+          unsigned char* cell = pout + (col >> 6) * img_out + orow * 128 + ((((col & 63) >> 3) ^ (orow & 7)) * 16) + (col & 4) * 2;
+          *reinterpret_cast<u32x2*>(cell) = u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+        }
+      }
+    }
+  };
+
+  for (int si = 0; si < nseg; ++si) {
+    const u32x4* rec = reinterpret_cast<const u32x4*>(tab + si * SEG_BYTES);
+    const u32x4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+    const int nkt = sc(q0.w), kb = sc(q1.y), endi = sc(q1.z);
+    SegCtl sg;
+    sg.ntiles = sc(q1.x); sg.N = sc(q1.w);
+    sg.vec_off = sc(q2.x); sg.dcol_off = sc(q2.y); sg.nout_off = sc(q2.z); sg.site = sc(q2.w);
+    sg.shift = sc(q3.x); sg.relu = sc(q3.y); sg.fold = sc(q3.z);
+    const int mb = sc(q3.w);
+    sg.rows_out = sc(q4.x); sg.kin_off = sc(q4.y);
+    stamp(3 + 3 * si);
+#define CH_SEG(MBv, KBv, NKTv) seg_body(std::integral_constant<int, MBv>{}, std::integral_constant<bool, KBv>{}, std::integral_constant<int, NKTv>{}, sg)
+    if (!kb) {
+      if (mb == 1) {
+        if (nkt == 8) CH_SEG(1, false, 8); else if (nkt == 6) CH_SEG(1, false, 6); else if (nkt == 4) CH_SEG(1, false, 4);
+        else if (nkt == 2) CH_SEG(1, false, 2); else CH_SEG(1, false, 1);
+      } else {
+        if (nkt == 4) CH_SEG(2, false, 4); else if (nkt == 2) CH_SEG(2, false, 2); else CH_SEG(2, false, 1);
+      }
+    } else {
+      if (mb == 1) { if (nkt == 2) CH_SEG(1, true, 2); else CH_SEG(1, true, 1); }
+      else CH_SEG(2, true, 1);
+    }
+#undef CH_SEG
+    stamp(4 + 3 * si);
+    if (endi >= 0) {
+      const int rows_out = sg.rows_out, img_out = rows_out * 128;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();              // the output panel is complete
+      const u32x4* er = reinterpret_cast<const u32x4*>(tab + END0 + endi * (int)sizeof(ChainEndK));
+      const u32x4 e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
+      bf16_t* stash = reinterpret_cast<bf16_t*>(sp(e0.x, e0.y));
+      const int ld_stash = sc(e2.z), nout = sc(e2.w);
+      const int gb_off = sc(e3.x), has_ln = sc(e3.y);
+      if (has_ln) {
+        ChainLnOut o;
+        o.stash = stash; o.xln = reinterpret_cast<bf16_t*>(sp(e0.z, e0.w)); o.out32 = reinterpret_cast<float*>(sp(e1.x, e1.y));
+        o.mean = reinterpret_cast<float*>(sp(e1.z, e1.w)); o.rstd = reinterpret_cast<float*>(sp(e2.x, e2.y));
+        o.ld_stash = ld_stash; o.gb_off = gb_off;
+        for (int r = 2 * wave + (lane >> 5); r < rows_out; r += 16) {
+          if (nout == 512) chain_ln<8>(pout, img_out, r, valid_of(r), grow_of(r), lane, vec, o);
+          else chain_ln<4>(pout, img_out, r, valid_of(r), grow_of(r), lane, vec, o);
+        }
+      } else if (stash) {
+        const int nch = nout >> 3;
+        for (int r = wave; r < rows_out; r += 8) {
+          if (!valid_of(r)) continue;
+          const long long gr = grow_of(r);
+          for (int cc = lane; cc < nch; cc += 64) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(pout + (cc >> 3) * img_out + r * 128 + (((cc & 7) ^ (r & 7)) * 16));
+            store_wt16(stash + gr * ld_stash + cc * 8, raw);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      unsigned char* t = pin; pin = pout; pout = t;
+      rows_in = rows_out;
+    }
+    stamp(5 + 3 * si);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+void chain_seg_defaults(ChainSeg& s) {
+  s = ChainSeg{};
+  s.drop_site = -1;
+}
+
+int launch_chain(const ChainArgs& a, hipStream_t stream) {
+  MMDEER_CHECK(a.nseg >= 1 && a.nseg <= CHAIN_MAX_SEGS, "chain: 1..%d segments (got %d)", CHAIN_MAX_SEGS, a.nseg);
+  MMDEER_CHECK(a.B > 0 && a.X && ((uintptr_t)a.X % 16) == 0 && a.ldx % 8 == 0, "chain: input rows must be 16-byte aligned");
+  MMDEER_CHECK(a.groups == 1 || a.groups == 2, "chain: groups must be 1 or 2");
+  MMDEER_CHECK(a.K0 % 64 == 0 && a.K0 * a.groups <= 512, "chain: input width %d x %d groups does not fit the panel", a.K0, a.groups);
+  ChainKArgs k{};
+  k.X = a.X; k.ldx = a.ldx; k.K0 = a.K0; k.B = a.B; k.groups = a.groups; k.group_stride = a.group_stride; k.drop = a.drop;
+  k.stamps = a.stamps;
+  int vec = 0, nend = 0, nvec = 0;
+  int blocks_in = a.groups, width_in = a.K0, layer_first_seg = 0;
+  auto add_vec = [&](const float* src, int n) { ChainVecK& v = k.vec[nvec++]; v.src = src; v.off = vec; v.n4 = n / 4; vec += n; return v.off; };
+  for (int i = 0; i < a.nseg; ++i) {
+    const ChainSeg& s = a.seg[i];
+    MMDEER_CHECK(s.W && ((uintptr_t)s.W % 16) == 0 && s.ldw % 8 == 0, "chain: segment %d weights must be 16-byte aligned", i);
+    MMDEER_CHECK(s.N > 0 && s.N % 64 == 0 && s.K > 0 && s.K % 64 == 0 && (s.N % 128 == 0 || s.K % 128 == 0),
+                 "chain: segment %d has unsupported N = %d, K = %d", i, s.N, s.K);
+    MMDEER_CHECK(s.kin_off % 64 == 0 && s.kin_off + s.K <= width_in, "chain: segment %d reads columns [%d, %d) of a %d-wide panel", i,
+                 s.kin_off, s.kin_off + s.K, width_in);
+    MMDEER_CHECK(s.nout_off % 64 == 0, "chain: segment %d output offset", i);
+    MMDEER_CHECK(!s.bias || ((uintptr_t)s.bias % 16) == 0, "chain: segment %d bias alignment", i);
+    const int mblocks = s.mblocks ? s.mblocks : blocks_in;
+    MMDEER_CHECK(mblocks <= blocks_in && mblocks <= 2, "chain: segment %d m-blocks", i);
+    MMDEER_CHECK(nvec + 3 <= CHAIN_MAX_VECS, "chain: too many bias / gamma / beta vectors");
+    const int vec_off = add_vec(s.bias, s.N);
+    const int kb = s.N % 128 != 0, ntl = kb ? s.N / 64 : s.N / 128, nkt = kb ? s.K / 128 : s.K / 64;
+    MMDEER_CHECK(ntl <= 4, "chain: segment %d has too many column tiles", i);
+    MMDEER_CHECK(kb ? (nkt <= 2 && mblocks * nkt <= 2) : ((nkt == 1 || nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8) && mblocks * nkt <= 8),
+                 "chain: segment %d: K = %d with %d row blocks is not instantiated", i, s.K, mblocks);
+    ChainSegK& td = k.seg[i];
+    td.W = s.W; td.ldw = s.ldw; td.nkt = nkt; td.ntiles = ntl; td.kindb = kb; td.end = -1;
+    td.N = s.N; td.vec_off = vec_off; td.dcol_off = s.dcol_off; td.nout_off = s.nout_off;
+    td.site = s.drop_site; td.shift = s.drop_shift; td.relu = s.relu; td.fold = s.fold_groups;
+    td.mblocks = mblocks; td.kin_off = s.kin_off;
+    if (s.end_layer) {
+      const int blocks_out = s.fold_groups ? blocks_in / 2 : blocks_in;
+      MMDEER_CHECK(!s.fold_groups || blocks_in == 2, "chain: segment %d folds the groups of a single-group panel", i);
+      MMDEER_CHECK(s.nout % 64 == 0 && s.nout * blocks_out <= 512, "chain: layer ending at segment %d does not fit the panel", i);
+      MMDEER_CHECK(!s.stash || (((uintptr_t)s.stash % 16) == 0 && s.ld_stash % 8 == 0), "chain: segment %d stash alignment", i);
+      MMDEER_CHECK(nend < CHAIN_MAX_ENDS, "chain: too many layers");
+      ChainEndK& e = k.end[nend];
+      e.stash = s.stash; e.ld_stash = s.ld_stash; e.nout = s.nout;
+      if (s.gamma) {
+        MMDEER_CHECK(s.nout == 256 || s.nout == 512, "chain: LayerNorm width %d", s.nout);
+        MMDEER_CHECK(s.beta && s.xln && s.mean && s.rstd && ((uintptr_t)s.gamma % 16) == 0 && ((uintptr_t)s.beta % 16) == 0 &&
+                         ((uintptr_t)s.xln % 16) == 0 && (!s.out32 || ((uintptr_t)s.out32 % 16) == 0),
+                     "chain: LayerNorm of segment %d: pointers / alignment", i);
+        e.has_ln = 1; e.xln = s.xln; e.out32 = s.out32; e.mean = s.mean; e.rstd = s.rstd;
+        e.gb_off = add_vec(s.gamma, s.nout);
+        add_vec(s.beta, s.nout);
+      }
+      td.end = nend++;
+      for (int t = layer_first_seg; t <= i; ++t) k.seg[t].rows_out = blocks_out * 16;   // every segment of the layer needs the output geometry
+      layer_first_seg = i + 1;
+      blocks_in = blocks_out; width_in = s.nout;
+    }
+  }
+  MMDEER_CHECK(a.seg[a.nseg - 1].end_layer, "chain: the last segment must end its layer");
+  MMDEER_CHECK(vec <= CHAIN_VEC_FLOATS, "chain: %d bias / gamma / beta floats exceed the LDS area (%d)", vec, CHAIN_VEC_FLOATS);
+  k.nseg = a.nseg; k.nvec = nvec;
+  hipLaunchKernelGGL(chain_kernel, dim3((a.B + 15) / 16), dim3(512), 0, stream, k);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mmdeer

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_ln_kernel(const LnGemmArgs a, co
   //      over 8 lanes and one pass of a wave covers 8 rows (the first version gave a row the whole wave: 14 dependent DPP
   //      steps per row, 175 instructions per row -- the fused launch was slower than the two it replaced).
   {
+#pragma clang fp contract(off)   // the same arithmetic, operation by operation, as chain_ln() of chain.hip
     const bool writer = tnb == 0;
     const int sub = lane & 7;
     const f32x4* gam = reinterpret_cast<const f32x4*>(lds + GB_OFF);
@@ -150,17 +151,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_ln_kernel(const LnGemmArgs a, co
         x[8 * i + 4] = __uint_as_float(raw.z << 16); x[8 * i + 5] = __uint_as_float(raw.z & 0xFFFF0000u);
         x[8 * i + 6] = __uint_as_float(raw.w << 16); x[8 * i + 7] = __uint_as_float(raw.w & 0xFFFF0000u);
       }
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      // Row statistics in a fixed order that chain.hip reproduces with 32 lanes per row (both launch plans give the same bits):
+      // per 8-element chunk a fixed tree, q[g] = chunk of image g + chunk of image g + 4 (K = 512), t[g] = sum of q[g] over the
+      // 8 chunk positions (DPP), (t0 + t1) + (t2 + t3)
+      auto chunk_sum = [](const float* v) -> float { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); };
+      float t[4];
 #pragma unroll
-      for (int e = 0; e < NKT * 8; e += 4) { s0 += x[e]; s1 += x[e + 1]; s2 += x[e + 2]; s3 += x[e + 3]; }
-      const float mu = oct_sum((s0 + s1) + (s2 + s3)) * inv_k;
-      float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
-#pragma unroll
-      for (int e = 0; e < NKT * 8; e += 4) {
-        const float d0 = x[e] - mu, d1 = x[e + 1] - mu, d2 = x[e + 2] - mu, d3 = x[e + 3] - mu;
-        q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float q = chunk_sum(x + 8 * g4);
+        if constexpr (NKT == 8) q += chunk_sum(x + 8 * (g4 + 4));
+        t[g4] = oct_sum(q);
       }
-      const float var = oct_sum((q0 + q1) + (q2 + q3)) * inv_k;
+      const float mu = ((t[0] + t[1]) + (t[2] + t[3])) * inv_k;
+      float d[NKT * 8];
+#pragma unroll
+      for (int e = 0; e < NKT * 8; ++e) { const float u = x[e] - mu; d[e] = u * u; }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float q = chunk_sum(d + 8 * g4);
+        if constexpr (NKT == 8) q += chunk_sum(d + 8 * (g4 + 4));
+        t[g4] = oct_sum(q);
+      }
+      const float var = ((t[0] + t[1]) + (t[2] + t[3])) * inv_k;
       const float rs = 1.0f / __builtin_sqrtf(var + 1e-5f);
       const int grow = row0 + r;
       const bool store = writer && grow < M;
