@@ -5,7 +5,7 @@ set -u
 mkdir -p gpurun_out
 for cfg in "$@"; do
   envs=""; for kv in ${cfg//,/ }; do envs="$envs MMDEER_$kv"; done
-  env $envs timeout -k 10 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline > gpurun_out/sweep.json 2> gpurun_out/sweep.err
+  env $envs timeout -k 10 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/sweep.json 2> gpurun_out/sweep.err
   python - "$cfg" <<'PY'
 import json, sys
 try:

@@ -495,24 +495,6 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     g.p[2] = X.fwd(a->text, in_f32, TXT, P_TXT_W, P_TXT_B, L.xtok + (size_t)FUS * es, 2 * FUS, B, 0, -1);     // token 1
     TRY(X.run(g));
   }
-  // F2: value projection of the shared AV cross-attention on [video_proj; audio_proj] (fusion.py:244-255;
-  //     L = S = 1 so q/k are dead), attention-weight dropout = one decision per (row, head)
-  {
-    GemmProblem p = X.fwd(L.avin, f32, INTER, P_AIN_W, P_AIN_B, L.avv, INTER, 2 * B, 0, SITE_AV_ATTN);
-    p.B = X.W(P_AIN_W) + (size_t)2 * INTER * INTER * es;   // rows [2E, 3E) of the packed [q;k;v] matrix
-    p.bias = X.V(P_AIN_B) + 2 * INTER;
-    p.N = INTER;
-    p.drop_shift = 5;  // 32 columns = one head
-    TRY(X.run1(p));
-  }
-  // F3: out_proj, batched over the two calls; batch z writes columns [256 z, 256 z + 256) of cat (fusion.py:262)
-  {
-    GemmProblem p = X.fwd(L.avv, f32, INTER, P_AOUT_W, P_AOUT_B, L.cat, 2 * INTER, B, 0, -1);
-    p.batch = 2; p.sA = (long long)B * INTER; p.sC = INTER;
-    TRY(X.run1(p));
-  }
-  // F4-F5: fusion_layers = Linear -> ReLU -> Dropout -> LayerNorm (fusion.py:263)
-  TRY(X.run1(X.fwd(L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, L.y_a2, INTER, B, 1, SITE_AV_FUSE)));
   // bf16 mode: each LayerNorm runs inside the GEMM that consumes it (gemm_ln.hip: the workgroup of a 64-row tile owns whole
   // rows of its A operand, K = the LayerNorm width) -- three launches fewer in the forward; option "ln_fused" = 0 restores
   // the stand-alone LayerNorm kernel
@@ -524,13 +506,78 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     g.drop = X.dc;
     return launch_gemm_ln(g, Y, X.V(pidG), X.V(pidBt), xln, out32, mean, rstd, s);
   };
-  // F5-F6: LayerNorm + audiovisual_projection -> token 0 (fusion.py:263, 321, 325)
-  if (lnf) {
-    TRY(ln_gemm(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1), L.y_a2, P_AVF_G, P_AVF_BT, L.av, a->audiovisual_features,
-                L.mean_a2, L.rstd_a2));
+  const bool chains = !f32 && opt(OPT_CHAIN);
+  // F2-F6 are local to a sample (the AV "attention" has one key per query: softmax == 1, only the value and output projections
+  // remain): in bf16 mode ONE launch walks them with the rows resident in LDS (chain.hip).  A workgroup holds the video and the
+  // audio row of its 16 samples as two row groups; torch.cat of the two attention outputs is a re-view of the panel.
+  if (chains) {
+    ChainArgs c{};
+    c.X = reinterpret_cast<const bf16_t*>(L.avin); c.ldx = INTER; c.K0 = INTER; c.B = B; c.groups = 2; c.group_stride = B;
+    c.drop = X.dc;
+    int k = 0;
+    {   // F2: value projection (rows [2E, 3E) of the packed in_proj), attention-weight dropout = one decision per (row, head)
+      ChainSeg q;
+      chain_seg_defaults(q);
+      q.W = reinterpret_cast<const bf16_t*>(X.W(P_AIN_W)) + (size_t)2 * INTER * INTER; q.bias = X.V(P_AIN_B) + 2 * INTER;
+      q.N = INTER; q.K = INTER; q.ldw = INTER;
+      q.drop_site = X.drop_on ? SITE_AV_ATTN : -1; q.drop_shift = 5;
+      q.end_layer = 1; q.nout = INTER; q.stash = reinterpret_cast<bf16_t*>(L.avv); q.ld_stash = INTER;
+      c.seg[k++] = q;
+    }
+    {   // F3: out_proj of both calls; group z lands in columns [256 z, 256 z + 256) of cat (fusion.py:262)
+      ChainSeg q;
+      chain_seg_defaults(q);
+      q.W = reinterpret_cast<const bf16_t*>(X.W(P_AOUT_W)); q.bias = X.V(P_AOUT_B); q.N = INTER; q.K = INTER; q.ldw = INTER;
+      q.fold_groups = 1;
+      q.end_layer = 1; q.nout = 2 * INTER; q.stash = reinterpret_cast<bf16_t*>(L.cat); q.ld_stash = 2 * INTER;
+      c.seg[k++] = q;
+    }
+    {   // F4-F5: fusion_layers = Linear -> ReLU -> Dropout -> LayerNorm (fusion.py:263)
+      ChainSeg q;
+      chain_seg_defaults(q);
+      q.W = reinterpret_cast<const bf16_t*>(X.W(P_AVF_W)); q.bias = X.V(P_AVF_B); q.N = INTER; q.K = 2 * INTER; q.ldw = 2 * INTER;
+      q.relu = 1; q.drop_site = X.drop_on ? SITE_AV_FUSE : -1;
+      q.end_layer = 1; q.nout = INTER; q.stash = reinterpret_cast<bf16_t*>(L.y_a2); q.ld_stash = INTER;
+      q.gamma = X.V(P_AVF_G); q.beta = X.V(P_AVF_BT); q.xln = reinterpret_cast<bf16_t*>(L.av); q.out32 = a->audiovisual_features;
+      q.mean = L.mean_a2; q.rstd = L.rstd_a2;
+      c.seg[k++] = q;
+    }
+    {   // F6: audiovisual_projection -> token 0 (fusion.py:321, 325)
+      ChainSeg q;
+      chain_seg_defaults(q);
+      q.W = reinterpret_cast<const bf16_t*>(X.W(P_AVP_W)); q.bias = X.V(P_AVP_B); q.N = FUS; q.K = INTER; q.ldw = INTER;
+      q.end_layer = 1; q.nout = FUS; q.stash = reinterpret_cast<bf16_t*>(L.xtok); q.ld_stash = 2 * FUS;
+      c.seg[k++] = q;
+    }
+    c.nseg = k;
+    TRY(launch_chain(c, s));
   } else {
-    TRY(launch_ln_fwd(L.y_a2, L.av, a->audiovisual_features, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), X.V(P_AVF_BT), B, INTER, f32, s));
-    TRY(X.run1(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1)));
+    // F2: value projection of the shared AV cross-attention on [video_proj; audio_proj] (fusion.py:244-255;
+    //     L = S = 1 so q/k are dead), attention-weight dropout = one decision per (row, head)
+    {
+      GemmProblem p = X.fwd(L.avin, f32, INTER, P_AIN_W, P_AIN_B, L.avv, INTER, 2 * B, 0, SITE_AV_ATTN);
+      p.B = X.W(P_AIN_W) + (size_t)2 * INTER * INTER * es;   // rows [2E, 3E) of the packed [q;k;v] matrix
+      p.bias = X.V(P_AIN_B) + 2 * INTER;
+      p.N = INTER;
+      p.drop_shift = 5;  // 32 columns = one head
+      TRY(X.run1(p));
+    }
+    // F3: out_proj, batched over the two calls; batch z writes columns [256 z, 256 z + 256) of cat (fusion.py:262)
+    {
+      GemmProblem p = X.fwd(L.avv, f32, INTER, P_AOUT_W, P_AOUT_B, L.cat, 2 * INTER, B, 0, -1);
+      p.batch = 2; p.sA = (long long)B * INTER; p.sC = INTER;
+      TRY(X.run1(p));
+    }
+    // F4-F5: fusion_layers = Linear -> ReLU -> Dropout -> LayerNorm (fusion.py:263)
+    TRY(X.run1(X.fwd(L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, L.y_a2, INTER, B, 1, SITE_AV_FUSE)));
+    // F5-F6: LayerNorm + audiovisual_projection -> token 0 (fusion.py:263, 321, 325)
+    if (lnf) {
+      TRY(ln_gemm(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1), L.y_a2, P_AVF_G, P_AVF_BT, L.av, a->audiovisual_features,
+                  L.mean_a2, L.rstd_a2));
+    } else {
+      TRY(launch_ln_fwd(L.y_a2, L.av, a->audiovisual_features, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), X.V(P_AVF_BT), B, INTER, f32, s));
+      TRY(X.run1(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1)));
+    }
   }
   // F7: packed q|k|v in_proj of the 2-token self-attention (fusion.py:328)
   //     + F8: 2x2 softmax attention, token-pooled context.  bf16: ONE kernel, q|k|v stay in its accumulators
@@ -547,7 +594,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   }
   // F9-F17 are local to a sample (Linear / ReLU / Dropout / LayerNorm): in bf16 mode ONE launch walks the chain with the rows
   // resident in LDS (chain.hip) and writes the same workspace buffers; option "chain" = 0 restores the separate launches
-  if (!f32 && opt(OPT_CHAIN)) {
+  if (chains) {
     ChainArgs c{};
     c.X = reinterpret_cast<const bf16_t*>(L.obar); c.ldx = FUS; c.K0 = FUS; c.B = B; c.groups = 1; c.group_stride = 0;
     c.drop = X.dc;
