@@ -506,7 +506,9 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     g.drop = X.dc;
     return launch_gemm_ln(g, Y, X.V(pidG), X.V(pidBt), xln, out32, mean, rstd, s);
   };
-  const bool chains = !f32 && opt(OPT_CHAIN);
+  // one workgroup per 16 samples, each streaming all weights of its chain: worth it while the chip holds all of them at once
+  // (B = 4096: -12 us per step; B = 8192 in two rounds: +9 us, measured)
+  const bool chains = !f32 && opt(OPT_CHAIN) && B <= 4096;
   // F2-F6 are local to a sample (the AV "attention" has one key per query: softmax == 1, only the value and output projections
   // remain): in bf16 mode ONE launch walks them with the rows resident in LDS (chain.hip).  A workgroup holds the video and the
   // audio row of its 16 samples as two row groups; torch.cat of the two attention outputs is a re-view of the panel.

@@ -4,26 +4,38 @@
 // LayerNorm act on one row (reference fusion.py:98-103, 216-221, 301-306; deer.py:215-221, 49-55).  As separate launches
 // each of them is a 5-7 us GEMM of 2-4 GFLOP whose time is the fixed cost of a dependent launch plus one fill / drain of
 // the chip (the small GEMMs are bound by LDS-DMA issue, not by MFMA), and each writes its rows to HBM only for
-// the next launch to read them back.  Here a workgroup owns MS = 16 or 32 samples and walks the whole chain: the input
-// rows are DMA-copied into an LDS panel once, every layer multiplies the resident panel by its weight matrix -- streamed
-// through a ring of 16-KiB LDS slots by `global_load_lds`, NST - 1 stages ahead, ACROSS tile and layer boundaries, so the
-// weight stream never drains -- and writes bias / ReLU / dropout'ed bf16 rows into the second panel, which is then the
-// input of the next layer.  A finished panel is also copied to the workspace buffer the separate launches wrote (the
-// backward pass and the teacher-forced tests read the same buffers), and a LayerNorm runs on it in place.
+// the next launch to read them back.  Here a workgroup owns 16 samples and walks the whole chain: the input rows are
+// DMA-copied into an LDS panel once, every layer multiplies the resident panel by its weight matrix -- streamed through a
+// ring of six 16-KiB LDS slots by `global_load_lds`, five stages ahead, ACROSS tile and layer boundaries, so the weight
+// stream never drains -- and writes bias / ReLU / dropout'ed bf16 rows into the second panel, which is then the input of
+// the next layer.  A finished panel is also copied to the workspace buffer the separate launches wrote (the backward pass
+// and the teacher-forced tests read the same buffers), and a LayerNorm runs on it in place.
 //
 // Layout.  A panel holds `rows` x 64-column images, image = rows x 128 B, 16-byte chunk c of row r at chunk slot
 // c ^ (r & 7) (the bank-conflict-free layout of gemm_glds.hip).  A weight stage is 16 KiB = sixteen 1-KiB DMA pieces,
 // two per wave: 128 output columns x 64 k (N % 128 == 0) or 64 output columns x 128 k (the three 128 -> 64 heads).
 // MFMA roles: A = weights, B = activations, so a lane ends up with four consecutive output columns of one sample row --
-// one 8-byte LDS write into the next panel.  Accumulation order over k is that of the stand-alone GEMM kernels: the
-// chain reproduces their outputs bit for bit.
+// one 8-byte LDS write into the next panel.  A wave's activation fragments (all K of the 16 or 32 rows) are read from the
+// panel once per segment and stay in registers.  Accumulation order over k is that of the stand-alone GEMM kernels: the
+// chain reproduces their outputs bit for bit (tests/test_gpu_model.py).
 //
-// vmcnt bookkeeping: every wave issues exactly two DMA instructions per stage and the stream runs four stages ahead of
-// the one being multiplied, so "stages j and j+1 have landed" is a counted `s_waitcnt vmcnt(4)` (two stages are consumed
-// per barrier; `vmcnt(6)` for a lone stage); global stores issued in between (stash copies, LayerNorm outputs) only make
-// the count conservative (loads and stores retire in order on gfx9).  Past the last stage the stream wraps around to the first
-// segment, so the count is the same at every stage of the chain and the tail needs no special case.  All bias / gamma /
-// beta vectors are staged into LDS once at kernel start: a tracked global load in the steady state would make the compiler drain the ring with vmcnt(0).
+// vmcnt bookkeeping: every wave issues exactly two DMA instructions per stage and the stream runs five stages ahead, so
+// "stage j has landed" is a counted `s_waitcnt vmcnt(8)`; global stores issued in between (stash copies, LayerNorm outputs)
+// only make the count conservative (loads and stores retire in order on gfx9).  Past the last stage the stream wraps around
+// to the first segment, so the count is the same at every stage of the chain and the tail needs no special case.  All bias /
+// gamma / beta vectors and the segment tables are staged into LDS once at kernel start: a tracked global load in the steady
+// state would make the compiler drain the ring with vmcnt(0).
+//
+// What bounds it (cycle stamps of workgroup 0, tools/chain_stamps.py; B = 4096, 256 workgroups): the weight stream.  Every
+// workgroup streams ALL weights of the chain (2.2 MB for F9..F17) for its 16 rows; with 80 KiB in flight per CU against
+// ~1500 cycles of L2 latency (256 workgroups ask for the same lines) a 16-KiB stage lands every ~350 cycles (45 B/clk/CU).
+// Measured dead ends: (1) re-reading the activation fragments from LDS at every stage made the loop LDS-bandwidth-bound
+// (48 KiB of LDS traffic per stage, 475 cycles); (2) two stages per barrier leave only four stages in flight: slower than
+// one stage per barrier with five; (3) reading the segment tables from the kernarg segment with scalar loads cost ~1000
+// cycles per record; (4) weights straight from global memory into registers in the MFMA layout (no ring, no barrier in the
+// stage loop, 128 KiB in flight) ran at 22 B/clk/CU -- a 16-lane x 64-byte request pattern instead of the DMA's full lines --
+// and was 30 us slower per step.  One workgroup per 16 rows also means the launch only pays while the chip holds all
+// workgroups at once: api.hip uses the chains for B <= 4096 and the separate launches above.
 #include <type_traits>
 #include "gemm_kernel.inc"
 #include "chain.h"
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
   };
   p_load();
 #pragma unroll
-  for (int t = 0; t < NST - 2; ++t) issue(t);
+  for (int t = 0; t < NST - 1; ++t) issue(t);
 
   // ---- every bias / gamma / beta of the chain into LDS, by DMA as well (vector e is wave e % 8's job)
   for (int e = wave; e < nvec; e += 8) {
@@ -337,36 +349,17 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
         for (int c = 0; c < NCH; ++c) fw[c] = *reinterpret_cast<const u32x4*>(sw + (c >> 1) * 8192 + ((c & 1) ? swz1 : swz0));
       };
 #pragma unroll
-      for (int kt = 0; kt + 2 <= NKT; kt += 2) {
-        ch_wait_vm<4>();                            // this wave's pieces of both stages have landed: two younger stages in flight
-        __builtin_amdgcn_s_barrier();               // ... for every wave; and the two slots refilled below have been read by everyone
-        u32x4 fw0[NCH], fw1[NCH];
-        if (active) { wfrag(fw0, slot); wfrag(fw1, wrap(slot + 1)); }
-        issue(wrap(slot + 4));
+      for (int kt = 0; kt < NKT; ++kt) {
+        ch_wait_vm<8>();                            // this wave's pieces of the stage have landed: four younger stages in flight
+        __builtin_amdgcn_s_barrier();               // ... for every wave; and the slot refilled below has been read by everyone
+        u32x4 fw0[NCH];
+        if (active) wfrag(fw0, slot);
         issue(wrap(slot + 5));
         if (active) {
 #pragma unroll
           for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(fw0[c], afr[kt * NCH + c][i], acc[i]);
-#pragma unroll
-          for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(fw1[c], afr[(kt + 1) * NCH + c][i], acc[i]);
-        }
-        slot = wrap(slot + 2);
-      }
-      if constexpr (NKT & 1) {
-        ch_wait_vm<6>();                            // a lone stage: three younger stages in flight
-        __builtin_amdgcn_s_barrier();
-        u32x4 fw0[NCH];
-        if (active) wfrag(fw0, slot);
-        issue(wrap(slot + 4));
-        if (active) {
-#pragma unroll
-          for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(fw0[c], afr[(NKT - 1) * NCH + c][i], acc[i]);
         }
         slot = wrap(slot + 1);
       }
