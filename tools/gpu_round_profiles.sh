@@ -16,5 +16,14 @@ timeout -k 10 200 python tools/fwd_only.py > $OUT/fwd_only.txt 2> /dev/null; ech
 python tools/step_trace.py $OUT/prof/*/*_kernel_trace.csv 3 > $OUT/step_trace.txt 2>&1; echo "step trace rc=$?"
 bash tools/gpu_pmc_fused.sh > $OUT/pmc.log 2>&1; echo "pmc rc=$?"
 cp gpurun_out/pmc_fused_summary.txt gpurun_out/pmc_traffic.json $OUT/ 2>/dev/null
+bash tools/gpu_pmc_step.sh > $OUT/pmc_step.log 2>&1; echo "pmc step rc=$?"
+cp gpurun_out/pmc_step_summary.txt $OUT/ 2>/dev/null
 timeout -k 10 200 python tools/tf_stamps.py > $OUT/tf_stamps.txt 2>&1; echo "stamps rc=$?"
+timeout -k 10 200 python tools/chain_stamps.py 4096 > $OUT/chain_stamps.txt 2>&1; echo "chain stamps rc=$?"
+timeout -k 10 120 tools/probes/calibrate > $OUT/calibration.txt 2>&1; echo "calibration rc=$?"
+timeout -k 10 300 python tools/stackb_fused_time.py > $OUT/stackb_train.txt 2>&1; echo "stack B training rc=$?"
+# data-parallel rehearsal on the one GPU (1-rank group, the collective really runs): single in-graph exchange vs overlapped plan
+MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_dp1_single.json 2> /dev/null; echo "dp single rc=$?"
+MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_dp1_overlap.json 2> /dev/null; echo "dp overlap rc=$?"
+MMDEER_CHAIN=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_nochain.json 2> /dev/null; echo "bench without chains rc=$?"
 ls -la $OUT
