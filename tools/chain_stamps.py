@@ -1,7 +1,7 @@
 """Cycle-counter samples of workgroup 0 of the layer-chain kernel (chain.hip) from the diagnostic library
 libmmdeer_stamps.so (python -c "from mmdeer import build; build.build_stamps()"; the product library carries no stamp):
 where the time of the chain goes -- prologue, every column tile, every layer end.
-usage: python tools/chain_stamps.py [batch]"""
+usage: python tools/chain_stamps.py [batch] [bwd]     (bwd: the backward chain, stamps of mmdeer_backward(phase = 1))"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,16 +22,20 @@ a, v, t, y = (torch.from_numpy(b[k]).to(dev) for k in ("audio", "video", "text",
 for _ in range(3):
     m.train_step(a, v, t, y)
 torch.cuda.synchronize()
+bwd = len(sys.argv) > 2 and sys.argv[2] == "bwd"
 o = m._launch_forward(a, v, t, y, want_features=False)
+if bwd:
+    meta = o["_meta"]
+    m._launch_backward(meta, meta["targets"], loss_out=torch.empty(20, device=dev), flat=torch.zeros_like(m.flat_grad()), want_views=False, phase=1)
 torch.cuda.synchronize()
 ws = m._workspace(B, torch.device(dev))
-off = lib.mmdeer_workspace_offset(B, 0, b"slab")
+off = lib.mmdeer_workspace_offset(B, 0, b"davin" if bwd else b"slab")
 raw = ws.view(torch.uint8)[off:off + 8 * 128].cpu().numpy().view(np.uint64).astype(np.int64)
 t0 = raw[0]
-print("stamp  cycles-from-start  delta   (3+4t: tile t decoded, 4+4t: stages done, 5+4t: epilogue done, 6+4t: layer end done)")
+print("stamp  cycles-from-start  delta   (1: tables in LDS, 2: prologue done; 3+3s: segment s decoded, 4+3s: its tiles done, 5+3s: its layer end done)")
 prev = t0
-for i, x in enumerate(raw[:96]):
-    if x == 0:
+for i, x in enumerate(raw[:128]):
+    if x == 0 or abs(int(x) - int(t0)) > 10**9:
         continue
     print(f"{i:3d} {x - t0:10d} {x - prev:8d}")
     prev = x

@@ -154,7 +154,7 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
 struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
 OptEntry g_opts[OPT_COUNT] = {
     {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
-    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"splitk_max", 8, {8}},
+    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"splitk_max", 8, {8}},
 };
 }  // namespace
 
@@ -748,6 +748,48 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // B1: last head layer + NIG activations (+ loss gradient)
   TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->targets ? a->global_stats : nullptr, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
                      L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
+  // B2-B10 are local to a sample like the forward's layers: in bf16 mode (B <= 4096, no outside gradient on fused_features)
+  // ONE launch of the layer-chain kernel walks the head's four dX products, both LayerNorm backwards and the three trimodal dX
+  // products with the rows resident in LDS, and writes the same workspace buffers (the weight-gradient launch reads them)
+  const bool bchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B <= 4096 && !a->g_fused;
+  if (bchain) {
+    ChainArgs c{};
+    c.X = reinterpret_cast<const bf16_t*>(L.dz2); c.ldx = 3 * EV2; c.K0 = 3 * EV2; c.B = B; c.groups = 1; c.group_stride = 0;
+    c.drop = X.dc;
+    auto dxseg = [&](int pidW, int N, int K, void* stash, const void* ymask, int ldmask) {
+      ChainSeg q;
+      chain_seg_defaults(q);
+      q.W = reinterpret_cast<const bf16_t*>(X.WT(pidW)); q.N = N; q.K = K; q.ldw = K;
+      q.end_layer = 1; q.nout = N; q.stash = reinterpret_cast<bf16_t*>(stash); q.ld_stash = N;
+      q.mask_y = reinterpret_cast<const bf16_t*>(ymask); q.ld_mask = ldmask; q.mask_scale = X.mask_scale;
+      return q;
+    };
+    auto with_lnb = [&](ChainSeg q, int pidG, const void* y, const float* mean, const float* rstd, void* dz, float* part) {
+      q.lnb_gamma = X.V(pidG); q.lnb_y = reinterpret_cast<const bf16_t*>(y); q.lnb_mean = mean; q.lnb_rstd = rstd;
+      q.lnb_dz = reinterpret_cast<bf16_t*>(dz); q.lnb_partial = part; q.lnb_mask_scale = X.mask_scale;
+      return q;
+    };
+    int k = 0;
+    for (int z = 0; z < 3; ++z) {     // evidence_net layer 3 (128 -> 64) per head: W^T [128][64], dX masked by e1
+      ChainSeg q = dxseg(P_EV1_W, EV1, EV2, nullptr, L.e1, 3 * EV1);
+      q.W += (size_t)z * EV2 * EV1;
+      q.kin_off = z * EV2; q.nout_off = z * EV1; q.mask_col0 = z * EV1;
+      q.end_layer = z == 2; q.nout = 3 * EV1;
+      if (z == 2) { q.stash = reinterpret_cast<bf16_t*>(L.de1); q.ld_stash = 3 * EV1; }
+      c.seg[k++] = q;
+    }
+    c.seg[k++] = dxseg(P_EV0_W, HID, 3 * EV1, L.dh2, L.h2, HID);          // evidence_net layer 0: W^T of the stacked heads [256][384]
+    c.seg[k++] = dxseg(P_FP1_W, HID, HID, L.dh1, L.h1, HID);              // feature_processor
+    c.seg[k++] = with_lnb(dxseg(P_FP0_W, FUS, HID, L.dfused, nullptr, 0), P_OP_G, L.y_o1, L.mean_o1, L.rstd_o1, L.dz_o1, L.part_ln_o1);
+    c.seg[k++] = with_lnb(dxseg(P_OP_W, FUS, FUS, L.dtri, nullptr, 0), P_TFF_G, L.y_t3, L.mean_t3, L.rstd_t3, L.dz_t3, L.part_ln_t3);
+    c.seg[k++] = dxseg(P_TFF_W, FUS, FUS, L.dpool, nullptr, 0);
+    c.seg[k++] = dxseg(P_TOUT_W, FUS, FUS, L.dobar, nullptr, 0);         // attention out_proj (pooled context)
+    c.nseg = k;
+#ifdef MMDEER_STAMPS
+    c.stamps = reinterpret_cast<unsigned long long*>(L.davin);   // diagnostic library: untouched until phase 2 (tools/chain_stamps.py bwd)
+#endif
+    TRY(launch_chain(c, s));
+  } else
   {
     // evidence_net layer 3 (128 -> 64), batched over heads: dX masked by e1
     {
@@ -781,11 +823,13 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   TRY(flush(0, false));
 
   // ================= bucket 1: output_projection + trimodal fusion =================
-  TRY(launch_ln_bwd(L.dfused, L.y_o1, L.mean_o1, L.rstd_o1, X.V(P_OP_G), L.dz_o1, L.part_ln_o1, B, FUS, f32, X.mask_scale, s));
-  TRY(X.run1(X.dx(L.dz_o1, FUS, P_OP_W, L.dtri, FUS, B, nullptr, 0)));
-  TRY(launch_ln_bwd(L.dtri, L.y_t3, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), L.dz_t3, L.part_ln_t3, B, FUS, f32, X.mask_scale, s));
-  TRY(X.run1(X.dx(L.dz_t3, FUS, P_TFF_W, L.dpool, FUS, B, nullptr, 0)));
-  TRY(X.run1(X.dx(L.dpool, FUS, P_TOUT_W, L.dobar, FUS, B, nullptr, 0)));      // attention out_proj (pooled context)
+  if (!bchain) {
+    TRY(launch_ln_bwd(L.dfused, L.y_o1, L.mean_o1, L.rstd_o1, X.V(P_OP_G), L.dz_o1, L.part_ln_o1, B, FUS, f32, X.mask_scale, s));
+    TRY(X.run1(X.dx(L.dz_o1, FUS, P_OP_W, L.dtri, FUS, B, nullptr, 0)));
+    TRY(launch_ln_bwd(L.dtri, L.y_t3, L.mean_t3, L.rstd_t3, X.V(P_TFF_G), L.dz_t3, L.part_ln_t3, B, FUS, f32, X.mask_scale, s));
+    TRY(X.run1(X.dx(L.dz_t3, FUS, P_TFF_W, L.dpool, FUS, B, nullptr, 0)));
+    TRY(X.run1(X.dx(L.dpool, FUS, P_TOUT_W, L.dobar, FUS, B, nullptr, 0)));      // attention out_proj (pooled context)
+  }
   if (!f32 && env_fused_attn() && env_qkv_recompute())    // the forward kept q|k|v on chip: recompute the head tiles
     TRY(launch_tri_fused_bwd(L.xtok, L.wqkv_hm, X.V(P_TIN_B), L.dobar, L.probs, L.dqkv, B, X.drop_on ? 1 : 0, X.dc, s));
   else

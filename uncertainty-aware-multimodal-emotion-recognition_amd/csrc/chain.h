@@ -33,6 +33,18 @@ struct ChainSeg {
   int relu, drop_site, drop_shift, end_layer;
   int mblocks;             // 16-row blocks of the input panel this segment multiplies (0: all of them)
   int fold_groups;         // 1: rows of group z land in rows of group 0, columns + z * N (torch.cat of the two AV calls)
+  // backward chains (dX = dY W through the packed W^T copies):
+  const bf16_t* mask_y;    // epilogue: out *= (Y > 0) * mask_scale with Y = mask_y[row][mask_col0 + n] (ReLU + dropout of the
+  int ld_mask, mask_col0;  //   forward layer below), or null
+  float mask_scale;
+  // end_layer, instead of gamma / xln: LayerNorm BACKWARD of the finished panel (= d out of the LayerNorm) in place
+  const float* lnb_gamma;  // non-null selects it
+  const bf16_t* lnb_y;     // the forward's pre-LayerNorm rows [row][nout]
+  const float* lnb_mean;
+  const float* lnb_rstd;
+  bf16_t* lnb_dz;          // result rows [row][nout] (also the next layer's input panel)
+  float* lnb_partial;      // [workgroup][2][nout] column sums of d * xhat and d (folded by reduce_partials)
+  float lnb_mask_scale;    // > 0: the (y > 0) * scale mask of the Linear-ReLU-Dropout in front of the LayerNorm
 };
 
 // Host-side description of a chain (api.hip fills it; launch_chain() validates it and derives the kernel's tables).

@@ -36,6 +36,14 @@
 // stage loop, 128 KiB in flight) ran at 22 B/clk/CU -- a 16-lane x 64-byte request pattern instead of the DMA's full lines --
 // and was 30 us slower per step.  One workgroup per 16 rows also means the launch only pays while the chip holds all
 // workgroups at once: api.hip uses the chains for B <= 4096 and the separate launches above.
+//
+// Backward chains (dX = dY W through the packed W^T copies) use the same kernel: a segment's epilogue can multiply by the
+// (Y > 0) * scale mask of the forward layer below (four mask values per lane, requested by an untracked asm load before the
+// tile's stages and waited for by count), and a layer can end in a LayerNorm BACKWARD of the finished panel (chain_ln_bwd:
+// the forward's rows and statistics requested before the segment's stages; gamma / beta partial sums per workgroup in a
+// fixed order).  An LDS atomic in that reduction made the compiler insert vmcnt(0) -- it cannot tell the atomic from the
+// LDS-DMA targets -- which drained the ring and waited for every write-through store: 13k cycles per LayerNorm; plain
+// ordered LDS operations of one wave do the same sum.
 #include <type_traits>
 #include "gemm_kernel.inc"
 #include "chain.h"
@@ -72,19 +80,23 @@ struct ChainSegK {           // one GEMM segment = ntiles column tiles of `nkt` 
   int N;
   int vec_off, dcol_off, nout_off, site;
   int shift, relu, fold, mblocks;
-  int rows_out, kin_off, pad0, pad1;
-  int pad2[4];
+  int rows_out, kin_off;
+  float mask_scale; int has_bias;
+  const bf16_t* mask_y;      // backward chains: (Y > 0) * mask_scale epilogue mask, or null
+  int ld_mask, mask_col0;
 };
-struct ChainEndK {           // what happens to a finished panel; 64 bytes
-  bf16_t* stash; bf16_t* xln; float* out32; float* mean; float* rstd;
+struct ChainEndK {           // what happens to a finished panel; 80 bytes
+  bf16_t* stash; bf16_t* xln; float* out32; float* mean; float* rstd;   // has_ln == 2 (LayerNorm backward): xln = dz, out32 = partial
   int ld_stash, nout, gb_off, has_ln;
-  int pad[2];
+  const bf16_t* lnb_y;       // LayerNorm backward: the forward's pre-LayerNorm rows
+  float lnb_mask_scale; int pad;
+  int pad2[2];
 };
 struct ChainVecK {           // one bias / gamma / beta vector to stage into LDS; 16 bytes
   const float* src;
   int off, n4;               // LDS float offset, 16-byte chunks
 };
-static_assert(sizeof(ChainSegK) == 96 && sizeof(ChainEndK) == 64 && sizeof(ChainVecK) == 16, "table record sizes");
+static_assert(sizeof(ChainSegK) == 96 && sizeof(ChainEndK) == 80 && sizeof(ChainVecK) == 16, "table record sizes");
 
 struct ChainKArgs {
   const bf16_t* X;
@@ -179,6 +191,98 @@ __device__ __forceinline__ void chain_ln(unsigned char* pan, int img, int r, boo
     }
   }
   if (valid && l32 == 0) { o_.mean[grow] = mu; o_.rstd[grow] = rs; }
+}
+
+struct ChainLnbIn {
+  u32x4 y[2];            // this lane's chunks of the forward's pre-LayerNorm row (requested at the start of the segment)
+  float mu, rs;
+};
+
+// LayerNorm BACKWARD of a finished 16-row panel in place (ln_bwd_kernel of rowops.hip restated on the panel): d = panel,
+// xhat = (y - mean) rstd, g = d gamma, dy = (g - mean(g) - xhat mean(g xhat)) rstd, masked by (y > 0) * scale when the
+// LayerNorm sits behind Linear-ReLU-Dropout; dz replaces d in the panel and goes to the workspace.  The column sums of
+// d xhat and d over the workgroup's rows (gamma / beta gradients) are formed deterministically: each wave adds its two rows
+// in LDS (lower half writes, upper half reads and adds -- one wave's LDS operations execute in order), the workgroup's eight waves are
+// summed column by column in a fixed order.  `red` = 16 KiB of LDS (the idle input panel).
+template <int NKT>
+__device__ __forceinline__ void chain_ln_bwd(unsigned char* pan, int img, float* red, int wave, int lane, int tid, int r, bool valid,
+                                             long long grow, const float* gam, const ChainLnbIn& in, float ms, bf16_t* dz,
+                                             float* slab) {
+#pragma clang fp contract(off)
+  constexpr int KD = NKT * 64, NC = NKT / 4;
+  constexpr float inv_k = 1.0f / (float)KD;
+  const int l32 = lane & 31;
+  float d[NC * 8], xh[NC * 8], gd[NC * 8], yy[NC * 8];
+  unsigned char* cell[NC];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int c = l32 + 32 * j;
+    cell[j] = pan + (c >> 3) * img + r * 128 + (((c & 7) ^ (r & 7)) * 16);
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(cell[j]);
+    const u32x4 yr = in.y[j];
+    const unsigned dw[4] = {raw.x, raw.y, raw.z, raw.w}, yw[4] = {yr.x, yr.y, yr.z, yr.w};
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam + 8 * c), g1 = *reinterpret_cast<const f32x4*>(gam + 8 * c + 4);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d[8 * j + 2 * e] = __uint_as_float(dw[e] << 16); d[8 * j + 2 * e + 1] = __uint_as_float(dw[e] & 0xFFFF0000u);
+      yy[8 * j + 2 * e] = __uint_as_float(yw[e] << 16); yy[8 * j + 2 * e + 1] = __uint_as_float(yw[e] & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xh[8 * j + e] = (yy[8 * j + e] - in.mu) * in.rs;
+      gd[8 * j + e] = d[8 * j + e] * gg[e];
+      s1 += gd[8 * j + e];
+      s2 += gd[8 * j + e] * xh[8 * j + e];
+    }
+  }
+  const float m1 = half_sum(s1, lane) * inv_k, m2 = half_sum(s2, lane) * inv_k;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int c = l32 + 32 * j;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dy = (gd[8 * j + e] - m1 - xh[8 * j + e] * m2) * in.rs;
+      o[e] = ms > 0.f ? (yy[8 * j + e] > 0.f ? dy * ms : 0.f) : dy;
+    }
+    const u32x4 packed{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(cell[j]) = packed;
+    if (valid) store_wt16(dz + grow * KD + c * 8, packed);
+  }
+  // ---- gamma / beta partial sums over the workgroup's rows (rows past the batch contribute nothing)
+  const float live = valid ? 1.f : 0.f;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float* mine = red + wave * KD;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int c = l32 + 32 * j;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (pass == 0 ? d[8 * j + e] * xh[8 * j + e] : d[8 * j + e]) * live;
+      // lower half writes its row's values, upper half adds its own on top: plain LDS operations of ONE wave execute in order
+      // (an LDS atomic here made the compiler wait for vmcnt(0) -- the weight ring and every write-through store -- 13k cycles)
+      f32x4* dst = reinterpret_cast<f32x4*>(mine + 8 * c);
+      if (lane < 32) { dst[0] = f32x4{v[0], v[1], v[2], v[3]}; dst[1] = f32x4{v[4], v[5], v[6], v[7]}; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane >= 32) {
+        const f32x4 a0 = dst[0], a1 = dst[1];
+        dst[0] = f32x4{a0.x + v[0], a0.y + v[1], a0.z + v[2], a0.w + v[3]};
+        dst[1] = f32x4{a1.x + v[4], a1.y + v[5], a1.z + v[6], a1.w + v[7]};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int col = tid; col < KD; col += 512) {
+      const float t = ((red[col] + red[KD + col]) + (red[2 * KD + col] + red[3 * KD + col])) +
+                      ((red[4 * KD + col] + red[5 * KD + col]) + (red[6 * KD + col] + red[7 * KD + col]));
+      slab[pass * KD + col] = t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 }
 
 __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
@@ -315,7 +419,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
   const int swz0 = (lg ^ (li & 7)) * 16, swz1 = ((4 + lg) ^ (li & 7)) * 16;
   auto wrap = [](int s_) -> int { return s_ >= NST ? s_ - NST : s_; };
 
-  struct SegCtl { int N, ntiles, vec_off, dcol_off, nout_off, site, shift, relu, fold, kin_off, rows_out; };
+  struct SegCtl { int N, ntiles, vec_off, dcol_off, nout_off, site, shift, relu, fold, kin_off, rows_out, has_bias, ld_mask, mask_col0; float mask_scale; const bf16_t* mask_y; };
 
   // One segment.  The activation fragments of its 16 (or 32) rows stay in REGISTERS for all its column tiles: re-read from the
   // panel at every stage they were half of the LDS traffic of the stage loop, and the loop is LDS-bandwidth-bound (8 waves x
@@ -343,6 +447,20 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       f32x4 acc[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // backward chains: this lane's four mask values per row block, requested before the tile's stages (an asm load the compiler
+      // does not track: the counted wait in front of the epilogue names its registers)
+      u32x2 mk[MB];
+      const bf16_t* mask_y = sg.mask_y;
+      if (mask_y && active) {
+        const int n0m = sg.mask_col0 + (KB ? nt * 64 : nt * 128) + 16 * wave + 4 * lg;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const int r = 16 * i + li;
+          const long long gr = valid_of(r) ? grow_of(r) : (long long)(r >> LOG_MS) * gstride;
+          const bf16_t* q = mask_y + gr * sg.ld_mask + n0m;
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(mk[i]) : "v"(q) : "memory");
+        }
+      }
       auto wfrag = [&](u32x4 (&fw)[NCH], int sl) __attribute__((always_inline)) {
         const unsigned char* sw = lds + RING + sl * SLOT + (16 * wave + li) * 128;
 #pragma unroll
@@ -366,9 +484,13 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       // ---- bias, ReLU, dropout, bf16 -> output panel
       if (active) {
         const int n0 = (KB ? nt * 64 : nt * 128) + 16 * wave + 4 * lg;
-        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(vec + sg.vec_off + n0);
+        const f32x4 bias4 = sg.has_bias ? *reinterpret_cast<const f32x4*>(vec + sg.vec_off + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned dcol = (unsigned)(sg.dcol_off + n0);
         const int colb = sg.nout_off + n0;
+        if (mask_y) {      // the mask loads are older than this tile's 2 NKT weight DMAs (at most 10 of them still in flight)
+          if constexpr (MB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(mk[0]) : "n"(2 * NKT < 10 ? 2 * NKT : 10) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(mk[0]), "+v"(mk[1]) : "n"(2 * NKT < 10 ? 2 * NKT : 10) : "memory");
+        }
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
           const int r = 16 * i + li;
@@ -385,6 +507,12 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
               const float f = mix32(rk ^ ((dcol >> shift) * 0x85EBCA77u)) < dthresh ? dscale : 0.f;
               v.x *= f; v.y *= f; v.z *= f; v.w *= f;
             }
+          }
+          if (mask_y) {
+            const float ms = sg.mask_scale;
+            const unsigned m0 = mk[i].x, m1 = mk[i].y;
+            v.x = __uint_as_float(m0 << 16) > 0.f ? v.x * ms : 0.f; v.y = __uint_as_float(m0 & 0xFFFF0000u) > 0.f ? v.y * ms : 0.f;
+            v.z = __uint_as_float(m1 << 16) > 0.f ? v.z * ms : 0.f; v.w = __uint_as_float(m1 & 0xFFFF0000u) > 0.f ? v.w * ms : 0.f;
           }
           int col = colb, orow = r;
           if (fold) { col += (r >> LOG_MS) * N; orow = r & (MS - 1); }
@@ -405,6 +533,35 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
     sg.shift = sc(q3.x); sg.relu = sc(q3.y); sg.fold = sc(q3.z);
     const int mb = sc(q3.w);
     sg.rows_out = sc(q4.x); sg.kin_off = sc(q4.y);
+    sg.mask_scale = __uint_as_float((unsigned)sc(q4.z)); sg.has_bias = sc(q4.w);
+    {
+      const u32x4 q5 = rec[5];
+      sg.mask_y = reinterpret_cast<const bf16_t*>(sp(q5.x, q5.y)); sg.ld_mask = sc(q5.z); sg.mask_col0 = sc(q5.w);
+    }
+    // a layer that ends in a LayerNorm backward: this lane's chunks of the forward's rows and the row statistics are requested
+    // now, before the segment's weight stages (>= 5 of them: 10 younger DMAs), and waited for with vmcnt(10) at the layer end
+    ChainLnbIn lnb;
+    lnb.y[0] = lnb.y[1] = u32x4{0u, 0u, 0u, 0u}; lnb.mu = 0.f; lnb.rs = 0.f;
+    int end_mode = 0;
+    if (endi >= 0) {
+      const u32x4* er = reinterpret_cast<const u32x4*>(tab + END0 + endi * (int)sizeof(ChainEndK));
+      const u32x4 e1 = er[1], e2 = er[2], e3 = er[3], e4 = er[4];
+      end_mode = sc(e3.y);
+      if (end_mode == 2) {
+        const bf16_t* ly = reinterpret_cast<const bf16_t*>(sp(e3.z, e3.w));
+        const float* lmean = reinterpret_cast<const float*>(sp(e1.z, e1.w));
+        const float* lrstd = reinterpret_cast<const float*>(sp(e2.x, e2.y));
+        const int nout = sc(e2.w);
+        const int r = 2 * wave + (lane >> 5);
+        const long long gr = valid_of(r) ? grow_of(r) : 0;
+        const bf16_t* q = ly + gr * nout + (lane & 31) * 8;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lnb.y[0]) : "v"(q) : "memory");
+        if (nout == 512) asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(lnb.y[1]) : "v"(q) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lnb.mu) : "v"(lmean + gr) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lnb.rs) : "v"(lrstd + gr) : "memory");
+        (void)e4;
+      }
+    }
     stamp(3 + 3 * si);
 #define CH_SEG(MBv, KBv, NKTv) seg_body(std::integral_constant<int, MBv>{}, std::integral_constant<bool, KBv>{}, std::integral_constant<int, NKTv>{}, sg)
     if (!kb) {
@@ -429,7 +586,31 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       bf16_t* stash = reinterpret_cast<bf16_t*>(sp(e0.x, e0.y));
       const int ld_stash = sc(e2.z), nout = sc(e2.w);
       const int gb_off = sc(e3.x), has_ln = sc(e3.y);
-      if (has_ln) {
+      if (has_ln == 2) {
+        stamp(100);
+        asm volatile("s_waitcnt vmcnt(10)" : "+v"(lnb.y[0]), "+v"(lnb.y[1]), "+v"(lnb.mu), "+v"(lnb.rs) : : "memory");
+        stamp(101);
+        const u32x4 e4 = er[4];
+        const float lms = __uint_as_float((unsigned)sc(e4.x));
+        bf16_t* dz = reinterpret_cast<bf16_t*>(sp(e0.z, e0.w));
+        float* slab = reinterpret_cast<float*>(sp(e1.x, e1.y)) + (long long)blockIdx.x * 2 * nout;
+        const int r = 2 * wave + (lane >> 5);
+        if (stash) {       // the raw panel (d out of the LayerNorm) first: the teacher-forced tests and g_fused callers read it
+          const int nch = nout >> 3;
+          for (int rr = wave; rr < rows_out; rr += 8) {
+            if (!valid_of(rr)) continue;
+            for (int cc = lane; cc < nch; cc += 64)
+              store_wt16(stash + grow_of(rr) * ld_stash + cc * 8,
+                         *reinterpret_cast<const u32x4*>(pout + (cc >> 3) * img_out + rr * 128 + (((cc & 7) ^ (rr & 7)) * 16)));
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        stamp(102);
+        if (nout == 512) chain_ln_bwd<8>(pout, img_out, reinterpret_cast<float*>(pin), wave, lane, tid, r, valid_of(r), grow_of(r), vec + gb_off, lnb, lms, dz, slab);
+        else chain_ln_bwd<4>(pout, img_out, reinterpret_cast<float*>(pin), wave, lane, tid, r, valid_of(r), grow_of(r), vec + gb_off, lnb, lms, dz, slab);
+        stamp(103);
+      } else if (has_ln) {
         ChainLnOut o;
         o.stash = stash; o.xln = reinterpret_cast<bf16_t*>(sp(e0.z, e0.w)); o.out32 = reinterpret_cast<float*>(sp(e1.x, e1.y));
         o.mean = reinterpret_cast<float*>(sp(e1.z, e1.w)); o.rstd = reinterpret_cast<float*>(sp(e2.x, e2.y));
@@ -489,7 +670,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     const int mblocks = s.mblocks ? s.mblocks : blocks_in;
     MMDEER_CHECK(mblocks <= blocks_in && mblocks <= 2, "chain: segment %d m-blocks", i);
     MMDEER_CHECK(nvec + 3 <= CHAIN_MAX_VECS, "chain: too many bias / gamma / beta vectors");
-    const int vec_off = add_vec(s.bias, s.N);
+    const int vec_off = s.bias ? add_vec(s.bias, s.N) : 0;
     const int kb = s.N % 128 != 0, ntl = kb ? s.N / 64 : s.N / 128, nkt = kb ? s.K / 128 : s.K / 64;
     MMDEER_CHECK(ntl <= 4, "chain: segment %d has too many column tiles", i);
     MMDEER_CHECK(kb ? (nkt <= 2 && mblocks * nkt <= 2) : ((nkt == 1 || nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8) && mblocks * nkt <= 8),
@@ -499,6 +680,9 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     td.N = s.N; td.vec_off = vec_off; td.dcol_off = s.dcol_off; td.nout_off = s.nout_off;
     td.site = s.drop_site; td.shift = s.drop_shift; td.relu = s.relu; td.fold = s.fold_groups;
     td.mblocks = mblocks; td.kin_off = s.kin_off;
+    td.has_bias = s.bias != nullptr;
+    td.mask_y = s.mask_y; td.ld_mask = s.ld_mask; td.mask_col0 = s.mask_col0; td.mask_scale = s.mask_scale;
+    MMDEER_CHECK(!s.mask_y || (((uintptr_t)s.mask_y % 8) == 0 && s.ld_mask % 4 == 0 && s.mask_col0 % 4 == 0), "chain: segment %d mask alignment", i);
     if (s.end_layer) {
       const int blocks_out = s.fold_groups ? blocks_in / 2 : blocks_in;
       MMDEER_CHECK(!s.fold_groups || blocks_in == 2, "chain: segment %d folds the groups of a single-group panel", i);
@@ -507,7 +691,18 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
       MMDEER_CHECK(nend < CHAIN_MAX_ENDS, "chain: too many layers");
       ChainEndK& e = k.end[nend];
       e.stash = s.stash; e.ld_stash = s.ld_stash; e.nout = s.nout;
-      if (s.gamma) {
+      if (s.lnb_gamma) {
+        MMDEER_CHECK(!s.gamma && (s.nout == 256 || s.nout == 512) && blocks_out == 1, "chain: LayerNorm backward of segment %d: width %d, one row group", i, s.nout);
+        MMDEER_CHECK(s.lnb_y && s.lnb_mean && s.lnb_rstd && s.lnb_dz && s.lnb_partial && ((uintptr_t)s.lnb_gamma % 16) == 0 &&
+                         ((uintptr_t)s.lnb_y % 16) == 0 && ((uintptr_t)s.lnb_dz % 16) == 0 && ((uintptr_t)s.lnb_partial % 16) == 0,
+                     "chain: LayerNorm backward of segment %d: pointers / alignment", i);
+        int stages = 0;   // the layer's last segment must issue >= 5 stages behind the prefetch of the forward's rows
+        stages = ntl * nkt;
+        MMDEER_CHECK(stages >= 5, "chain: LayerNorm backward behind a segment of %d stages", stages);
+        e.has_ln = 2; e.xln = s.lnb_dz; e.out32 = s.lnb_partial; e.mean = const_cast<float*>(s.lnb_mean); e.rstd = const_cast<float*>(s.lnb_rstd);
+        e.lnb_y = s.lnb_y; e.lnb_mask_scale = s.lnb_mask_scale;
+        e.gb_off = add_vec(s.lnb_gamma, s.nout);
+      } else if (s.gamma) {
         MMDEER_CHECK(s.nout == 256 || s.nout == 512, "chain: LayerNorm width %d", s.nout);
         MMDEER_CHECK(s.beta && s.xln && s.mean && s.rstd && ((uintptr_t)s.gamma % 16) == 0 && ((uintptr_t)s.beta % 16) == 0 &&
                          ((uintptr_t)s.xln % 16) == 0 && (!s.out32 || ((uintptr_t)s.out32 % 16) == 0),
