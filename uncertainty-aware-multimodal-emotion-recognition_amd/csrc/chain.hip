@@ -19,8 +19,8 @@
 // panel once per segment and stay in registers.  Accumulation order over k is that of the stand-alone GEMM kernels: the
 // chain reproduces their outputs bit for bit (tests/test_gpu_model.py).
 //
-// vmcnt bookkeeping: every wave issues exactly two DMA instructions per stage and the stream runs five stages ahead, so
-// "stage j has landed" is a counted `s_waitcnt vmcnt(8)`; global stores issued in between (stash copies, LayerNorm outputs)
+// vmcnt bookkeeping: every wave issues exactly two DMA instructions per stage and the stream runs NST - 1 stages ahead, so
+// "stage j has landed" is a counted `s_waitcnt vmcnt(2 (NST - 2))`; global stores issued in between (stash copies, LayerNorm outputs)
 // only make the count conservative (loads and stores retire in order on gfx9).  Past the last stage the stream wraps around
 // to the first segment, so the count is the same at every stage of the chain and the tail needs no special case.  All bias /
 // gamma / beta vectors and the segment tables are staged into LDS once at kernel start: a tracked global load in the steady
@@ -285,11 +285,14 @@ __device__ __forceinline__ void chain_ln_bwd(unsigned char* pan, int img, float*
   }
 }
 
+// NST ring slots of 16 KiB (NST - 1 stages in flight), VECF floats of bias / gamma / beta.  Instantiated as <6, 4864>; a
+// seven-slot ring for the chains with few vectors (<7, 2560>, 156 KiB of LDS) was 4-5 us per step SLOWER on the same box.
+template <int NST, int VECF>
 __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
-  constexpr int MS = 16, LOG_MS = 4, NST = 6;
+  constexpr int MS = 16, LOG_MS = 4, FLY = 2 * (NST - 1);   // FLY: weight DMAs of one wave in flight
   constexpr int PAN = MS * 1024;           // 16 rows x 512 columns (or 32 x 256) of bf16
   constexpr int SLOT = 16384;
-  constexpr int RING = 2 * PAN, VEC = RING + NST * SLOT, TAB = VEC + CHAIN_VEC_FLOATS * 4;
+  constexpr int RING = 2 * PAN, VEC = RING + NST * SLOT, TAB = VEC + VECF * 4;
   constexpr int SEG_BYTES = (int)sizeof(ChainSegK);
   constexpr int END0 = CHAIN_MAX_SEGS * SEG_BYTES, VEC0 = END0 + CHAIN_MAX_ENDS * (int)sizeof(ChainEndK);
   constexpr int TAB_BYTES = VEC0 + CHAIN_MAX_VECS * (int)sizeof(ChainVecK);
@@ -468,11 +471,11 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       };
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
-        ch_wait_vm<8>();                            // this wave's pieces of the stage have landed: four younger stages in flight
+        ch_wait_vm<FLY - 2>();                      // this wave's pieces of the stage have landed: NST - 2 younger stages in flight
         __builtin_amdgcn_s_barrier();               // ... for every wave; and the slot refilled below has been read by everyone
         u32x4 fw0[NCH];
         if (active) wfrag(fw0, slot);
-        issue(wrap(slot + 5));
+        issue(wrap(slot + NST - 1));
         if (active) {
 #pragma unroll
           for (int c = 0; c < NCH; ++c)
@@ -488,8 +491,8 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
         const unsigned dcol = (unsigned)(sg.dcol_off + n0);
         const int colb = sg.nout_off + n0;
         if (mask_y) {      // the mask loads are older than this tile's 2 NKT weight DMAs (at most 10 of them still in flight)
-          if constexpr (MB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(mk[0]) : "n"(2 * NKT < 10 ? 2 * NKT : 10) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(mk[0]), "+v"(mk[1]) : "n"(2 * NKT < 10 ? 2 * NKT : 10) : "memory");
+          if constexpr (MB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(mk[0]) : "n"(2 * NKT < FLY ? 2 * NKT : FLY) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(mk[0]), "+v"(mk[1]) : "n"(2 * NKT < FLY ? 2 * NKT : FLY) : "memory");
         }
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       sg.mask_y = reinterpret_cast<const bf16_t*>(sp(q5.x, q5.y)); sg.ld_mask = sc(q5.z); sg.mask_col0 = sc(q5.w);
     }
     // a layer that ends in a LayerNorm backward: this lane's chunks of the forward's rows and the row statistics are requested
-    // now, before the segment's weight stages (>= 5 of them: 10 younger DMAs), and waited for with vmcnt(10) at the layer end
+    // now, before the segment's weight stages (>= NST - 1 of them: FLY younger DMAs), and waited for with vmcnt(FLY) at the layer end
     ChainLnbIn lnb;
     lnb.y[0] = lnb.y[1] = u32x4{0u, 0u, 0u, 0u}; lnb.mu = 0.f; lnb.rs = 0.f;
     int end_mode = 0;
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       const int gb_off = sc(e3.x), has_ln = sc(e3.y);
       if (has_ln == 2) {
         stamp(100);
-        asm volatile("s_waitcnt vmcnt(10)" : "+v"(lnb.y[0]), "+v"(lnb.y[1]), "+v"(lnb.mu), "+v"(lnb.rs) : : "memory");
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(lnb.y[0]), "+v"(lnb.y[1]), "+v"(lnb.mu), "+v"(lnb.rs) : "n"(FLY) : "memory");
         stamp(101);
         const u32x4 e4 = er[4];
         const float lms = __uint_as_float((unsigned)sc(e4.x));
@@ -698,7 +701,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
                      "chain: LayerNorm backward of segment %d: pointers / alignment", i);
         int stages = 0;   // the layer's last segment must issue >= 5 stages behind the prefetch of the forward's rows
         stages = ntl * nkt;
-        MMDEER_CHECK(stages >= 5, "chain: LayerNorm backward behind a segment of %d stages", stages);
+        MMDEER_CHECK(stages >= 6, "chain: LayerNorm backward behind a segment of %d stages", stages);
         e.has_ln = 2; e.xln = s.lnb_dz; e.out32 = s.lnb_partial; e.mean = const_cast<float*>(s.lnb_mean); e.rstd = const_cast<float*>(s.lnb_rstd);
         e.lnb_y = s.lnb_y; e.lnb_mask_scale = s.lnb_mask_scale;
         e.gb_off = add_vec(s.lnb_gamma, s.nout);
@@ -720,7 +723,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   MMDEER_CHECK(a.seg[a.nseg - 1].end_layer, "chain: the last segment must end its layer");
   MMDEER_CHECK(vec <= CHAIN_VEC_FLOATS, "chain: %d bias / gamma / beta floats exceed the LDS area (%d)", vec, CHAIN_VEC_FLOATS);
   k.nseg = a.nseg; k.nvec = nvec;
-  hipLaunchKernelGGL(chain_kernel, dim3((a.B + 15) / 16), dim3(512), 0, stream, k);
+  hipLaunchKernelGGL((chain_kernel<6, CHAIN_VEC_FLOATS>), dim3((a.B + 15) / 16), dim3(512), 0, stream, k);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
