@@ -21,6 +21,7 @@ enum OptId {
   OPT_LN_FUSED,         // 1: every LayerNorm of the forward runs inside the GEMM that consumes it (gemm_ln.hip, bf16 mode)
   OPT_CHAIN,            // 1: the row-local layer chains of the forward run as single launches (chain.hip, bf16 mode)
   OPT_CHAIN_BWD,        // 1 (with chain = 1): the head / trimodal dX products and LayerNorm backwards of the backward pass as one chain launch
+  OPT_CHAIN_MIN,        // smallest batch that takes the chains (default 2049; the backward chain from 2561; tests lower it)
   OPT_SPLITK_MAX,       // largest number of split-K slices of a weight-gradient problem (slabs: 4 B per parameter per slice)
   OPT_COUNT
 };
