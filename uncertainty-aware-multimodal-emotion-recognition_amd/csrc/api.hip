@@ -154,7 +154,7 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
 struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
 OptEntry g_opts[OPT_COUNT] = {
     {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
-    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"chain_min", 2049, {2049}}, {"splitk_max", 8, {8}},
+    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"chain_min", 2049, {2049}}, {"dw_tile", 2, {2}}, {"splitk_max", 8, {8}},
 };
 }  // namespace
 
@@ -177,7 +177,9 @@ namespace {
 // traffic, 4 B per parameter per slice written and read back, is what limits the slice count; fp32 8.
 int ksteps_target(int f32) {
   const int v = opt(OPT_KSTEPS);
-  return v > 0 ? v : (f32 ? 8 : 16);
+  if (v > 0) return v;
+  if (!f32 && opt(OPT_DW_TILE) == 4) return 32;   // 256x128: two K-slices at 4096 rows
+  return f32 ? 8 : 16;
 }
 // option "fused_attn" = 0: the unfused pair (in_proj GEMM writing q|k|v + one-wave-per-sample attention kernels) also in
 // bf16 mode.  Default 1: tri_fused.hip.  "qkv_recompute" = 0 (with the fused forward): the forward also stores q|k|v and
@@ -191,7 +193,7 @@ int forced_tile() { return opt(OPT_TILE); }
 // (declared in gemm.h: the Stack B executor in stackb.hip uses the same policy)
 GemmTile pick_tile(const GemmGroup& g) {
   const int ft = forced_tile();
-  if (ft >= 0 && ft <= 3) return (GemmTile)ft;
+  if (ft >= 0 && ft <= 4) return (GemmTile)ft;
   static const int bm[3] = {64, 128, 128}, bn[3] = {64, 64, 128};
   long long tiles[3];
   for (int t = 0; t < 3; ++t) {
@@ -203,7 +205,7 @@ GemmTile pick_tile(const GemmGroup& g) {
   }
   // weight-gradient groups (both operands transposed): the strided loads and the packing LDS store cost the same per
   // K-tile whatever the tile size, so the largest tile wins; split-K supplies the parallelism
-  if (g.p[0].trans_a) return TILE_256x256;   // (falls back to 128x128 per sub-group where the kernel does not apply)
+  if (g.p[0].trans_a) return (GemmTile)opt(OPT_DW_TILE);   // 256x256 (falls back to 128x128 per sub-group where the kernel does not apply)
   // bf16: 128x64 and 64x64 run on the LDS-DMA kernel, 128x128 only on the register-staged one (measured on the
   // trimodal in_proj, 768 tiles of 128x128: 28.5 us against 17 us as 1536 tiles of 128x64)
   const bool f32 = g.p[0].a_f32 && g.p[0].b_f32;
@@ -282,7 +284,11 @@ struct Exec {
   // (re)derive the split-K fields from p.K and the final destinations p.C / p.bias_grad
   void set_split(GemmProblem& p, float* grads) const {
     const int nk = gemm_ktiles(p.K, f32);
-    const int kst = ksteps_target(f32);
+    int kst = ksteps_target(f32);
+    // 128x128 weight-gradient tiles (option dw_tile = 2, the default): K-slices of B rows -- the B-row problems run their whole
+    // reduction in one workgroup (no slab, nothing to fold), the 2B-row ones (trimodal in_proj, the stacked AV calls) get two
+    // slices as long as the others' one.  Measured against other slice lengths at B = 512 ... 16384.
+    if (!f32 && opt(OPT_DW_TILE) == 2 && opt(OPT_KSTEPS) == 0) { kst = B / 64; kst = kst < 4 ? 4 : kst > 128 ? 128 : kst; }
     int sk = (nk + kst - 1) / kst;
     const int cap = opt(OPT_SPLITK_MAX) < SPLITK_MAX ? opt(OPT_SPLITK_MAX) : SPLITK_MAX;
     if (sk > cap) sk = cap;

@@ -55,7 +55,7 @@ struct GemmGroup {
   GemmProblem p[GEMM_MAX_PROBLEMS];
 };
 
-enum GemmTile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3 };   // 256x256: bf16 weight gradients only
+enum GemmTile { TILE_64x64 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x256 = 3, TILE_256x128 = 4 };   // 256x256: bf16 LDS-DMA kernels only; 256x128: bf16 weight gradients only
 
 // compute_f32 = 1: fp32 operands in LDS, v_mfma_f32_16x16x4_f32 (exact fp32); 0: bf16 operands, v_mfma_f32_16x16x32_bf16.
 // Enqueues on `stream`, never synchronises.  Returns 0 / -1 (message via mmdeer_last_error()).

@@ -12,6 +12,8 @@ int gemm_dispatch_nx(const GemmGroup& g, int total, int compute_f32, GemmTile ti
 int gemm_dispatch_tt(const GemmGroup& g, int total, int compute_f32, GemmTile tile, int am, int bm, hipStream_t s);
 int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStream_t s);
 int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s);
+int gemm_dispatch_tt128(const GemmGroup& g, int total, hipStream_t s);
+int gemm_dispatch_tt256x128(const GemmGroup& g, int total, hipStream_t s);
 int gemm_dispatch_nt256(const GemmGroup& g, int total, int bn, hipStream_t s);
 
 namespace {
@@ -34,13 +36,16 @@ void gemm_problem_defaults(GemmProblem& p) {
 }
 
 int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStream_t stream) {
-  static const int bm_of[4] = {64, 128, 128, 256}, bn_of[4] = {64, 64, 128, 256};
+  static const int bm_of[5] = {64, 128, 128, 256, 256}, bn_of[5] = {64, 64, 128, 256, 128};
   MMDEER_CHECK(g.nprob >= 1 && g.nprob <= GEMM_MAX_PROBLEMS, "gemm: bad problem count %d", g.nprob);
-  MMDEER_CHECK((int)tile_req >= 0 && (int)tile_req <= 3, "gemm: bad tile id %d", (int)tile_req);
+  MMDEER_CHECK((int)tile_req >= 0 && (int)tile_req <= 4, "gemm: bad tile id %d", (int)tile_req);
   g.xcd_remap = env_xcd();
   const int ta = g.p[0].trans_a ? 1 : 0, tb = g.p[0].trans_b ? 1 : 0;
   // the whole group can run on the 256x256 weight-gradient kernel (it alone tolerates padded, half-valid row ends)
-  bool pad256 = tile_req == TILE_256x256 && ta && tb && !compute_f32 && env_glds();
+  // the weight-gradient DMA kernel on 128x128 / 256x128 tiles (option dw_tile)
+  const bool dw128 = tile_req == TILE_128x128 && ta && tb && !compute_f32 && env_glds() && opt(OPT_DW_TILE) == 2;
+  const bool dw256x128 = tile_req == TILE_256x128 && ta && tb && !compute_f32 && env_glds();
+  bool pad256 = (tile_req == TILE_256x256 || dw128 || dw256x128) && ta && tb && !compute_f32 && env_glds();
   for (int i = 0; i < g.nprob && pad256; ++i) {
     const GemmProblem& q = g.p[i];
     pad256 = !q.a_f32 && !q.b_f32 && q.K % 32 == 0 && q.c_f32 && !q.bias && !q.relu && !q.Y && q.drop_site < 0 && q.regen_site < 0 &&
@@ -102,7 +107,7 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
       sub.p[sub.nprob++] = g.p[j];
     }
     // 256x256 tiles exist only as the LDS-DMA weight-gradient kernel; anything else of such a group runs 128x128
-    bool tt256 = tile_req == TILE_256x256 && ta && tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 &&
+    bool tt256 = (tile_req == TILE_256x256 || dw128 || dw256x128) && ta && tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 &&
                  env_glds();
     for (int j = 0; j < sub.nprob && tt256; ++j) {
       const GemmProblem& q = sub.p[j];
@@ -118,7 +123,8 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
               q.ldc % 8 == 0 &&
               (!q.bias || ((uintptr_t)q.bias % 16 == 0 && q.sBias % 4 == 0));
     }
-    GemmTile tile = (tt256 || nt256) ? TILE_256x256 : (tile_req == TILE_256x256 ? (ta ? TILE_128x128 : TILE_128x64) : tile_req);
+    GemmTile tile = (tt256 && dw128) ? TILE_128x128 : (tt256 && dw256x128) ? TILE_256x128 : (tt256 || nt256) ? TILE_256x256 :
+                    ((tile_req == TILE_256x256 || tile_req == TILE_256x128) ? (ta ? TILE_128x128 : TILE_128x64) : tile_req);
     // LDS-DMA fast path: bf16 NT problems whose operands are 16-byte aligned, row-contiguous and K % 64 == 0
     bool glds_ok = !ta && !tb && !compute_f32 && am == SRC_BF16_V16 && bm == SRC_BF16_V16 && env_glds();
     for (int j = 0; j < sub.nprob && glds_ok; ++j)
@@ -164,7 +170,9 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
     int rc;
     // (other 128x128 launches keep the register-staged kernel: its 74 KiB of LDS allow two workgroups per CU)
     const bool glds = glds_ok && (tile != TILE_128x128 || glds128);
-    if (tt256) rc = gemm_dispatch_tt256(sub, total, stream);
+    if (tt256 && dw128) rc = gemm_dispatch_tt128(sub, total, stream);
+    else if (tt256 && dw256x128) rc = gemm_dispatch_tt256x128(sub, total, stream);
+    else if (tt256) rc = gemm_dispatch_tt256(sub, total, stream);
     else if (nt256) rc = gemm_dispatch_nt256(sub, total, BN, stream);
     else if (glds) rc = gemm_dispatch_nt_glds(sub, total, tile, stream);
     else if (!ta && !tb) rc = gemm_dispatch_nt(sub, total, compute_f32, tile, am, bm, stream);

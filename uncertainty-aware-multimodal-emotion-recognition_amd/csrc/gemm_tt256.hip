@@ -56,12 +56,22 @@ __device__ __forceinline__ void wait_lgkm(u32x2& a, u32x2& b, u32x2& c, u32x2& d
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
 }
 
-__global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
-  constexpr int BM = 256, BN = 256, KT = 32, NST = 5;
-  constexpr int TM = 4, TN = 8;                 // 16x16 accumulators per wave: 64 x 128
-  constexpr int ROWB = 512;                     // bytes per image row
-  constexpr int OPER = KT * ROWB, STAGE = 2 * OPER;
-  constexpr int LPT = 4;                        // DMA instructions per wave per stage
+// BM x BN = 256 x 256 (the kernel described above), 128 x 128 or 256 x 128: the same schedule on smaller tiles.  128 x 128: a wave owns 32 x 64 (2 x 4 accumulators),
+// image rows are 256 B (a 1-KiB DMA piece = 4 rows, two pieces per wave per stage), 80 KiB of ring.  The small tile exists to
+// run weight gradients WITHOUT split-K: ~175 full-K tiles fill the chip, no partial slabs are written and re-read.
+// 256 x 128 is the compromise: a wave owns 64 x 64 (4 x 4 accumulators), the K loop moves as few LDS bytes per MAC as the 256 x 256
+// tile's does (it is LDS-bandwidth-bound on the small tile: 64 KiB of LDS traffic per 16-KiB stage), and ~110 tiles need only
+// two K-slices to fill the chip.
+template <int BM, int BN>
+__global__ __launch_bounds__(512) void gemm_tt_dma_kernel(const GemmGroup g) {
+  constexpr int KT = 32;
+  constexpr int TM = BM / 64, TN = BN / 32;     // 16x16 accumulators per wave: 4 waves along M, 2 along N
+  constexpr int ROWA = 2 * BM, ROWB = 2 * BN;   // bytes per image row of the two operands
+  constexpr int OPER = KT * ROWA, STAGE = KT * (ROWA + ROWB);   // OPER: offset of the B image inside a stage
+  constexpr int NST = BM == 256 && BN == 128 ? 6 : 5;   // ring slots: 160 / 144 / 80 KiB (ten slots on the 128 x 128 tile changed nothing: its loop is LDS-bandwidth-bound)
+  constexpr int LPRA = ROWA / 16, RPPA = 64 / LPRA, PPWA = KT / RPPA / 8;   // lanes per image row, rows per 1-KiB DMA piece,
+  constexpr int LPRB = ROWB / 16, RPPB = 64 / LPRB, PPWB = KT / RPPB / 8;   //   pieces per wave per stage
+  constexpr int LPT = PPWA + PPWB;              // DMA instructions per wave per stage
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -102,25 +112,26 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
   // ---- DMA source pointers.  Piece 8j + wave of an operand image = rows 2(8j + wave) + (lane >> 5); lane l writes
   //      slot (l & 31), so it fetches logical chunk (l & 31) ^ f(row).  f does not depend on j.  A chunk beyond the
   //      operand's width reads column 0 instead (it only feeds outputs that are never stored).
-  const int rsub = lane >> 5;
-  const int fsw = (((wave >> 2) & 1) << 3) | ((((wave & 1) << 1) | rsub) << 1);
-  const int chunk = (lane & 31) ^ fsw;
+  const int r0a = RPPA * wave + lane / LPRA;    // image row of this lane's first piece (piece j: + 8 RPP j rows; f is the same)
+  const int r0b = RPPB * wave + lane / LPRB;
+  const int chunk_a = (lane & (LPRA - 1)) ^ ((((r0a >> 3) & 1) << 3) | ((r0a & 3) << 1));
+  const int chunk_b = (lane & (LPRB - 1)) ^ ((((r0b >> 3) & 1) << 3) | ((r0b & 3) << 1));
   const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (long long)z * p.sA;
   const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B) + (long long)z * p.sB;
   const long long lda = p.lda, ldb = p.ldb;
-  const long long krow = (long long)kt0 * KT + 2 * wave + rsub;
-  const int ca = row0 + chunk * 8, cb = col0 + chunk * 8;
-  const bf16_t* pa = Ab + krow * lda + (ca < M ? ca : 0);
-  const bf16_t* pb = Bb + krow * ldb + (cb < N ? cb : 0);
+  const long long krow_a = (long long)kt0 * KT + r0a, krow_b = (long long)kt0 * KT + r0b;
+  const int ca = row0 + chunk_a * 8, cb = col0 + chunk_b * 8;
+  const bf16_t* pa = Ab + krow_a * lda + (ca < M ? ca : 0);
+  const bf16_t* pb = Bb + krow_b * ldb + (cb < N ? cb : 0);
   auto issue = [&](int stage) __attribute__((always_inline)) {
     unsigned char* sa = lds + stage * STAGE + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + 16 * j * lda),
+    for (int j = 0; j < PPWA; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + 8 * RPPA * j * lda),
                                        (__attribute__((address_space(3))) void*)(sa + j * 8192), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + 16 * j * ldb),
+    for (int j = 0; j < PPWB; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + 8 * RPPB * j * ldb),
                                        (__attribute__((address_space(3))) void*)(sa + OPER + j * 8192), 16, 0, 0);
     pa += KT * lda;
     pb += KT * ldb;
@@ -144,13 +155,14 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
   //      Both rows share f, so one offset per fragment: logical chunk 2 c16 + (pp >> 1) -> slot 2 (c16 ^ h) + (pp >> 1).
   const int q = (lane & 15) >> 2, pp = lane & 3;
   const int h = ((lg & 1) << 2) | q;   // f(row) >> 1
-  const int lane_off = (8 * lg + q) * ROWB + (pp >> 1) * 16 + (pp & 1) * 8;
+  const int lane_off_a = (8 * lg + q) * ROWA + (pp >> 1) * 16 + (pp & 1) * 8;
+  const int lane_off_b = (8 * lg + q) * ROWB + (pp >> 1) * 16 + (pp & 1) * 8;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   unsigned offa[TM], offb[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) offa[i] = lds_base + lane_off + (((wm * 4 + i) ^ h) * 32);
+  for (int i = 0; i < TM; ++i) offa[i] = lds_base + lane_off_a + (((wm * TM + i) ^ h) * 32);
 #pragma unroll
-  for (int j = 0; j < TN; ++j) offb[j] = lds_base + lane_off + (((wn * 8 + j) ^ h) * 32) + OPER;
+  for (int j = 0; j < TN; ++j) offb[j] = lds_base + lane_off_b + (((wn * TN + j) ^ h) * 32) + OPER;
 
   // ---- ring (5 slots) + ping-pong, the schedule of tri_fused.hip.  A wave alternates
   //        L(t): DMA issue of tile t+4 | wait: fragments of tile t in registers, own pieces of tile t+2 landed | barrier
@@ -170,18 +182,25 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
     if (t < nk) issue(t);
-  {   // tiles 0 and 1 landed (those issued after them may be in flight)
-    const int younger = (nk < NST - 1 ? nk : NST - 1) - 2;
-    if (younger >= 2) wait_vm<2 * LPT>();
+  // wait until at most `younger` whole tiles of this wave's DMA pieces are in flight (0 <= younger <= NST - 3)
+  auto wait_tiles = [&](int younger) __attribute__((always_inline)) {
+    static_assert(NST - 3 <= 7, "cases below");
+    if (younger >= NST - 3) wait_vm<(NST - 3) * LPT>();
+    else if (younger == 6) wait_vm<6 * LPT>();
+    else if (younger == 5) wait_vm<5 * LPT>();
+    else if (younger == 4) wait_vm<4 * LPT>();
+    else if (younger == 3) wait_vm<3 * LPT>();
+    else if (younger == 2) wait_vm<2 * LPT>();
     else if (younger == 1) wait_vm<LPT>();
     else wait_vm<0>();
-  }
+  };
+  wait_tiles((nk < NST - 1 ? nk : NST - 1) - 2);   // tiles 0 and 1 landed (those issued after them may be in flight)
   __builtin_amdgcn_s_barrier();
   TSTAMP(1);
   u32x2 al0[TM], ah0[TM], bl0[TN], bh0[TN], al1[TM], ah1[TM], bl1[TN], bh1[TN];
   auto read_frags = [&](unsigned so, u32x2 (&al)[TM], u32x2 (&ah)[TM], u32x2 (&bl)[TN], u32x2 (&bh)[TN]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) { al[i] = lds_tr_read<0>(offa[i] + so); ah[i] = lds_tr_read<4 * ROWB>(offa[i] + so); }
+    for (int i = 0; i < TM; ++i) { al[i] = lds_tr_read<0>(offa[i] + so); ah[i] = lds_tr_read<4 * ROWA>(offa[i] + so); }
 #pragma unroll
     for (int j = 0; j < TN; ++j) { bl[j] = lds_tr_read<0>(offb[j] + so); bh[j] = lds_tr_read<4 * ROWB>(offb[j] + so); }
   };
@@ -189,16 +208,19 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
   if (second) __builtin_amdgcn_s_barrier();     // waves 4-7: one phase behind
   unsigned rd = STAGE;                          // byte offset of the slot the next M phase reads (tile kt + 1)
   int wr = NST - 1;                             // slot the next L phase fills (tile kt + 4)
+  // all fragment reads of a register set have landed, and no use of them can be scheduled above this point
+  auto retire = [&](u32x2 (&al)[TM], u32x2 (&ah)[TM], u32x2 (&bl)[TN], u32x2 (&bh)[TN]) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(al[i]), "+v"(ah[i]));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bl[j]), "+v"(bh[j]));
+  };
   auto phase_l = [&](int kt, u32x2 (&al)[TM], u32x2 (&ah)[TM], u32x2 (&bl)[TN], u32x2 (&bh)[TN]) __attribute__((always_inline)) {
     if (kt + NST - 1 < nk) { issue(wr); wr = wr + 1 == NST ? 0 : wr + 1; }
-    wait_lgkm<0>(al[0], ah[0], al[1], ah[1], al[2], ah[2], al[3], ah[3]);
-    wait_lgkm<0>(bl[0], bh[0], bl[1], bh[1], bl[2], bh[2], bl[3], bh[3]);
-    wait_lgkm<0>(bl[4], bh[4], bl[5], bh[5], bl[6], bh[6], bl[7], bh[7]);
+    retire(al, ah, bl, bh);
     // own pieces of tile kt+2 landed; the tiles issued after it (kt+3, kt+4, where they exist) may be in flight
-    int younger = (nk - 1 < kt + NST - 1 ? nk - 1 : kt + NST - 1) - (kt + 2);
-    if (younger >= 2) wait_vm<2 * LPT>();
-    else if (younger == 1) wait_vm<LPT>();
-    else wait_vm<0>();
+    wait_tiles((nk - 1 < kt + NST - 1 ? nk - 1 : kt + NST - 1) - (kt + 2));
     __builtin_amdgcn_s_barrier();
   };
   // M phase: MFMA column block j (4 MFMAs, all row blocks) behind three fragment reads of the next tile -- reads 3 j .. 3 j + 2
@@ -216,22 +238,28 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
     }
     auto nread = [&](auto rtag) __attribute__((always_inline)) {
       constexpr int R = decltype(rtag)::value;
-      if constexpr (R < 4) nal[R] = lds_tr_read<0>(offa[R] + so);
-      else if constexpr (R < 8) nah[R - 4] = lds_tr_read<4 * ROWB>(offa[R - 4] + so);
-      else if constexpr (R < 16) nbl[R - 8] = lds_tr_read<0>(offb[R - 8] + so);
-      else nbh[R - 16] = lds_tr_read<4 * ROWB>(offb[R - 16] + so);
+      if constexpr (R < TM) nal[R] = lds_tr_read<0>(offa[R] + so);
+      else if constexpr (R < 2 * TM) nah[R - TM] = lds_tr_read<4 * ROWA>(offa[R - TM] + so);
+      else if constexpr (R < 2 * TM + TN) nbl[R - 2 * TM] = lds_tr_read<0>(offb[R - 2 * TM] + so);
+      else nbh[R - 2 * TM - TN] = lds_tr_read<4 * ROWB>(offb[R - 2 * TM - TN] + so);
     };
+    constexpr int RPG = (2 * TM + 2 * TN) / TN;   // next-tile fragment reads in front of each column block's MFMAs
     auto group = [&](auto jtag) __attribute__((always_inline)) {
       constexpr int J = decltype(jtag)::value;
-      nread(std::integral_constant<int, 3 * J>{}); nread(std::integral_constant<int, 3 * J + 1>{}); nread(std::integral_constant<int, 3 * J + 2>{});
+      nread(std::integral_constant<int, RPG * J>{}); nread(std::integral_constant<int, RPG * J + 1>{}); nread(std::integral_constant<int, RPG * J + 2>{});
+      if constexpr (RPG == 4) nread(std::integral_constant<int, RPG * J + 3>{});
       const u32x4 fb{bl[J].x, bl[J].y, bh[J].x, bh[J].y};
 #pragma unroll
       for (int i = 0; i < TM; ++i) acc[i][J] = mma_chunk<bf16_t>(fb, fa[i], acc[i][J]);
       __builtin_amdgcn_sched_barrier(0);
     };
+    static_assert(RPG * TN == 2 * TM + 2 * TN && (RPG == 3 || RPG == 4), "RPG next-tile reads per column block cover all fragment reads");
     group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{});
-    group(std::integral_constant<int, 3>{}); group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
-    group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+    group(std::integral_constant<int, 3>{});
+    if constexpr (TN == 8) {
+      group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+      group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+    }
     rd = rd + STAGE == NST * STAGE ? 0 : rd + STAGE;
     if (!last) __builtin_amdgcn_s_barrier();
   };
@@ -246,13 +274,9 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
   if (kt < nk) {      // odd tile count: the last tile's fragments sit in set 0
     phase_l(kt, al0, ah0, bl0, bh0);
     phase_m(true, al0, ah0, bl0, bh0, al1, ah1, bl1, bh1);
-    wait_lgkm<0>(al1[0], ah1[0], al1[1], ah1[1], al1[2], ah1[2], al1[3], ah1[3]);
-    wait_lgkm<0>(bl1[0], bh1[0], bl1[1], bh1[1], bl1[2], bh1[2], bl1[3], bh1[3]);
-    wait_lgkm<0>(bl1[4], bh1[4], bl1[5], bh1[5], bl1[6], bh1[6], bl1[7], bh1[7]);
+    retire(al1, ah1, bl1, bh1);
   } else {            // the dummy reads of the last phase: dead values, but their registers must not be reused before they land
-    wait_lgkm<0>(al0[0], ah0[0], al0[1], ah0[1], al0[2], ah0[2], al0[3], ah0[3]);
-    wait_lgkm<0>(bl0[0], bh0[0], bl0[1], bh0[1], bl0[2], bh0[2], bl0[3], bh0[3]);
-    wait_lgkm<0>(bl0[4], bh0[4], bl0[5], bh0[5], bl0[6], bh0[6], bl0[7], bh0[7]);
+    retire(al0, ah0, bl0, bh0);
   }
   if (!second) __builtin_amdgcn_s_barrier();   // pairs with the extra barrier of waves 4-7
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
     float* bg = sliced ? p.slab_b + (long long)slice * p.slab_stride : p.bias_grad;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int r = row0 + wm * 64 + i * 16 + li;
+      const int r = row0 + wm * (16 * TM) + i * 16 + li;
       if (lg == 0 && r < M) bg[(long long)z * p.sBiasGrad + r] = bsum[i].x;
     }
   }
@@ -274,12 +298,12 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
   const bool accumulate = !sliced && p.accumulate;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = row0 + wm * 64 + i * 16 + li;
+    const int m = row0 + wm * (16 * TM) + i * 16 + li;
     if (m >= M) continue;
-    float* rowp = dst + (long long)m * ldc + col0 + wn * 128 + 4 * lg;
+    float* rowp = dst + (long long)m * ldc + col0 + wn * (16 * TN) + 4 * lg;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if (col0 + wn * 128 + j * 16 + 4 * lg >= N) continue;   // N % 4 == 0: a 4-column group is all in or all out
+      if (col0 + wn * (16 * TN) + j * 16 + 4 * lg >= N) continue;   // N % 4 == 0: a 4-column group is all in or all out
       f32x4 v = acc[i][j];
       f32x4* cp = reinterpret_cast<f32x4*>(rowp + j * 16);
       if (accumulate) v += *cp;
@@ -296,7 +320,19 @@ __global__ __launch_bounds__(512) void gemm_tt256_kernel(const GemmGroup g) {
 // caller guarantees: bf16 compute, trans_a = trans_b = 1, both operands bf16 with ld % 8 == 0 and 16-byte aligned,
 // K (the reduction = batch rows) % 32 == 0, fp32 C, no bias / ReLU / dropout / mask epilogue, tiles counted 256x256
 int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s) {
-  hipLaunchKernelGGL(gemm_tt256_kernel, dim3(total), dim3(512), 0, s, g);
+  hipLaunchKernelGGL((gemm_tt_dma_kernel<256, 256>), dim3(total), dim3(512), 0, s, g);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+// the same with tiles counted 128x128
+int gemm_dispatch_tt128(const GemmGroup& g, int total, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_tt_dma_kernel<128, 128>), dim3(total), dim3(512), 0, s, g);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+// ... 256x128
+int gemm_dispatch_tt256x128(const GemmGroup& g, int total, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_tt_dma_kernel<256, 128>), dim3(total), dim3(512), 0, s, g);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

@@ -22,6 +22,7 @@ enum OptId {
   OPT_CHAIN,            // 1: the row-local layer chains of the forward run as single launches (chain.hip, bf16 mode)
   OPT_CHAIN_BWD,        // 1 (with chain = 1): the head / trimodal dX products and LayerNorm backwards of the backward pass as one chain launch
   OPT_CHAIN_MIN,        // smallest batch that takes the chains (default 2049; the backward chain from 2561; tests lower it)
+  OPT_DW_TILE,          // GemmTile of the weight-gradient launch: 2 = 128x128 tiles without split-K (default), 3 = 256x256 + split-K slabs, 4 = 256x128
   OPT_SPLITK_MAX,       // largest number of split-K slices of a weight-gradient problem (slabs: 4 B per parameter per slice)
   OPT_COUNT
 };
