@@ -75,6 +75,11 @@ size_t mmdeer_weights_bytes(int compute_f32);
  *   fused_attn (1)     0: unfused in_proj GEMM + attention kernels also in bf16 mode
  *   qkv_recompute (1)  0: the fused forward stores q|k|v for the backward instead of recomputing the head tiles
  *   ln_fused (1)       0: the LayerNorms of the forward as stand-alone launches instead of inside the consuming GEMM (bf16)
+ *   chain (1)          0: every sample-local layer as its own launch; 1 (bf16, chain_min <= B <= 4096): the runs F2-F6 and F9-F17
+ *                      of the forward and, with chain_bwd (1), the head / trimodal dX run of the backward as one launch each
+ *   chain_min (2049)   smallest batch that takes the chains (the backward chain from 2561)
+ *   dw_tile (2)        weight-gradient launch: 2 = 128x128 tiles, K-slices of B rows (no split-K slabs for the B-row problems),
+ *                      3 = 256x256 tiles + split-K slabs, 4 = 256x128 tiles
  *   xcd, nt128, nt192, glds, nt8 (1), t128 (512), tile (-1), ksteps (0), splitk_max (8)   GEMM tile / split-K selection
  * mmdeer_set_option / mmdeer_get_option return -1 for an unknown name; mmdeer_option_name(i) enumerates (NULL past the end). */
 int mmdeer_set_option(const char* name, int value);
@@ -213,7 +218,7 @@ typedef struct mmdeer_gemm_args {
   const void* A; const void* W; void* C; const float* bias; float* bias_grad; const void* Y;
   int32_t M, N, K, lda, ldw, ldc, ldy;
   int32_t a_f32, w_f32, c_f32, y_f32, trans_a, trans_w, relu, accumulate;
-  int32_t compute_f32, tile;            /* tile: 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 256x256 (bf16 dW), -1 = auto */
+  int32_t compute_f32, tile;            /* tile: 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 256x256, 4 = 256x128 (bf16 dW), -1 = auto */
   int32_t drop_site, drop_shift, regen_site;
   float dropout_p, mask_scale;
   uint64_t seed, offset;

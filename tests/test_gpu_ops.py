@@ -116,7 +116,7 @@ def test_gemm_dx(compute_f32, tile, M, N, K):
 
 @pytest.mark.parametrize("compute_f32", [1, 0])
 @pytest.mark.parametrize("splitk", [1, 3, 8])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])     # bf16: 2 / 3 / 4 = the LDS-DMA kernel on 128x128 / 256x256 / 256x128 tiles
 @pytest.mark.parametrize("Bt,Nl,Kl", [(64, 128, 64), (100, 256, 84), (7, 64, 256), (513, 384, 256), (1100, 64, 128),
                                       (1024, 512, 768), (2048, 384, 256), (96, 64, 128), (4096, 520, 264)])
 def test_gemm_dw_and_bias_grad(compute_f32, splitk, tile, Bt, Nl, Kl):
@@ -136,7 +136,7 @@ def test_gemm_dw_and_bias_grad(compute_f32, splitk, tile, Bt, Nl, Kl):
     assert (dbias.double() - dY.double().sum(0)).abs().max().item() < tol * max(1.0, math.sqrt(Bt) / 4)
 
 
-@pytest.mark.parametrize("tile", [2, 3])
+@pytest.mark.parametrize("tile", [2, 3, 4])
 @pytest.mark.parametrize("splitk", [1, 4])
 def test_gemm_dw_padded_rows(tile, splitk):
     """dW against an activation block whose 84 valid columns sit in 128-element rows (the padded audio block):

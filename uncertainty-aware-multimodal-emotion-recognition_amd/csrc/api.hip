@@ -984,7 +984,7 @@ int mmdeer_gemm(const mmdeer_gemm_args* a) {
   }
   g.drop = make_drop(a->dropout_p, a->seed, a->offset, a->offset_dev);
   g.stamps = reinterpret_cast<unsigned long long*>(a->debug);
-  GemmTile t = (a->tile >= 0 && a->tile <= 3) ? (GemmTile)a->tile : pick_tile(g);
+  GemmTile t = (a->tile >= 0 && a->tile <= 4) ? (GemmTile)a->tile : pick_tile(g);
   TRY(launch_gemm_group(g, a->compute_f32 ? 1 : 0, t, (hipStream_t)a->stream));
   if (g.p[0].splitk > 1) {   // fold the K-slices into C (and bias_grad)
     ReduceTable rt{};
