@@ -154,7 +154,7 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
 struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
 OptEntry g_opts[OPT_COUNT] = {
     {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
-    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"chain_min", 2049, {2049}}, {"dw_tile", 2, {2}}, {"splitk_max", 8, {8}},
+    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"chain_min", 2049, {2049}}, {"dw_tile", 2, {2}}, {"dw_kg", 2, {2}}, {"splitk_max", 8, {8}},
 };
 }  // namespace
 

@@ -14,6 +14,7 @@ int gemm_dispatch_nt_glds(const GemmGroup& g, int total, GemmTile tile, hipStrea
 int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s);
 int gemm_dispatch_tt128(const GemmGroup& g, int total, hipStream_t s);
 int gemm_dispatch_tt256x128(const GemmGroup& g, int total, hipStream_t s);
+int gemm_dispatch_tt128k2(const GemmGroup& g, int total, hipStream_t s);
 int gemm_dispatch_nt256(const GemmGroup& g, int total, int bn, hipStream_t s);
 
 namespace {
@@ -170,7 +171,10 @@ int launch_gemm_group(GemmGroup& g, int compute_f32, GemmTile tile_req, hipStrea
     int rc;
     // (other 128x128 launches keep the register-staged kernel: its 74 KiB of LDS allow two workgroups per CU)
     const bool glds = glds_ok && (tile != TILE_128x128 || glds128);
-    if (tt256 && dw128) rc = gemm_dispatch_tt128(sub, total, stream);
+    bool k64 = opt(OPT_DW_KG) == 2;     // 128x128: the K-split form needs 64-row stages
+    for (int j = 0; j < sub.nprob && k64; ++j) k64 = sub.p[j].K % 64 == 0;
+    if (tt256 && dw128 && k64) rc = gemm_dispatch_tt128k2(sub, total, stream);
+    else if (tt256 && dw128) rc = gemm_dispatch_tt128(sub, total, stream);
     else if (tt256 && dw256x128) rc = gemm_dispatch_tt256x128(sub, total, stream);
     else if (tt256) rc = gemm_dispatch_tt256(sub, total, stream);
     else if (nt256) rc = gemm_dispatch_nt256(sub, total, BN, stream);

@@ -62,10 +62,15 @@ __device__ __forceinline__ void wait_lgkm(u32x2& a, u32x2& b, u32x2& c, u32x2& d
 // 256 x 128 is the compromise: a wave owns 64 x 64 (4 x 4 accumulators), the K loop moves as few LDS bytes per MAC as the 256 x 256
 // tile's does (it is LDS-bandwidth-bound on the small tile: 64 KiB of LDS traffic per 16-KiB stage), and ~110 tiles need only
 // two K-slices to fill the chip.
-template <int BM, int BN>
+// KG = 2 (128 x 128 only): a stage is 64 rows of K and the two halves of the workgroup split it -- waves 0-3 multiply its first
+// 32 rows, waves 4-7 the second 32, each wave a 64 x 64 sub-tile (2 x 2 waves) -- so a fragment is re-read by two waves
+// instead of four / two (48 KiB of LDS traffic per 32 rows of K instead of 64) and there is one barrier pair per 64 rows; the
+// halves' accumulators are added through LDS at the end.
+template <int BM, int BN, int KG = 1>
 __global__ __launch_bounds__(512) void gemm_tt_dma_kernel(const GemmGroup g) {
-  constexpr int KT = 32;
-  constexpr int TM = BM / 64, TN = BN / 32;     // 16x16 accumulators per wave: 4 waves along M, 2 along N
+  constexpr int KT = 32 * KG;
+  constexpr int WM = KG == 2 ? 2 : 4, WN = 2;   // waves along M / N (times KG along K)
+  constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);     // 16x16 accumulators per wave
   constexpr int ROWA = 2 * BM, ROWB = 2 * BN;   // bytes per image row of the two operands
   constexpr int OPER = KT * ROWA, STAGE = KT * (ROWA + ROWB);   // OPER: offset of the B image inside a stage
   constexpr int NST = BM == 256 && BN == 128 ? 6 : 5;   // ring slots: 160 / 144 / 80 KiB (ten slots on the 128 x 128 tile changed nothing: its loop is LDS-bandwidth-bound)
@@ -76,7 +81,8 @@ __global__ __launch_bounds__(512) void gemm_tt_dma_kernel(const GemmGroup g) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = KG == 2 ? wave >> 2 : 0;       // K half of the stage this wave multiplies
+  const int wm = (KG == 2 ? (wave & 3) : wave) >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
 
   int bid = blockIdx.x;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(512) void gemm_tt_dma_kernel(const GemmGroup g) {
   const int tmb = rem / p.tiles_n, tnb = rem - tmb * p.tiles_n;
   const int row0 = tmb * BM, col0 = tnb * BN;
   const int M = p.M, N = p.N;
-  const int nk_all = p.K >> 5;   // K % 32 == 0 (checked by the launcher)
+  const int nk_all = p.K / KT;   // K % KT == 0 (checked by the launcher)
   const int nk_per = (nk_all + p.splitk - 1) / p.splitk;
   const int kt0 = slice * nk_per;
   const int kt1 = (kt0 + nk_per < nk_all) ? kt0 + nk_per : nk_all;
@@ -155,8 +161,8 @@ __global__ __launch_bounds__(512) void gemm_tt_dma_kernel(const GemmGroup g) {
   //      Both rows share f, so one offset per fragment: logical chunk 2 c16 + (pp >> 1) -> slot 2 (c16 ^ h) + (pp >> 1).
   const int q = (lane & 15) >> 2, pp = lane & 3;
   const int h = ((lg & 1) << 2) | q;   // f(row) >> 1
-  const int lane_off_a = (8 * lg + q) * ROWA + (pp >> 1) * 16 + (pp & 1) * 8;
-  const int lane_off_b = (8 * lg + q) * ROWB + (pp >> 1) * 16 + (pp & 1) * 8;
+  const int lane_off_a = (32 * kg + 8 * lg + q) * ROWA + (pp >> 1) * 16 + (pp & 1) * 8;
+  const int lane_off_b = (32 * kg + 8 * lg + q) * ROWB + (pp >> 1) * 16 + (pp & 1) * 8;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   unsigned offa[TM], offb[TN];
 #pragma unroll
@@ -282,6 +288,27 @@ __global__ __launch_bounds__(512) void gemm_tt_dma_kernel(const GemmGroup g) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   TSTAMP(2);
 
+  if constexpr (KG == 2) {   // add the K halves: waves 4-7 hand their accumulators to waves 0-3 through the (now idle) ring
+    __builtin_amdgcn_s_barrier();                 // every wave has read its last fragments
+    f32x4* xch = reinterpret_cast<f32x4*>(lds) + ((wave & 3) * (TM * TN + TM)) * 64 + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) xch[(i * TN + j) * 64] = acc[i][j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xch[(TM * TN + i) * 64] = bsum[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += xch[(i * TN + j) * 64];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) bsum[i] += xch[(TM * TN + i) * 64];
+  }
   // ---- epilogue: accumulators straight to the fp32 destination.  acc[i][j] holds C[m][n..n+3] with m = the i-th
   //      16-row block + li, n = the j-th 16-column block + 4 lg: one 16-byte store per accumulator.
   const bool sliced = p.splitk > 1;
@@ -327,6 +354,12 @@ int gemm_dispatch_tt256(const GemmGroup& g, int total, hipStream_t s) {
 // the same with tiles counted 128x128
 int gemm_dispatch_tt128(const GemmGroup& g, int total, hipStream_t s) {
   hipLaunchKernelGGL((gemm_tt_dma_kernel<128, 128>), dim3(total), dim3(512), 0, s, g);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
+// ... 128x128 with the stage's 64 rows of K split between the two halves of the workgroup (every K % 64 == 0)
+int gemm_dispatch_tt128k2(const GemmGroup& g, int total, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_tt_dma_kernel<128, 128, 2>), dim3(total), dim3(512), 0, s, g);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
