@@ -26,12 +26,13 @@
 // gamma / beta vectors and the segment tables are staged into LDS once at kernel start: a tracked global load in the steady
 // state would make the compiler drain the ring with vmcnt(0).
 //
-// What bounds it (cycle stamps of workgroup 0, tools/chain_stamps.py; B = 4096, 256 workgroups): the weight stream out of
-// the L2.  Every workgroup streams ALL weights of the chain (2.2 MB for F9..F17) for its 16 rows, so the 32 workgroups of
-// an XCD pull 32 x 16 KiB per stage through that XCD's 16 L2 channels, and all of them want the same lines: a stage lands
-// every 350-450 cycles (36-45 B/clk per CU, about half of what the L2 delivers to 32 CUs reading different lines).  A
-// seventh ring slot (96 KiB in flight instead of 80) made it slower, i.e. it is the L2's throughput on shared lines, not
-// latency; fewer bytes per row would need more rows per workgroup, and two 32-row panels leave no room for the ring.
+// What bounds it (cycle stamps of workgroup 0, tools/chain_stamps.py; B = 4096, 256 workgroups): the weight stream into the
+// CU.  Every workgroup streams ALL weights of the chain (2.2 MB for F9..F17) for its 16 rows, and a 16-KiB stage lands every
+// 350-450 cycles = 36-45 B/clk per CU -- the rate the L2 -> LDS DMA path of a CU delivered in every kernel of this library
+// (tri_fused.hip: ~40 B/clk; the calibration probe's best case is 57).  It is not latency (a seventh ring slot, 96 KiB in
+// flight instead of 80, was 4-5 us per step slower) and not 32 CUs of an XCD asking one L2 for the same lines at the same
+// moment (staggering the workgroups in time by up to 8 x 512 cycles cost exactly the stagger).  Fewer bytes per row would
+// need more rows per workgroup, and two 32-row panels leave no room for the ring.
 // Measured dead ends: (1) re-reading the activation fragments from LDS at every stage made the loop LDS-bandwidth-bound
 // (48 KiB of LDS traffic per stage, 475 cycles); (2) two stages per barrier leave only four stages in flight: slower than
 // one stage per barrier with five; (3) reading the segment tables from the kernarg segment with scalar loads cost ~1000
