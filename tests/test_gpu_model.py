@@ -363,6 +363,30 @@ def test_backward_chain_matches_the_separate_launches(B):
     assert rel < 2e-2 and cos > 0.9998, (rel, cos)       # measured: see DESIGN.md
 
 
+@pytest.mark.parametrize("opts", [dict(dw_tile=3), dict(dw_tile=4), dict(dw_kg=1), dict(ln_fused=0, chain=0), dict(chain=0, dw_tile=3),
+                                  dict(splitk_max=2), dict(ksteps=8)])
+def test_weight_gradient_and_launch_plan_options_agree(opts):
+    """Every launch plan the options select computes the same training step: the weight-gradient kernel on 128x128 tiles (default,
+    K-slices of B rows, the workgroup's halves splitting 64-row stages), 256x256 tiles with split-K slabs (rounds 1-2), 256x128
+    tiles, other slice lengths; chains and fused LayerNorms on or off.  Weight gradients are fp32 sums of the same bf16 products in
+    another order: plans that leave the activations alone must agree to 1e-5 of the gradient's norm; plans that change a LayerNorm's
+    summation order move a bf16 rounding now and then (bounded like the backward-chain test)."""
+    B = 4096
+    base = _chain_step(B)                      # helper lowers chain_min to 1: chains run as in the default plan at this size
+    other = _chain_step(B, **opts)
+    exact_acts = not ({"ln_fused", "chain"} & set(opts))
+    g1, g0 = other[1].double(), base[1].double()
+    rel = float((g1 - g0).norm() / g0.norm())
+    if exact_acts:
+        assert other[0] == base[0]
+        for k in base[2]:
+            assert torch.equal(other[2][k], base[2][k]), k
+        assert rel < 1e-5, rel
+    else:
+        assert other[0] == pytest.approx(base[0], rel=1e-4)
+        assert rel < 2e-2, rel
+
+
 def test_two_phase_backward_equals_single_call():
     """mmdeer_backward with phase = 1 then 2 (the data-parallel overlap plan) fills the flat gradient buffer with
     exactly what the single call produces; after phase 1 buckets 0-1 are final and bucket 2 is still untouched."""
