@@ -38,7 +38,8 @@
 // one stage per barrier with five; (3) reading the segment tables from the kernarg segment with scalar loads cost ~1000
 // cycles per record; (4) weights straight from global memory into registers in the MFMA layout (no ring, no barrier in the
 // stage loop, 128 KiB in flight) ran at 22 B/clk/CU -- a 16-lane x 64-byte request pattern instead of the DMA's full lines --
-// and was 30 us slower per step.  One workgroup per 16 rows also means the launch only pays while the chip holds all
+// and was 30 us slower per step; (5) running a tile's epilogue inside the first stage of the next tile, behind that stage's DMA
+// issue, so that the ring never waits for the epilogue: 2 us per step slower.  One workgroup per 16 rows also means the launch only pays while the chip holds all
 // workgroups at once: api.hip uses the chains for B <= 4096 and the separate launches above.
 //
 // Backward chains (dX = dY W through the packed W^T copies) use the same kernel: a segment's epilogue can multiply by the
