@@ -1,7 +1,8 @@
-// Weight-gradient GEMM with 256x256 tiles:  C[M,N] = sum_k A[k][m] * B[k][n]  (A = dY stored [K][M], B = X stored
-// [K][N], K = batch rows), bf16 operands, fp32 result / split-K slabs.
+// Weight-gradient GEMM on LDS-DMA:  C[M,N] = sum_k A[k][m] * B[k][n]  (A = dY stored [K][M], B = X stored
+// [K][N], K = batch rows), bf16 operands, fp32 result / split-K slabs.  One kernel template, three tiles (see the template's
+// comment): 256x256 (rounds 1-2, described first), 128x128 (the default since round 3) and 256x128.
 //
-// Why this tile: the operands of a weight gradient are activations (tens of MB per layer), served from the Infinity
+// Which tile.  Rounds 1-2 argued per MAC: the operands of a weight gradient are activations (tens of MB per layer), served from the Infinity
 // Cache / L2 at 14-30 B/clk per CU.  A 128x128 tile moves 32 B of operand per 1 Ki MAC and the 128x128 kernel ran at
 // the cache's byte rate (9.6 TB/s chip-wide, ~4000 cycles per 64-deep K-tile); 256x256 halves the bytes per MAC.
 //
@@ -15,6 +16,12 @@
 // image row r holds logical chunk p ^ f(r), f(r) = (((r >> 3) & 1) << 3) | ((r & 3) << 1), applied to the DMA source
 // address and to the read address alike: the 8 rows a half-wave reads in one LDS cycle land on 8 distinct 32-byte
 // bank groups.  Counted vmcnt + raw s_barrier as in gemm_glds.hip.
+//
+// Round 3 measured the launch as memory-bound INCLUDING its own split-K slabs (130 MB of operand reads + 59 MB of slab writes,
+// then the fold reads them back): with 256x256 tiles only ~56 tiles exist and split-K supplies the parallelism.  On 128x128
+// tiles ~175 tiles fill the chip with whole reductions, no slab is written for the B-row problems and the fold almost disappears;
+// that the small tile's K loop is slower per MAC (LDS-bandwidth-bound) costs less than the slabs did: -6 us per step at
+// B = 4096, -43 us at 8192.
 #include "gemm_kernel.inc"
 
 #include <type_traits>
@@ -50,12 +57,6 @@ __device__ __forceinline__ u32x2 lds_tr_read(unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
   return v;
 }
-// s_waitcnt lgkmcnt(N) that the uses of the listed registers cannot be scheduled above
-template <int N>
-__device__ __forceinline__ void wait_lgkm(u32x2& a, u32x2& b, u32x2& c, u32x2& d, u32x2& e, u32x2& f, u32x2& g, u32x2& h) {
-  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
-}
-
 // BM x BN = 256 x 256 (the kernel described above), 128 x 128 or 256 x 128: the same schedule on smaller tiles.  128 x 128: a wave owns 32 x 64 (2 x 4 accumulators),
 // image rows are 256 B (a 1-KiB DMA piece = 4 rows, two pieces per wave per stage), 80 KiB of ring.  The small tile exists to
 // run weight gradients WITHOUT split-K: ~175 full-K tiles fill the chip, no partial slabs are written and re-read.
