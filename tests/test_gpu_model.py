@@ -387,6 +387,24 @@ def test_weight_gradient_and_launch_plan_options_agree(opts):
         assert rel < 2e-2, rel
 
 
+def test_eval_forward_with_chains_is_bit_identical():
+    """The inference path takes the forward chains as well (no dropout: every site is off): all outputs of forward() in eval mode
+    must equal the separate-launch plan's bit for bit, also on a ragged batch."""
+    B = 2500
+    b = synth.make_batch(B, seed=23)
+    a, v, t = (torch.from_numpy(b[k]).to(DEV) for k in ("audio", "video", "text"))
+    m = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=4)).to(DEV).eval()
+    outs = {}
+    for chain in (1, 0):
+        with _lib.options(chain=chain, chain_min=1), torch.no_grad():
+            o = m(a, v, t)
+            torch.cuda.synchronize()
+        outs[chain] = {k: x.clone() for k, x in o.items() if torch.is_tensor(x)}
+    assert set(outs[1]) == set(outs[0]) and len(outs[1]) >= 5
+    for k in outs[1]:
+        assert torch.equal(outs[1][k], outs[0][k]), k
+
+
 def test_two_phase_backward_equals_single_call():
     """mmdeer_backward with phase = 1 then 2 (the data-parallel overlap plan) fills the flat gradient buffer with
     exactly what the single call produces; after phase 1 buckets 0-1 are final and bucket 2 is still untouched."""
