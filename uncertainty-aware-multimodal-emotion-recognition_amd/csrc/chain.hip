@@ -401,11 +401,8 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       }
     }
   };
-  p_load();
-#pragma unroll
-  for (int t = 0; t < NST - 1; ++t) issue(t);
-
-  // ---- every bias / gamma / beta of the chain into LDS, by DMA as well (vector e is wave e % 8's job)
+  // ---- every bias / gamma / beta of the chain into LDS, by DMA as well (vector e is wave e % 8's job); BEFORE the ring's first
+  //      stages, so that the wait below can leave those in flight
   for (int e = wave; e < nvec; e += 8) {
     const u32x4 q = *reinterpret_cast<const u32x4*>(tab + VEC0 + e * 16);
     const float* src = reinterpret_cast<const float*>(sp(q.x, q.y));
@@ -416,8 +413,11 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       else if (j * 64 + lane < n4) *reinterpret_cast<f32x4*>(dst + j * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  p_load();
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t) issue(t);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FLY) : "memory");   // the vectors (and anything older) have landed; the ring's
+  __builtin_amdgcn_s_barrier();                                           // first stages are waited for stage by stage in the loop
   stamp(2);
 
   // ---- the chain
@@ -638,8 +638,13 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
           }
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      // A LayerNorm (forward or backward) rewrote the panel in place: everyone must see it before the next layer reads it.  A plain
+      // stash copy only READ the panel, the next layer only reads it too, and what the next layer writes is the other panel, whose
+      // last readers (this layer's fragment loads) are at least one barrier behind: no second barrier.
+      if (has_ln) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       unsigned char* t = pin; pin = pout; pout = t;
       rows_in = rows_out;
     }
