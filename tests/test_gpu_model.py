@@ -407,7 +407,8 @@ def test_eval_forward_with_chains_is_bit_identical():
 
 def test_two_phase_backward_equals_single_call():
     """mmdeer_backward with phase = 1 then 2 (the data-parallel overlap plan) fills the flat gradient buffer with
-    exactly what the single call produces; after phase 1 buckets 0-1 are final and bucket 2 is still untouched."""
+    what the single call produces (buckets 0-1 bit for bit, bucket 2 up to the fp32 summation order); after phase 1 buckets 0-1 are
+    final and bucket 2 is still untouched."""
     lib = _lib.load()
     m = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=8)).to(DEV).train()
     b = batch(512, seed=13)
@@ -431,7 +432,11 @@ def test_two_phase_backward_equals_single_call():
     assert float(flat[:lo].abs().sum()) == 0.0
     m._launch_backward(meta, meta["targets"], loss_out=loss, flat=flat, want_views=False, phase=2)
     torch.cuda.synchronize()
-    assert torch.equal(flat, flat0)
+    assert torch.equal(flat[lo:], flat0[lo:])
+    # the second call cuts the K of its five weight gradients into shorter slices (few problems: whole-reduction tiles would idle
+    # the chip): the same bf16 products summed in fp32 in another order
+    d = (flat[:lo].double() - flat0[:lo].double()).norm() / flat0[:lo].double().norm()
+    assert float(d) < 1e-5, float(d)
     assert torch.equal(loss, loss0)
 
 

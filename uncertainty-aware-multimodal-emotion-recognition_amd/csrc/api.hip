@@ -232,6 +232,7 @@ namespace {
 // Builder for the executor's GEMM problems.  `es` = bytes of one activation element.
 struct Exec {
   int B, f32;
+  int slice_div = 1; // > 1: weight-gradient K-slices this many times shorter (a launch with few problems: see mmdeer_backward phase 2)
   size_t es;
   bool drop_on;      // dropout active
   float mask_scale;  // 1/(1-p) when dropout is active, else 1
@@ -288,7 +289,7 @@ struct Exec {
     // 128x128 weight-gradient tiles (option dw_tile = 2, the default): K-slices of B rows -- the B-row problems run their whole
     // reduction in one workgroup (no slab, nothing to fold), the 2B-row ones (trimodal in_proj, the stacked AV calls) get two
     // slices as long as the others' one.  Measured against other slice lengths at B = 512 ... 16384.
-    if (!f32 && opt(OPT_DW_TILE) == 2 && opt(OPT_KSTEPS) == 0) { kst = B / 64; kst = kst < 4 ? 4 : kst > 128 ? 128 : kst; }
+    if (!f32 && opt(OPT_DW_TILE) == 2 && opt(OPT_KSTEPS) == 0) { kst = B / 64 / slice_div; kst = kst < 4 ? 4 : kst > 128 ? 128 : kst; }
     int sk = (nk + kst - 1) / kst;
     const int cap = opt(OPT_SPLITK_MAX) < SPLITK_MAX ? opt(OPT_SPLITK_MAX) : SPLITK_MAX;
     if (sk > cap) sk = cap;
@@ -858,6 +859,10 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   if (phase == 1) return 0;
   }   // phase != 2
 
+  // Two-call mode, second call: only the five audio-visual weight gradients are left (~30 tiles of 128x128): whole-reduction
+  // tiles would leave 7/8 of the chip idle for a full tile's latency, so their K is cut into eight slices (slabs + fold, as the
+  // 256x256 plan did for everything).  Costs nothing in the single-call mode, where they ride along with the other ~200 tiles.
+  if (phase == 2) X.slice_div = 8;
   // ================= bucket 2: audio-visual fusion =================
   TRY(launch_ln_bwd(L.dav, L.y_a2, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), L.dz_a2, L.part_ln_a2, B, INTER, f32, X.mask_scale, s));
   // fusion_layers dX, written "stacked" ([2B,256]: rows [0,B) = d audio_attended, rows [B,2B) = d video_attended)
