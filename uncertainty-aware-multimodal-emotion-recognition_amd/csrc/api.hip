@@ -736,6 +736,10 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   const int phase = a->phase;
   MMDEER_CHECK(phase >= 0 && phase <= 2, "backward: phase must be 0, 1 or 2 (got %d)", phase);
   int ev_done = phase == 2 ? 2 : 0;   // first bucket whose event has not been recorded yet
+  // backward chains (chain.hip): the head / trimodal run always when enabled; the audio-visual run only in the single-call mode
+  // (in the two-call mode its first product, the token-0 dX, belongs to the first call)
+  const int bmin = opt(OPT_CHAIN_MIN) >= 2049 ? 2561 : opt(OPT_CHAIN_MIN);   // the backward chains pay later than the forward's: B = 2048 +5 us, 3072 -1 us
+  const bool dchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= 4096 && phase == 0;
   auto flush = [&](int bucket, bool last) -> int {
     if (!last) return 0;
     if (dwg.nprob > 0) {
@@ -759,7 +763,6 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // B2-B10 are local to a sample like the forward's layers: in bf16 mode (B <= 4096, no outside gradient on fused_features)
   // ONE launch of the layer-chain kernel walks the head's four dX products, both LayerNorm backwards and the three trimodal dX
   // products with the rows resident in LDS, and writes the same workspace buffers (the weight-gradient launch reads them)
-  const int bmin = opt(OPT_CHAIN_MIN) >= 2049 ? 2561 : opt(OPT_CHAIN_MIN);   // the backward chain pays later: B = 2048 +5 us, 3072 -1 us
   const bool bchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= 4096 && !a->g_fused;
   if (bchain) {
     ChainArgs c{};
@@ -844,7 +847,8 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   else
     TRY(launch_tri_attn_bwd(L.qkv, L.dobar, L.probs, L.dqkv, B, f32, X.drop_on ? 1 : 0, X.dc, s));
   TRY(X.run1(X.dx(L.dqkv, 3 * FUS, P_TIN_W, L.dxtok, FUS, 2 * B, nullptr, 0)));  // in_proj
-  TRY(X.run1(X.dx(L.dxtok, 2 * FUS, P_AVP_W, L.dav, INTER, B, nullptr, 0)));     // token 0 -> audiovisual features
+  // (with the AV chain below, this product is its first segment)
+  if (!dchain) TRY(X.run1(X.dx(L.dxtok, 2 * FUS, P_AVP_W, L.dav, INTER, B, nullptr, 0)));     // token 0 -> audiovisual features
   {
     add_dw(X.dw(L.dz_o1, FUS, L.tri, f32, FUS, P_OP_W, P_OP_B, G, B));
     add_dw(X.dw(L.dz_t3, FUS, L.pool, f32, FUS, P_TFF_W, P_TFF_B, G, B));
@@ -864,26 +868,63 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // 256x256 plan did for everything).  Costs nothing in the single-call mode, where they ride along with the other ~200 tiles.
   if (phase == 2) X.slice_div = 8;
   // ================= bucket 2: audio-visual fusion =================
-  TRY(launch_ln_bwd(L.dav, L.y_a2, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), L.dz_a2, L.part_ln_a2, B, INTER, f32, X.mask_scale, s));
-  // fusion_layers dX, written "stacked" ([2B,256]: rows [0,B) = d audio_attended, rows [B,2B) = d video_attended)
-  // by batching over the two column halves of the weight
-  {
-    GemmProblem p = X.dx(L.dz_a2, INTER, P_AVF_W, L.dcats, INTER, B, nullptr, 0);
-    p.N = INTER; p.batch = 2; p.sB = (long long)INTER * INTER; p.sC = (long long)B * INTER;   // rows [256 z, 256 z + 256) of W^T [512][256]
-    TRY(X.run1(p));
-  }
-  // AV out_proj; dX gets the regenerated attention-dropout factor of the forward value projection
-  {
-    GemmProblem p = X.dx(L.dcats, INTER, P_AOUT_W, L.davv, INTER, 2 * B, nullptr, 0);
-    if (X.drop_on) { p.regen_site = SITE_AV_ATTN; p.drop_shift = 5; }
-    TRY(X.run1(p));
-  }
-  // AV value projection (rows [2E,3E) of in_proj)
-  {
-    GemmProblem p = X.dx(L.davv, INTER, P_AIN_W, L.davin, INTER, 2 * B, nullptr, 0);
-    p.B = X.WT(P_AIN_W) + (size_t)2 * INTER * es;   // columns [2E, 3E) of W^T [256][768]
-    p.K = INTER;
-    TRY(X.run1(p));
+  // B13-B17 (token-0 dX, LayerNorm backward, the three AV dX products) are sample-local as well: one more launch of the chain
+  // kernel.  The concatenation's backward is a re-view of the panel: columns [0,256) / [256,512) of d cat become the rows of the
+  // audio->video / video->audio call.
+  if (dchain) {
+    ChainArgs c{};
+    c.X = reinterpret_cast<const bf16_t*>(L.dxtok); c.ldx = 2 * FUS; c.K0 = FUS; c.B = B; c.groups = 1; c.group_stride = B;
+    c.drop = X.dc;
+    auto dxs = [&](const char* wt, int N, int K, int ldw, void* stash, int ld_stash, int nout) {
+      ChainSeg q;
+      chain_seg_defaults(q);
+      q.W = reinterpret_cast<const bf16_t*>(wt); q.N = N; q.K = K; q.ldw = ldw;
+      q.end_layer = 1; q.nout = nout; q.stash = reinterpret_cast<bf16_t*>(stash); q.ld_stash = ld_stash;
+      return q;
+    };
+    int k = 0;
+    {   // token 0 -> audiovisual features, then the LayerNorm of fusion_layers backwards (mask of its Linear-ReLU-Dropout)
+      ChainSeg q = dxs(X.WT(P_AVP_W), INTER, FUS, FUS, L.dav, INTER, INTER);
+      q.lnb_gamma = X.V(P_AVF_G); q.lnb_y = reinterpret_cast<const bf16_t*>(L.y_a2); q.lnb_mean = L.mean_a2; q.lnb_rstd = L.rstd_a2;
+      q.lnb_dz = reinterpret_cast<bf16_t*>(L.dz_a2); q.lnb_partial = L.part_ln_a2; q.lnb_mask_scale = X.mask_scale;
+      c.seg[k++] = q;
+    }
+    {   // fusion_layers dX: W^T [512][256]; the 512 columns = d cat, unfolded into the two calls' rows ([2B,256] stacked)
+      ChainSeg q = dxs(X.WT(P_AVF_W), 2 * INTER, INTER, INTER, L.dcats, INTER, INTER);
+      q.fold_groups = 2;
+      c.seg[k++] = q;
+    }
+    {   // AV out_proj; dX gets the regenerated attention-dropout factor of the forward value projection
+      ChainSeg q = dxs(X.WT(P_AOUT_W), INTER, INTER, INTER, L.davv, INTER, INTER);
+      if (X.drop_on) { q.drop_site = SITE_AV_ATTN; q.drop_shift = 5; }
+      c.seg[k++] = q;
+    }
+    // AV value projection (columns [2E, 3E) of W^T [256][768])
+    c.seg[k++] = dxs(X.WT(P_AIN_W) + (size_t)2 * INTER * es, INTER, INTER, 3 * INTER, L.davin, INTER, INTER);
+    c.nseg = k;
+    TRY(launch_chain(c, s));
+  } else {
+    TRY(launch_ln_bwd(L.dav, L.y_a2, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), L.dz_a2, L.part_ln_a2, B, INTER, f32, X.mask_scale, s));
+    // fusion_layers dX, written "stacked" ([2B,256]: rows [0,B) = d audio_attended, rows [B,2B) = d video_attended)
+    // by batching over the two column halves of the weight
+    {
+      GemmProblem p = X.dx(L.dz_a2, INTER, P_AVF_W, L.dcats, INTER, B, nullptr, 0);
+      p.N = INTER; p.batch = 2; p.sB = (long long)INTER * INTER; p.sC = (long long)B * INTER;   // rows [256 z, 256 z + 256) of W^T [512][256]
+      TRY(X.run1(p));
+    }
+    // AV out_proj; dX gets the regenerated attention-dropout factor of the forward value projection
+    {
+      GemmProblem p = X.dx(L.dcats, INTER, P_AOUT_W, L.davv, INTER, 2 * B, nullptr, 0);
+      if (X.drop_on) { p.regen_site = SITE_AV_ATTN; p.drop_shift = 5; }
+      TRY(X.run1(p));
+    }
+    // AV value projection (rows [2E,3E) of in_proj)
+    {
+      GemmProblem p = X.dx(L.davv, INTER, P_AIN_W, L.davin, INTER, 2 * B, nullptr, 0);
+      p.B = X.WT(P_AIN_W) + (size_t)2 * INTER * es;   // columns [2E, 3E) of W^T [256][768]
+      p.K = INTER;
+      TRY(X.run1(p));
+    }
   }
   {
     add_dw(X.dw(L.dz_a2, INTER, L.cat, f32, 2 * INTER, P_AVF_W, P_AVF_B, G, B));

@@ -32,7 +32,8 @@ struct ChainSeg {
   int ld_stash, nout;      // end_layer: leading dimension of stash, width of the finished panel
   int relu, drop_site, drop_shift, end_layer;
   int mblocks;             // 16-row blocks of the input panel this segment multiplies (0: all of them)
-  int fold_groups;         // 1: rows of group z land in rows of group 0, columns + z * N (torch.cat of the two AV calls)
+  int fold_groups;         // 1: rows of group z land in rows of group 0, columns + z * N (torch.cat of the two AV calls);
+                           // 2: the inverse (its backward): columns [z N/2, (z+1) N/2) of the one group become the rows of group z
   // backward chains (dX = dY W through the packed W^T copies):
   const bf16_t* mask_y;    // epilogue: out *= (Y > 0) * mask_scale with Y = mask_y[row][mask_col0 + n] (ReLU + dropout of the
   int ld_mask, mask_col0;  //   forward layer below), or null

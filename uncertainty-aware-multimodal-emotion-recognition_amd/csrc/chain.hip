@@ -523,7 +523,8 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
             v.z = __uint_as_float(m1 << 16) > 0.f ? v.z * ms : 0.f; v.w = __uint_as_float(m1 & 0xFFFF0000u) > 0.f ? v.w * ms : 0.f;
           }
           int col = colb, orow = r;
-          if (fold) { col += (r >> LOG_MS) * N; orow = r & (MS - 1); }
+          if (fold == 1) { col += (r >> LOG_MS) * N; orow = r & (MS - 1); }
+          else if (fold == 2) { const int half = N >> 1, z = col >= half; col -= z * half; orow = r + z * MS; }
           unsigned char* cell = pout + (col >> 6) * img_out + orow * 128 + ((((col & 63) >> 3) ^ (orow & 7)) * 16) + (col & 4) * 2;
           *reinterpret_cast<u32x2*>(cell) = u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
         }
@@ -697,8 +698,10 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     td.mask_y = s.mask_y; td.ld_mask = s.ld_mask; td.mask_col0 = s.mask_col0; td.mask_scale = s.mask_scale;
     MMDEER_CHECK(!s.mask_y || (((uintptr_t)s.mask_y % 8) == 0 && s.ld_mask % 4 == 0 && s.mask_col0 % 4 == 0), "chain: segment %d mask alignment", i);
     if (s.end_layer) {
-      const int blocks_out = s.fold_groups ? blocks_in / 2 : blocks_in;
-      MMDEER_CHECK(!s.fold_groups || blocks_in == 2, "chain: segment %d folds the groups of a single-group panel", i);
+      const int blocks_out = s.fold_groups == 1 ? blocks_in / 2 : s.fold_groups == 2 ? blocks_in * 2 : blocks_in;
+      MMDEER_CHECK(s.fold_groups != 1 || blocks_in == 2, "chain: segment %d folds the groups of a single-group panel", i);
+      MMDEER_CHECK(s.fold_groups != 2 || (blocks_in == 1 && s.nout_off == 0 && s.N == 2 * s.nout && s.nout % 64 == 0),
+                   "chain: segment %d unfolds: one row group, N = 2 x the panel width", i);
       MMDEER_CHECK(s.nout % 64 == 0 && s.nout * blocks_out <= 512, "chain: layer ending at segment %d does not fit the panel", i);
       MMDEER_CHECK(!s.stash || (((uintptr_t)s.stash % 16) == 0 && s.ld_stash % 8 == 0), "chain: segment %d stash alignment", i);
       MMDEER_CHECK(nend < CHAIN_MAX_ENDS, "chain: too many layers");
