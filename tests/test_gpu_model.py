@@ -331,13 +331,15 @@ def _chain_step(B, **opts):
     return float(d["total_loss"]), m.flat_grad().clone(), {k: d[k].clone() for k in ("gamma", "nu", "alpha", "beta") if k in d}
 
 
-@pytest.mark.parametrize("B", [300, 2500, 4096])
+@pytest.mark.parametrize("B", [300, 2500, 4096, 5000, 8192])
 def test_layer_chain_launch_is_bit_identical_to_the_separate_launches(B):
     """chain.hip walks F2..F6 (the AV value / output projections, fusion layer, LayerNorm, token-0 projection) and F9..F17
     (five Linear+ReLU+Dropout layers, two LayerNorms, the stacked evidence heads) as ONE launch each with the rows resident in LDS.
     Same accumulation order, same rounding points, same dropout decisions as the stand-alone
     GEMM / fused-LayerNorm launches: the training step must come out bit for bit (B = 300 and 2500: ragged 16-sample blocks;
-    the library uses the chains up to B = 4096).  The backward chain is switched off here: see the next test."""
+    the library
+    uses 16-sample workgroups up to B = 4096 and 32-sample ones, forward chains only, up to 8192: B = 5000 and 8192).  The backward
+    chains are switched off here: see the next test."""
     on, off = _chain_step(B, chain=1, chain_bwd=0), _chain_step(B, chain=0)
     assert on[0] == off[0]
     assert torch.equal(on[1], off[1])

@@ -513,10 +513,11 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     g.drop = X.dc;
     return launch_gemm_ln(g, Y, X.V(pidG), X.V(pidBt), xln, out32, mean, rstd, s);
   };
-  // one workgroup per 16 samples, each streaming all weights of its chain -- a fixed 25-45 us per chain whatever the batch:
-  // worth it while the chip holds all workgroups at once and most CUs have one (measured per step: B = 4096 -5 to -15 us
-  // depending on the box, 3072 -4 us, 2048 0, 1024 +1 us, 64 +12 us; B = 8192 in two rounds +9 us)
-  const bool chains = !f32 && opt(OPT_CHAIN) && B >= opt(OPT_CHAIN_MIN) && B <= 4096;
+  // one workgroup per 16 samples (32 above B = 4096), each streaming all weights of its chain -- a fixed 25-45 us per chain
+  // whatever the batch: worth it while the chip holds all workgroups at once and most CUs have one (measured per step: B = 4096
+  // -5 to -15 us depending on the box, 3072 -4 us, 2048 0, 1024 +1 us, 64 +12 us; 16-sample workgroups in two rounds at 8192:
+  // +9 us, 32-sample workgroups: see DESIGN.md)
+  const bool chains = !f32 && opt(OPT_CHAIN) && B >= opt(OPT_CHAIN_MIN) && B <= 8192;
   // F2-F6 are local to a sample (the AV "attention" has one key per query: softmax == 1, only the value and output projections
   // remain): in bf16 mode ONE launch walks them with the rows resident in LDS (chain.hip).  A workgroup holds the video and the
   // audio row of its 16 samples as two row groups; torch.cat of the two attention outputs is a re-view of the panel.

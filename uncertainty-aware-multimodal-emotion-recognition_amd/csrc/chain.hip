@@ -292,10 +292,12 @@ __device__ __forceinline__ void chain_ln_bwd(unsigned char* pan, int img, float*
 
 // NST ring slots of 16 KiB (NST - 1 stages in flight), VECF floats of bias / gamma / beta.  Instantiated as <6, 4864>; a
 // seven-slot ring for the chains with few vectors (<7, 2560>, 156 KiB of LDS) was 4-5 us per step SLOWER on the same box.
-template <int NST, int VECF>
+// TS = 1: 16 samples per workgroup (B <= 4096: one round of 256 workgroups); TS = 2: 32 samples (forward chains of 4096 < B <= 8192:
+// twice the rows per streamed weight byte; the two 32-KiB panels leave four ring slots).
+template <int NST, int VECF, int TS>
 __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
-  constexpr int MS = 16, LOG_MS = 4, FLY = 2 * (NST - 1);   // FLY: weight DMAs of one wave in flight
-  constexpr int PAN = MS * 1024;           // 16 rows x 512 columns (or 32 x 256) of bf16
+  constexpr int MS = 16 * TS, LOG_MS = TS == 1 ? 4 : 5, FLY = 2 * (NST - 1);   // FLY: weight DMAs of one wave in flight
+  constexpr int PAN = MS * 1024;           // MS rows x 512 columns (or 2 MS x 256) of bf16
   constexpr int SLOT = 16384;
   constexpr int RING = 2 * PAN, VEC = RING + NST * SLOT, TAB = VEC + VECF * 4;
   constexpr int SEG_BYTES = (int)sizeof(ChainSegK);
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       const u32x4* er = reinterpret_cast<const u32x4*>(tab + END0 + endi * (int)sizeof(ChainEndK));
       const u32x4 e1 = er[1], e2 = er[2], e3 = er[3], e4 = er[4];
       end_mode = sc(e3.y);
-      if (end_mode == 2) {
+      if (TS == 1 && end_mode == 2) {
         const bf16_t* ly = reinterpret_cast<const bf16_t*>(sp(e3.z, e3.w));
         const float* lmean = reinterpret_cast<const float*>(sp(e1.z, e1.w));
         const float* lrstd = reinterpret_cast<const float*>(sp(e2.x, e2.y));
@@ -574,15 +576,15 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
     stamp(3 + 3 * si);
 #define CH_SEG(MBv, KBv, NKTv) seg_body(std::integral_constant<int, MBv>{}, std::integral_constant<bool, KBv>{}, std::integral_constant<int, NKTv>{}, sg)
     if (!kb) {
-      if (mb == 1) {
-        if (nkt == 8) CH_SEG(1, false, 8); else if (nkt == 6) CH_SEG(1, false, 6); else if (nkt == 4) CH_SEG(1, false, 4);
-        else if (nkt == 2) CH_SEG(1, false, 2); else CH_SEG(1, false, 1);
+      if (mb == TS) {
+        if (nkt == 8) CH_SEG(TS, false, 8); else if (nkt == 6) CH_SEG(TS, false, 6); else if (nkt == 4) CH_SEG(TS, false, 4);
+        else if (nkt == 2) CH_SEG(TS, false, 2); else CH_SEG(TS, false, 1);
       } else {
-        if (nkt == 4) CH_SEG(2, false, 4); else if (nkt == 2) CH_SEG(2, false, 2); else CH_SEG(2, false, 1);
+        if (nkt == 4) CH_SEG(2 * TS, false, 4); else if (nkt == 2) CH_SEG(2 * TS, false, 2); else CH_SEG(2 * TS, false, 1);
       }
     } else {
-      if (mb == 1) { if (nkt == 2) CH_SEG(1, true, 2); else CH_SEG(1, true, 1); }
-      else CH_SEG(2, true, 1);
+      if (mb == TS) { if (nkt == 2) CH_SEG(TS, true, 2); else CH_SEG(TS, true, 1); }
+      else CH_SEG(2 * TS, true, 1);
     }
 #undef CH_SEG
     stamp(4 + 3 * si);
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       bf16_t* stash = reinterpret_cast<bf16_t*>(sp(e0.x, e0.y));
       const int ld_stash = sc(e2.z), nout = sc(e2.w);
       const int gb_off = sc(e3.x), has_ln = sc(e3.y);
-      if (has_ln == 2) {
+      if (TS == 1 && has_ln == 2) {
         stamp(100);
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(lnb.y[0]), "+v"(lnb.y[1]), "+v"(lnb.mu), "+v"(lnb.rs) : "n"(FLY) : "memory");
         stamp(101);
@@ -670,7 +672,8 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   k.X = a.X; k.ldx = a.ldx; k.K0 = a.K0; k.B = a.B; k.groups = a.groups; k.group_stride = a.group_stride; k.drop = a.drop;
   k.stamps = a.stamps;
   int vec = 0, nend = 0, nvec = 0;
-  int blocks_in = a.groups, width_in = a.K0, layer_first_seg = 0;
+  const int ts = a.B > 4096 ? 2 : 1;       // 16-sample blocks per workgroup
+  int blocks_in = a.groups * ts, width_in = a.K0, layer_first_seg = 0;
   auto add_vec = [&](const float* src, int n) { ChainVecK& v = k.vec[nvec++]; v.src = src; v.off = vec; v.n4 = n / 4; vec += n; return v.off; };
   for (int i = 0; i < a.nseg; ++i) {
     const ChainSeg& s = a.seg[i];
@@ -682,12 +685,12 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     MMDEER_CHECK(s.nout_off % 64 == 0, "chain: segment %d output offset", i);
     MMDEER_CHECK(!s.bias || ((uintptr_t)s.bias % 16) == 0, "chain: segment %d bias alignment", i);
     const int mblocks = s.mblocks ? s.mblocks : blocks_in;
-    MMDEER_CHECK(mblocks <= blocks_in && mblocks <= 2, "chain: segment %d m-blocks", i);
+    MMDEER_CHECK(mblocks <= blocks_in && (mblocks == ts || mblocks == 2 * ts), "chain: segment %d m-blocks", i);
     MMDEER_CHECK(nvec + 3 <= CHAIN_MAX_VECS, "chain: too many bias / gamma / beta vectors");
     const int vec_off = s.bias ? add_vec(s.bias, s.N) : 0;
     const int kb = s.N % 128 != 0, ntl = kb ? s.N / 64 : s.N / 128, nkt = kb ? s.K / 128 : s.K / 64;
     MMDEER_CHECK(ntl <= 4, "chain: segment %d has too many column tiles", i);
-    MMDEER_CHECK(kb ? (nkt <= 2 && mblocks * nkt <= 2) : ((nkt == 1 || nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8) && mblocks * nkt <= 8),
+    MMDEER_CHECK(kb ? (nkt <= 2 && mblocks * nkt <= 2 * ts) : ((nkt == 1 || nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8) && mblocks * nkt <= 8 * ts),
                  "chain: segment %d: K = %d with %d row blocks is not instantiated", i, s.K, mblocks);
     ChainSegK& td = k.seg[i];
     td.W = s.W; td.ldw = s.ldw; td.nkt = nkt; td.ntiles = ntl; td.kindb = kb; td.end = -1;
@@ -699,16 +702,16 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     MMDEER_CHECK(!s.mask_y || (((uintptr_t)s.mask_y % 8) == 0 && s.ld_mask % 4 == 0 && s.mask_col0 % 4 == 0), "chain: segment %d mask alignment", i);
     if (s.end_layer) {
       const int blocks_out = s.fold_groups == 1 ? blocks_in / 2 : s.fold_groups == 2 ? blocks_in * 2 : blocks_in;
-      MMDEER_CHECK(s.fold_groups != 1 || blocks_in == 2, "chain: segment %d folds the groups of a single-group panel", i);
-      MMDEER_CHECK(s.fold_groups != 2 || (blocks_in == 1 && s.nout_off == 0 && s.N == 2 * s.nout && s.nout % 64 == 0),
+      MMDEER_CHECK(s.fold_groups != 1 || blocks_in == 2 * ts, "chain: segment %d folds the groups of a single-group panel", i);
+      MMDEER_CHECK(s.fold_groups != 2 || (blocks_in == ts && s.nout_off == 0 && s.N == 2 * s.nout && s.nout % 64 == 0),
                    "chain: segment %d unfolds: one row group, N = 2 x the panel width", i);
-      MMDEER_CHECK(s.nout % 64 == 0 && s.nout * blocks_out <= 512, "chain: layer ending at segment %d does not fit the panel", i);
+      MMDEER_CHECK(s.nout % 64 == 0 && s.nout * blocks_out <= 512 * ts, "chain: layer ending at segment %d does not fit the panel", i);
       MMDEER_CHECK(!s.stash || (((uintptr_t)s.stash % 16) == 0 && s.ld_stash % 8 == 0), "chain: segment %d stash alignment", i);
       MMDEER_CHECK(nend < CHAIN_MAX_ENDS, "chain: too many layers");
       ChainEndK& e = k.end[nend];
       e.stash = s.stash; e.ld_stash = s.ld_stash; e.nout = s.nout;
       if (s.lnb_gamma) {
-        MMDEER_CHECK(!s.gamma && (s.nout == 256 || s.nout == 512) && blocks_out == 1, "chain: LayerNorm backward of segment %d: width %d, one row group", i, s.nout);
+        MMDEER_CHECK(!s.gamma && (s.nout == 256 || s.nout == 512) && blocks_out == 1 && ts == 1, "chain: LayerNorm backward of segment %d: width %d, one row group", i, s.nout);
         MMDEER_CHECK(s.lnb_y && s.lnb_mean && s.lnb_rstd && s.lnb_dz && s.lnb_partial && ((uintptr_t)s.lnb_gamma % 16) == 0 &&
                          ((uintptr_t)s.lnb_y % 16) == 0 && ((uintptr_t)s.lnb_dz % 16) == 0 && ((uintptr_t)s.lnb_partial % 16) == 0,
                      "chain: LayerNorm backward of segment %d: pointers / alignment", i);
@@ -736,7 +739,8 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   MMDEER_CHECK(a.seg[a.nseg - 1].end_layer, "chain: the last segment must end its layer");
   MMDEER_CHECK(vec <= CHAIN_VEC_FLOATS, "chain: %d bias / gamma / beta floats exceed the LDS area (%d)", vec, CHAIN_VEC_FLOATS);
   k.nseg = a.nseg; k.nvec = nvec;
-  hipLaunchKernelGGL((chain_kernel<6, CHAIN_VEC_FLOATS>), dim3((a.B + 15) / 16), dim3(512), 0, stream, k);
+  if (ts == 1) hipLaunchKernelGGL((chain_kernel<6, CHAIN_VEC_FLOATS, 1>), dim3((a.B + 15) / 16), dim3(512), 0, stream, k);
+  else hipLaunchKernelGGL((chain_kernel<4, CHAIN_VEC_FLOATS, 2>), dim3((a.B + 31) / 32), dim3(512), 0, stream, k);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
