@@ -75,8 +75,9 @@ size_t mmdeer_weights_bytes(int compute_f32);
  *   fused_attn (1)     0: unfused in_proj GEMM + attention kernels also in bf16 mode
  *   qkv_recompute (1)  0: the fused forward stores q|k|v for the backward instead of recomputing the head tiles
  *   ln_fused (1)       0: the LayerNorms of the forward as stand-alone launches instead of inside the consuming GEMM (bf16)
- *   chain (1)          0: every sample-local layer as its own launch; 1 (bf16, chain_min <= B <= 4096): the runs F2-F6 and F9-F17
- *                      of the forward and, with chain_bwd (1), the head / trimodal dX run of the backward as one launch each
+ *   chain (1)          0: every sample-local layer as its own launch; 1 (bf16, chain_min <= B <= 8192): the runs F2-F6 and F9-F17
+ *                      of the forward and, with chain_bwd (1), the head / trimodal and the audio-visual dX runs of the backward as
+ *                      one launch each
  *   chain_min (2049)   smallest batch that takes the chains (the backward chain from 2561)
  *   dw_tile (2)        weight-gradient launch: 2 = 128x128 tiles, K-slices of B rows (no split-K slabs for the B-row problems),
  *                      3 = 256x256 tiles + split-K slabs, 4 = 256x128 tiles; dw_kg (2): 1 = the 128x128 kernel on 32-row K stages

@@ -347,7 +347,7 @@ def test_layer_chain_launch_is_bit_identical_to_the_separate_launches(B):
         assert torch.equal(on[2][k], off[2][k]), k
 
 
-@pytest.mark.parametrize("B", [300, 2500, 4096])
+@pytest.mark.parametrize("B", [300, 2500, 4096, 5000, 8192])
 def test_backward_chain_matches_the_separate_launches(B):
     """The backward's head / trimodal run (7 dX products with their (Y > 0) masks, two LayerNorm backwards with gamma / beta
     partials) as one chain launch.  The dX products are bit-identical to the GEMM launches; the LayerNorm backward sums a row in

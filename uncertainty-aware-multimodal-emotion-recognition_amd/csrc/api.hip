@@ -740,7 +740,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // backward chains (chain.hip): the head / trimodal run always when enabled; the audio-visual run only in the single-call mode
   // (in the two-call mode its first product, the token-0 dX, belongs to the first call)
   const int bmin = opt(OPT_CHAIN_MIN) >= 2049 ? 2561 : opt(OPT_CHAIN_MIN);   // the backward chains pay later than the forward's: B = 2048 +5 us, 3072 -1 us
-  const bool dchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= 4096 && phase == 0;
+  const bool dchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= 8192 && phase == 0;
   auto flush = [&](int bucket, bool last) -> int {
     if (!last) return 0;
     if (dwg.nprob > 0) {
@@ -764,7 +764,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // B2-B10 are local to a sample like the forward's layers: in bf16 mode (B <= 4096, no outside gradient on fused_features)
   // ONE launch of the layer-chain kernel walks the head's four dX products, both LayerNorm backwards and the three trimodal dX
   // products with the rows resident in LDS, and writes the same workspace buffers (the weight-gradient launch reads them)
-  const bool bchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= 4096 && !a->g_fused;
+  const bool bchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= 8192 && !a->g_fused;
   if (bchain) {
     ChainArgs c{};
     c.X = reinterpret_cast<const bf16_t*>(L.dz2); c.ldx = 3 * EV2; c.K0 = 3 * EV2; c.B = B; c.groups = 1; c.group_stride = 0;

@@ -209,10 +209,11 @@ struct ChainLnbIn {
 // d xhat and d over the workgroup's rows (gamma / beta gradients) are formed deterministically: each wave adds its two rows
 // in LDS (lower half writes, upper half reads and adds -- one wave's LDS operations execute in order), the workgroup's eight waves are
 // summed column by column in a fixed order.  `red` = 16 KiB of LDS (the idle input panel).
+// Row part (one call per 16-row pass): dz of this lane's row; its d * xhat and d are ADDED to gacc / bacc (this lane's chunks,
+// summed over the passes -- a 32-row panel is two passes).  Fold part: chain_ln_bwd_fold.
 template <int NKT>
-__device__ __forceinline__ void chain_ln_bwd(unsigned char* pan, int img, float* red, int wave, int lane, int tid, int r, bool valid,
-                                             long long grow, const float* gam, const ChainLnbIn& in, float ms, bf16_t* dz,
-                                             float* slab) {
+__device__ __forceinline__ void chain_ln_bwd(unsigned char* pan, int img, int lane, int r, bool valid, long long grow, const float* gam,
+                                             const ChainLnbIn& in, float ms, bf16_t* dz, float (&gacc)[NKT * 2], float (&bacc)[NKT * 2]) {
 #pragma clang fp contract(off)
   constexpr int KD = NKT * 64, NC = NKT / 4;
   constexpr float inv_k = 1.0f / (float)KD;
@@ -256,8 +257,22 @@ __device__ __forceinline__ void chain_ln_bwd(unsigned char* pan, int img, float*
     *reinterpret_cast<u32x4*>(cell[j]) = packed;
     if (valid) store_wt16(dz + grow * KD + c * 8, packed);
   }
-  // ---- gamma / beta partial sums over the workgroup's rows (rows past the batch contribute nothing)
+  // ---- gamma / beta contributions of this row (rows past the batch contribute nothing)
   const float live = valid ? 1.f : 0.f;
+#pragma unroll
+  for (int e = 0; e < NC * 8; ++e) { gacc[e] += d[e] * xh[e] * live; bacc[e] += d[e] * live; }
+}
+
+// gamma / beta partial sums over the workgroup's rows from the lanes' accumulated contributions: the two halves of a wave add
+// in LDS (lower half writes, upper half reads and adds -- plain LDS operations of ONE wave execute in order; an LDS atomic
+// here made the compiler wait for vmcnt(0), i.e. for the weight ring and every write-through store: 13k cycles), then the
+// eight waves' rows of `red` are summed column by column in a fixed order.
+template <int NKT>
+__device__ __forceinline__ void chain_ln_bwd_fold(float* red, int wave, int lane, int tid, const float (&gacc)[NKT * 2],
+                                                  const float (&bacc)[NKT * 2], float* slab) {
+#pragma clang fp contract(off)
+  constexpr int KD = NKT * 64, NC = NKT / 4;
+  const int l32 = lane & 31;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     float* mine = red + wave * KD;
@@ -266,9 +281,7 @@ __device__ __forceinline__ void chain_ln_bwd(unsigned char* pan, int img, float*
       const int c = l32 + 32 * j;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (pass == 0 ? d[8 * j + e] * xh[8 * j + e] : d[8 * j + e]) * live;
-      // lower half writes its row's values, upper half adds its own on top: plain LDS operations of ONE wave execute in order
-      // (an LDS atomic here made the compiler wait for vmcnt(0) -- the weight ring and every write-through store -- 13k cycles)
+      for (int e = 0; e < 8; ++e) v[e] = pass == 0 ? gacc[8 * j + e] : bacc[8 * j + e];
       f32x4* dst = reinterpret_cast<f32x4*>(mine + 8 * c);
       if (lane < 32) { dst[0] = f32x4{v[0], v[1], v[2], v[3]}; dst[1] = f32x4{v[4], v[5], v[6], v[7]}; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -551,28 +564,31 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
     }
     // a layer that ends in a LayerNorm backward: this lane's chunks of the forward's rows and the row statistics are requested
     // now, before the segment's weight stages (>= NST - 1 of them: FLY younger DMAs), and waited for with vmcnt(FLY) at the layer end
-    ChainLnbIn lnb;
-    lnb.y[0] = lnb.y[1] = u32x4{0u, 0u, 0u, 0u}; lnb.mu = 0.f; lnb.rs = 0.f;
-    int end_mode = 0;
-    if (endi >= 0) {
-      const u32x4* er = reinterpret_cast<const u32x4*>(tab + END0 + endi * (int)sizeof(ChainEndK));
-      const u32x4 e1 = er[1], e2 = er[2], e3 = er[3], e4 = er[4];
-      end_mode = sc(e3.y);
-      if (TS == 1 && end_mode == 2) {
-        const bf16_t* ly = reinterpret_cast<const bf16_t*>(sp(e3.z, e3.w));
-        const float* lmean = reinterpret_cast<const float*>(sp(e1.z, e1.w));
-        const float* lrstd = reinterpret_cast<const float*>(sp(e2.x, e2.y));
-        const int nout = sc(e2.w);
-        const int r = 2 * wave + (lane >> 5);
+    // 16-sample workgroups request them NOW, before the segment's weight stages (>= NST - 1 of them: FLY younger DMAs), and wait with
+    // vmcnt(FLY) at the layer end; 32-sample workgroups have no registers to hold them across the segment (the compiler would spill
+    // registers whose loads it does not know to be in flight) and request them at the layer end, draining the ring once.
+    ChainLnbIn lnb[TS];
+#pragma unroll
+    for (int ps = 0; ps < TS; ++ps) { lnb[ps].y[0] = lnb[ps].y[1] = u32x4{0u, 0u, 0u, 0u}; lnb[ps].mu = 0.f; lnb[ps].rs = 0.f; }
+    auto lnb_fetch = [&](int endi_) __attribute__((always_inline)) {
+      const u32x4* er = reinterpret_cast<const u32x4*>(tab + END0 + endi_ * (int)sizeof(ChainEndK));
+      const u32x4 e1 = er[1], e2 = er[2], e3 = er[3];
+      const bf16_t* ly = reinterpret_cast<const bf16_t*>(sp(e3.z, e3.w));
+      const float* lmean = reinterpret_cast<const float*>(sp(e1.z, e1.w));
+      const float* lrstd = reinterpret_cast<const float*>(sp(e2.x, e2.y));
+      const int nout = sc(e2.w);
+#pragma unroll
+      for (int ps = 0; ps < TS; ++ps) {       // 16 rows per pass: this lane's row is 16 ps + 2 wave + (lane >> 5)
+        const int r = 16 * ps + 2 * wave + (lane >> 5);
         const long long gr = valid_of(r) ? grow_of(r) : 0;
         const bf16_t* q = ly + gr * nout + (lane & 31) * 8;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lnb.y[0]) : "v"(q) : "memory");
-        if (nout == 512) asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(lnb.y[1]) : "v"(q) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(lnb.mu) : "v"(lmean + gr) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(lnb.rs) : "v"(lrstd + gr) : "memory");
-        (void)e4;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lnb[ps].y[0]) : "v"(q) : "memory");
+        if (nout == 512) asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(lnb[ps].y[1]) : "v"(q) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lnb[ps].mu) : "v"(lmean + gr) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lnb[ps].rs) : "v"(lrstd + gr) : "memory");
       }
-    }
+    };
+    if (TS == 1 && endi >= 0 && sc(*reinterpret_cast<const unsigned*>(tab + END0 + endi * (int)sizeof(ChainEndK) + 52)) == 2) lnb_fetch(endi);
     stamp(3 + 3 * si);
 #define CH_SEG(MBv, KBv, NKTv) seg_body(std::integral_constant<int, MBv>{}, std::integral_constant<bool, KBv>{}, std::integral_constant<int, NKTv>{}, sg)
     if (!kb) {
@@ -597,15 +613,21 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       bf16_t* stash = reinterpret_cast<bf16_t*>(sp(e0.x, e0.y));
       const int ld_stash = sc(e2.z), nout = sc(e2.w);
       const int gb_off = sc(e3.x), has_ln = sc(e3.y);
-      if (TS == 1 && has_ln == 2) {
+      if (has_ln == 2) {
         stamp(100);
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(lnb.y[0]), "+v"(lnb.y[1]), "+v"(lnb.mu), "+v"(lnb.rs) : "n"(FLY) : "memory");
+        if constexpr (TS == 1) {
+          asm volatile("s_waitcnt vmcnt(%4)" : "+v"(lnb[0].y[0]), "+v"(lnb[0].y[1]), "+v"(lnb[0].mu), "+v"(lnb[0].rs) : "n"(FLY) : "memory");
+        } else {
+          lnb_fetch(endi);
+#pragma unroll
+          for (int ps = 0; ps < TS; ++ps)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(lnb[ps].y[0]), "+v"(lnb[ps].y[1]), "+v"(lnb[ps].mu), "+v"(lnb[ps].rs) : : "memory");
+        }
         stamp(101);
         const u32x4 e4 = er[4];
         const float lms = __uint_as_float((unsigned)sc(e4.x));
         bf16_t* dz = reinterpret_cast<bf16_t*>(sp(e0.z, e0.w));
         float* slab = reinterpret_cast<float*>(sp(e1.x, e1.y)) + (long long)blockIdx.x * 2 * nout;
-        const int r = 2 * wave + (lane >> 5);
         if (stash) {       // the raw panel (d out of the LayerNorm) first: the teacher-forced tests and g_fused callers read it
           const int nch = nout >> 3;
           for (int rr = wave; rr < rows_out; rr += 8) {
@@ -618,8 +640,27 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
           __builtin_amdgcn_s_barrier();
         }
         stamp(102);
-        if (nout == 512) chain_ln_bwd<8>(pout, img_out, reinterpret_cast<float*>(pin), wave, lane, tid, r, valid_of(r), grow_of(r), vec + gb_off, lnb, lms, dz, slab);
-        else chain_ln_bwd<4>(pout, img_out, reinterpret_cast<float*>(pin), wave, lane, tid, r, valid_of(r), grow_of(r), vec + gb_off, lnb, lms, dz, slab);
+        if (nout == 512) {
+          float gacc[16], bacc[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) gacc[e] = bacc[e] = 0.f;
+#pragma unroll
+          for (int ps = 0; ps < TS; ++ps) {
+            const int r = 16 * ps + 2 * wave + (lane >> 5);
+            chain_ln_bwd<8>(pout, img_out, lane, r, valid_of(r), grow_of(r), vec + gb_off, lnb[ps], lms, dz, gacc, bacc);
+          }
+          chain_ln_bwd_fold<8>(reinterpret_cast<float*>(pin), wave, lane, tid, gacc, bacc, slab);
+        } else {
+          float gacc[8], bacc[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gacc[e] = bacc[e] = 0.f;
+#pragma unroll
+          for (int ps = 0; ps < TS; ++ps) {
+            const int r = 16 * ps + 2 * wave + (lane >> 5);
+            chain_ln_bwd<4>(pout, img_out, lane, r, valid_of(r), grow_of(r), vec + gb_off, lnb[ps], lms, dz, gacc, bacc);
+          }
+          chain_ln_bwd_fold<4>(reinterpret_cast<float*>(pin), wave, lane, tid, gacc, bacc, slab);
+        }
         stamp(103);
       } else if (has_ln) {
         ChainLnOut o;
@@ -711,7 +752,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
       ChainEndK& e = k.end[nend];
       e.stash = s.stash; e.ld_stash = s.ld_stash; e.nout = s.nout;
       if (s.lnb_gamma) {
-        MMDEER_CHECK(!s.gamma && (s.nout == 256 || s.nout == 512) && blocks_out == 1 && ts == 1, "chain: LayerNorm backward of segment %d: width %d, one row group", i, s.nout);
+        MMDEER_CHECK(!s.gamma && (s.nout == 256 || s.nout == 512) && blocks_out == ts, "chain: LayerNorm backward of segment %d: width %d, one row group", i, s.nout);
         MMDEER_CHECK(s.lnb_y && s.lnb_mean && s.lnb_rstd && s.lnb_dz && s.lnb_partial && ((uintptr_t)s.lnb_gamma % 16) == 0 &&
                          ((uintptr_t)s.lnb_y % 16) == 0 && ((uintptr_t)s.lnb_dz % 16) == 0 && ((uintptr_t)s.lnb_partial % 16) == 0,
                      "chain: LayerNorm backward of segment %d: pointers / alignment", i);
