@@ -290,3 +290,14 @@ def test_compat_modules_resolve_by_bare_name():
                         "from complete_project import CompleteDEERModel\nimport mmdeer.stackb as S\nassert CompleteDEERModel is S.CompleteDEERModel"
                         % (ROOT, os.path.join(ROOT, "compat"))], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_option_table_matches_the_enum_order():
+    """csrc/options.h (enum OptId) and the name table of csrc/api.hip are two lists that must stay in the same order: an option
+    looked up by id would otherwise read its neighbour's value (it happened once: dw_tile read chain_max)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uncertainty-aware-multimodal-emotion-recognition_amd", "csrc")
+    enum = [e.lower() for e in re.findall(r"^\s+OPT_([A-Z0-9_]+)\b", open(os.path.join(root, "options.h")).read(), re.M) if e != "COUNT"]
+    table = re.findall(r'\{"([a-z0-9_]+)",\s*-?\d+,', open(os.path.join(root, "api.hip")).read())
+    assert enum == table and len(enum) >= 15

@@ -154,7 +154,7 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
 struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
 OptEntry g_opts[OPT_COUNT] = {
     {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
-    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"chain_min", 2049, {2049}}, {"dw_tile", 2, {2}}, {"dw_kg", 2, {2}}, {"splitk_max", 8, {8}},
+    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"chain_min", 2049, {2049}}, {"dw_tile", 2, {2}}, {"dw_kg", 2, {2}}, {"chain_max", 8192, {8192}}, {"splitk_max", 8, {8}},
 };
 }  // namespace
 
@@ -517,7 +517,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   // whatever the batch: worth it while the chip holds all workgroups at once and most CUs have one (measured per step: B = 4096
   // -5 to -15 us depending on the box, 3072 -4 us, 2048 0, 1024 +1 us, 64 +12 us; 16-sample workgroups in two rounds at 8192:
   // +9 us, 32-sample workgroups: see DESIGN.md)
-  const bool chains = !f32 && opt(OPT_CHAIN) && B >= opt(OPT_CHAIN_MIN) && B <= 8192;
+  const bool chains = !f32 && opt(OPT_CHAIN) && B >= opt(OPT_CHAIN_MIN) && B <= opt(OPT_CHAIN_MAX);
   // F2-F6 are local to a sample (the AV "attention" has one key per query: softmax == 1, only the value and output projections
   // remain): in bf16 mode ONE launch walks them with the rows resident in LDS (chain.hip).  A workgroup holds the video and the
   // audio row of its 16 samples as two row groups; torch.cat of the two attention outputs is a re-view of the panel.
@@ -740,7 +740,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // backward chains (chain.hip): the head / trimodal run always when enabled; the audio-visual run only in the single-call mode
   // (in the two-call mode its first product, the token-0 dX, belongs to the first call)
   const int bmin = opt(OPT_CHAIN_MIN) >= 2049 ? 2561 : opt(OPT_CHAIN_MIN);   // the backward chains pay later than the forward's: B = 2048 +5 us, 3072 -1 us
-  const bool dchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= 8192 && phase == 0;
+  const bool dchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= opt(OPT_CHAIN_MAX) && phase == 0;
   auto flush = [&](int bucket, bool last) -> int {
     if (!last) return 0;
     if (dwg.nprob > 0) {
@@ -764,7 +764,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // B2-B10 are local to a sample like the forward's layers: in bf16 mode (B <= 4096, no outside gradient on fused_features)
   // ONE launch of the layer-chain kernel walks the head's four dX products, both LayerNorm backwards and the three trimodal dX
   // products with the rows resident in LDS, and writes the same workspace buffers (the weight-gradient launch reads them)
-  const bool bchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= 8192 && !a->g_fused;
+  const bool bchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= opt(OPT_CHAIN_MAX) && !a->g_fused;
   if (bchain) {
     ChainArgs c{};
     c.X = reinterpret_cast<const bf16_t*>(L.dz2); c.ldx = 3 * EV2; c.K0 = 3 * EV2; c.B = B; c.groups = 1; c.group_stride = 0;

@@ -24,6 +24,7 @@ enum OptId {
   OPT_CHAIN_MIN,        // smallest batch that takes the chains (default 2049; the backward chain from 2561; tests lower it)
   OPT_DW_TILE,          // GemmTile of the weight-gradient launch: 2 = 128x128 tiles without split-K (default), 3 = 256x256 + split-K slabs, 4 = 256x128
   OPT_DW_KG,            // 128x128 weight-gradient tiles: 2 = the workgroup's halves split each 64-row stage of K (default), 1 = 32-row stages
+  OPT_CHAIN_MAX,        // largest batch that takes the chains
   OPT_SPLITK_MAX,       // largest number of split-K slices of a weight-gradient problem (slabs: 4 B per parameter per slice)
   OPT_COUNT
 };
