@@ -761,7 +761,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // B1: last head layer + NIG activations (+ loss gradient)
   TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->targets ? a->global_stats : nullptr, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
                      L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
-  // B2-B10 are local to a sample like the forward's layers: in bf16 mode (B <= 4096, no outside gradient on fused_features)
+  // B2-B10 are local to a sample like the forward's layers: in bf16 mode (chain_min <= B <= chain_max, no outside gradient on fused_features)
   // ONE launch of the layer-chain kernel walks the head's four dX products, both LayerNorm backwards and the three trimodal dX
   // products with the rows resident in LDS, and writes the same workspace buffers (the weight-gradient launch reads them)
   const bool bchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= opt(OPT_CHAIN_MAX) && !a->g_fused;

@@ -40,7 +40,8 @@
 // stage loop, 128 KiB in flight) ran at 22 B/clk/CU -- a 16-lane x 64-byte request pattern instead of the DMA's full lines --
 // and was 30 us slower per step; (5) running a tile's epilogue inside the first stage of the next tile, behind that stage's DMA
 // issue, so that the ring never waits for the epilogue: 2 us per step slower.  One workgroup per 16 rows also means the launch only pays while the chip holds all
-// workgroups at once: api.hip uses the chains for B <= 4096 and the separate launches above.
+// workgroups at once: api.hip uses 16-sample workgroups for B <= 4096, 32-sample workgroups (TS = 2) up to 8192 and the separate
+// launches above (and below ~2000 rows, where most CUs would have no workgroup).
 //
 // Backward chains (dX = dY W through the packed W^T copies) use the same kernel: a segment's epilogue can multiply by the
 // (Y > 0) * scale mask of the forward layer below (four mask values per lane, requested by an untracked asm load before the
@@ -305,7 +306,7 @@ __device__ __forceinline__ void chain_ln_bwd_fold(float* red, int wave, int lane
 
 // NST ring slots of 16 KiB (NST - 1 stages in flight), VECF floats of bias / gamma / beta.  Instantiated as <6, 4864>; a
 // seven-slot ring for the chains with few vectors (<7, 2560>, 156 KiB of LDS) was 4-5 us per step SLOWER on the same box.
-// TS = 1: 16 samples per workgroup (B <= 4096: one round of 256 workgroups); TS = 2: 32 samples (forward chains of 4096 < B <= 8192:
+// TS = 1: 16 samples per workgroup (B <= 4096: one round of 256 workgroups); TS = 2: 32 samples (4096 < B <= 8192:
 // twice the rows per streamed weight byte; the two 32-KiB panels leave four ring slots).
 template <int NST, int VECF, int TS>
 __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
