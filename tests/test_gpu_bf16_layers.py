@@ -63,7 +63,7 @@ class Report:
         assert err <= tol, (name, err)
 
 
-@pytest.mark.parametrize("B,dropout", [(4096, 0.3), (515, 0.3), (256, 0.0)])
+@pytest.mark.parametrize("B,dropout", [(4096, 0.3), (515, 0.3), (256, 0.0), (8192, 0.3)])   # 8192: the 32-sample chain workgroups
 def test_every_launch_of_a_bf16_step_on_its_own_inputs(B, dropout):
     p = dropout
     b = {k: torch.from_numpy(v) for k, v in synth.make_batch(B, seed=42).items()}
