@@ -5,6 +5,7 @@ Tolerances: fp32 config <= 1e-4 abs on mu / nu / alpha / beta (BASELINE north st
 bf16 config gated on CCC >= 0.999 and a documented absolute band (SURVEY 7 "hard parts").
 """
 import json
+import math
 import os
 
 import numpy as np
@@ -387,6 +388,28 @@ def test_weight_gradient_and_launch_plan_options_agree(opts):
     else:
         assert other[0] == pytest.approx(base[0], rel=1e-4)
         assert rel < 2e-2, rel
+
+
+@pytest.mark.parametrize("B,opts", [(300, {}), (300, dict(chain_min=1)), (5000, {}), (5000, dict(chain=0)), (8192, {})])
+def test_training_step_reads_nothing_stale_from_the_workspace(B, opts):
+    """Every workspace buffer a step reads is written earlier in the same step -- in particular the per-workgroup partial slabs the
+    fold sums (a layer chain over 4096 < B < 8192 samples runs fewer workgroups than the LayerNorm-backward kernel it replaces:
+    the fold must take the chain's count).  The workspace is filled with NaN bit patterns before the step; the step must come out
+    bit for bit as on a fresh model."""
+    b = synth.make_batch(B, seed=23)
+    a, v, t, y = (torch.from_numpy(b[k]).to(DEV) for k in ("audio", "video", "text", "targets"))
+    res = []
+    for poison in (False, True):
+        m = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=8)).to(DEV).train()
+        with _lib.options(**opts):
+            if poison:
+                m._workspace(B, torch.device(DEV)).fill_(0xFF)
+            d = m.train_step(a, v, t, y)
+            torch.cuda.synchronize()
+        res.append((float(d["total_loss"]), m.flat_grad().clone()))
+    assert math.isfinite(res[1][0]) and res[0][0] == res[1][0]
+    assert bool(torch.isfinite(res[1][1]).all())
+    assert torch.equal(res[0][1], res[1][1])
 
 
 def test_eval_forward_with_chains_is_bit_identical():

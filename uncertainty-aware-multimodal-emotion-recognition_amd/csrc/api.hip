@@ -129,7 +129,8 @@ Layout make_layout(void* base, void* wbase, int B, int f32) {
   L.dpool = act(Bz, FUS); L.dobar = act(Bz, FUS); L.dqkv = act(2 * Bz, 3 * FUS); L.dxtok = act(2 * Bz, FUS);
   L.dav = act(Bz, INTER); L.dz_a2 = act(Bz, INTER); L.dcats = act(2 * Bz, INTER); L.davv = act(2 * Bz, INTER);
   L.davin = act(2 * Bz, INTER);
-  const size_t np = (size_t)ln_bwd_nparts(B);
+  // LayerNorm-backward partial slabs: one per workgroup of ln_bwd_kernel, or of the layer chain that ran instead (more above 8192)
+  const size_t np = (size_t)(ln_bwd_nparts(B) > chain_workgroups(B) ? ln_bwd_nparts(B) : chain_workgroups(B));
   L.part_ln_o1 = f32buf(np * 2 * FUS); L.part_ln_t3 = f32buf(np * 2 * FUS); L.part_ln_a2 = f32buf(np * 2 * INTER);
   L.part_w3 = f32buf(nblk * 3 * 256); L.part_b3 = f32buf(nblk * 3 * 4);
   L.slab = f32buf((size_t)SPLITK_MAX * MMDEER_FLAT_ELEMS);
@@ -720,9 +721,10 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     }
     t.nseg = k;
   };
-  auto reduce_ln = [&](ReduceTable& t, const float* part, int pidG, int N) {
+  // `chained`: the partial slabs were written by a layer chain, one per workgroup of ITS grid (32-sample workgroups above B = 4096)
+  auto reduce_ln = [&](ReduceTable& t, const float* part, int pidG, int N, bool chained) {
     int k = t.nseg;   // gamma and beta slices are adjacent in the flat buffer (N is a multiple of 64)
-    t.src[k] = part; t.dst[k] = G + kParams[pidG].off; t.nparts[k] = npl; t.n[k] = 2 * N; t.stride[k] = 2 * N; ++k;
+    t.src[k] = part; t.dst[k] = G + kParams[pidG].off; t.nparts[k] = chained ? chain_workgroups(B) : npl; t.n[k] = 2 * N; t.stride[k] = 2 * N; ++k;
     t.nseg = k;
   };
   // All weight-gradient problems are collected and run as ONE launch after the chain: a bucket on its own has
@@ -857,8 +859,8 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     add_dw(X.dw(L.dqkv, 3 * FUS, L.xtok, f32, FUS, P_TIN_W, P_TIN_B, G, 2 * B));
     add_dw(X.dw(L.dxtok, 2 * FUS, L.av, f32, INTER, P_AVP_W, P_AVP_B, G, B));                          // token 0
     add_dw(X.dw(L.dxtok + (size_t)FUS * es, 2 * FUS, a->text, in_f32, TXT, P_TXT_W, P_TXT_B, G, B));   // token 1
-    reduce_ln(rt, L.part_ln_o1, P_OP_G, FUS);
-    reduce_ln(rt, L.part_ln_t3, P_TFF_G, FUS);
+    reduce_ln(rt, L.part_ln_o1, P_OP_G, FUS, bchain);
+    reduce_ln(rt, L.part_ln_t3, P_TFF_G, FUS, bchain);
   }
   TRY(flush(1, phase == 1));
   if (phase == 1) return 0;
@@ -939,7 +941,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     add_dw(X.dw(L.davin, INTER, a->video, in_f32, VID, P_VID_W, P_VID_B, G, B));                                  // rows [0,B)
     if (f32) add_dw(X.dw(L.davin + (size_t)B * INTER * es, INTER, a->audio, in_f32, AUD, P_AUD_W, P_AUD_B, G, B));   // rows [B,2B)
     else add_dw(X.dw(L.davin + (size_t)B * INTER * es, INTER, L.audio_pad, 0, AUD_PAD, P_AUD_W, P_AUD_B, G, B));    // padded copy of F0
-    reduce_ln(rt, L.part_ln_a2, P_AVF_G, INTER);
+    reduce_ln(rt, L.part_ln_a2, P_AVF_G, INTER, dchain);
   }
   // ---- default: all weight gradients in one grouped split-K launch + one deterministic fold of every partial slab
   TRY(flush(2, true));

@@ -61,6 +61,11 @@ struct ChainArgs {
   ChainSeg seg[CHAIN_MAX_SEGS];
 };
 
+// Grid of a chain over B samples: 16-sample workgroups up to B = 4096, 32-sample workgroups above (one LayerNorm-backward
+// partial slab per workgroup).
+inline int chain_samples_per_workgroup(int B) { return B > 4096 ? 32 : 16; }
+inline int chain_workgroups(int B) { const int m = chain_samples_per_workgroup(B); return (B + m - 1) / m; }
+
 void chain_seg_defaults(ChainSeg& s);
 // Validates shapes / alignment, derives the kernel's tables and enqueues the chain on `stream`.
 int launch_chain(const ChainArgs& a, hipStream_t stream);

@@ -725,7 +725,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   k.X = a.X; k.ldx = a.ldx; k.K0 = a.K0; k.B = a.B; k.groups = a.groups; k.group_stride = a.group_stride; k.drop = a.drop;
   k.stamps = a.stamps;
   int vec = 0, nend = 0, nvec = 0;
-  const int ts = a.B > 4096 ? 2 : 1;       // 16-sample blocks per workgroup
+  const int ts = chain_samples_per_workgroup(a.B) / 16;       // 16-sample blocks per workgroup
   int blocks_in = a.groups * ts, width_in = a.K0, layer_first_seg = 0;
   auto add_vec = [&](const float* src, int n) { ChainVecK& v = k.vec[nvec++]; v.src = src; v.off = vec; v.n4 = n / 4; vec += n; return v.off; };
   for (int i = 0; i < a.nseg; ++i) {
@@ -792,8 +792,8 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   MMDEER_CHECK(a.seg[a.nseg - 1].end_layer, "chain: the last segment must end its layer");
   MMDEER_CHECK(vec <= CHAIN_VEC_FLOATS, "chain: %d bias / gamma / beta floats exceed the LDS area (%d)", vec, CHAIN_VEC_FLOATS);
   k.nseg = a.nseg; k.nvec = nvec;
-  if (ts == 1) hipLaunchKernelGGL((chain_kernel<6, CHAIN_VEC_FLOATS, 1>), dim3((a.B + 15) / 16), dim3(512), 0, stream, k);
-  else hipLaunchKernelGGL((chain_kernel<4, CHAIN_VEC_FLOATS, 2>), dim3((a.B + 31) / 32), dim3(512), 0, stream, k);
+  if (ts == 1) hipLaunchKernelGGL((chain_kernel<6, CHAIN_VEC_FLOATS, 1>), dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
+  else hipLaunchKernelGGL((chain_kernel<4, CHAIN_VEC_FLOATS, 2>), dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
