@@ -412,6 +412,29 @@ def test_training_step_reads_nothing_stale_from_the_workspace(B, opts):
     assert torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("B,dtype", [(5000, "bf16"), (4096, "bf16"), (200, "fp32")])
+def test_two_call_backward_reads_nothing_stale_from_the_workspace(B, dtype):
+    """The same for the data-parallel overlap plan (mmdeer_backward phase 1, then 2) and for the fp32 configuration."""
+    b = synth.make_batch(B, seed=29)
+    a, v, t, y = (torch.from_numpy(b[k]).to(DEV) for k in ("audio", "video", "text", "targets"))
+    res = []
+    for poison in (False, True):
+        m = MultimodalDEER(ModelConfig(compute_dtype=dtype, seed=8)).to(DEV).train()
+        m.train_step(a, v, t, y)                      # allocates the workspace, packs the weights
+        if poison:
+            m._workspace(B, torch.device(DEV)).fill_(0xFF)
+        o = m._launch_forward(a, v, t, y, want_features=False)
+        meta = o["_meta"]
+        flat = torch.zeros_like(m.flat_grad())
+        loss = torch.empty(20, device=DEV)
+        m._launch_backward(meta, meta["targets"], loss_out=loss, flat=flat, want_views=False, phase=1)
+        m._launch_backward(meta, meta["targets"], loss_out=loss, flat=flat, want_views=False, phase=2)
+        torch.cuda.synchronize()
+        res.append((loss.clone(), flat.clone()))
+    assert bool(torch.isfinite(res[1][0]).all()) and bool(torch.isfinite(res[1][1]).all())
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_eval_forward_with_chains_is_bit_identical():
     """The inference path takes the forward chains as well (no dropout: every site is off): all outputs of forward() in eval mode
     must equal the separate-launch plan's bit for bit, also on a ragged batch."""
