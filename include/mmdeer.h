@@ -79,6 +79,7 @@ size_t mmdeer_weights_bytes(int compute_f32);
  *                      of the forward and, with chain_bwd (1), the head / trimodal and the audio-visual dX runs of the backward as
  *                      one launch each
  *   chain_min (2049)   smallest batch that takes the chains (the backward chain from 2561)
+ *   chain_nig (1)      0: the head's last-layer backward + loss gradient as a launch of their own also when the backward chain runs
  *   dw_tile (2)        weight-gradient launch: 2 = 128x128 tiles, K-slices of B rows (no split-K slabs for the B-row problems),
  *                      3 = 256x256 tiles + split-K slabs, 4 = 256x128 tiles; dw_kg (2): 1 = the 128x128 kernel on 32-row K stages
  *   xcd, nt128, nt192, glds, nt8 (1), t128 (512), tile (-1), ksteps (0), splitk_max (8)   GEMM tile / split-K selection

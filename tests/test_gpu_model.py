@@ -366,8 +366,26 @@ def test_backward_chain_matches_the_separate_launches(B):
     assert rel < 2e-2 and cos > 0.9998, (rel, cos)       # measured: see DESIGN.md
 
 
+@pytest.mark.parametrize("B", [300, 4096, 5000, 8192])
+def test_head_backward_in_the_chain_prologue_matches_its_own_launch(B):
+    """Option chain_nig: the backward chain computes the head's last-layer backward and the loss gradient in its prologue instead
+    of reading what nig_bwd_kernel left (one launch fewer).  Same arithmetic per (sample, dimension): the loss record, d e2 and so
+    every gradient upstream come out bit for bit; only dW3 / db3 of the three heads' last layers are summed over other partial
+    blocks (16- or 32-sample workgroups instead of 64-sample ones)."""
+    from mmdeer.spec import param_offsets
+    lo = min(o for (name, _s, _i), o in zip(param_table(), param_offsets()[0]) if ".evidence_net.6." in name)
+    on, off = _chain_step(B, chain_nig=1), _chain_step(B, chain_nig=0)
+    assert on[0] == off[0]
+    for k in on[2]:
+        assert torch.equal(on[2][k], off[2][k]), k
+    assert torch.equal(on[1][:lo], off[1][:lo])
+    assert not torch.equal(on[1][lo:], off[1][lo:])       # the other plan really ran
+    d = (on[1][lo:].double() - off[1][lo:].double()).norm() / off[1][lo:].double().norm()
+    assert float(d) < 1e-5, float(d)
+
+
 @pytest.mark.parametrize("opts", [dict(dw_tile=3), dict(dw_tile=4), dict(dw_kg=1), dict(ln_fused=0, chain=0), dict(chain=0, dw_tile=3),
-                                  dict(splitk_max=2), dict(ksteps=8)])
+                                  dict(splitk_max=2), dict(ksteps=8), dict(chain_nig=0)])
 def test_weight_gradient_and_launch_plan_options_agree(opts):
     """Every launch plan the options select computes the same training step: the weight-gradient kernel on 128x128 tiles (default,
     K-slices of B rows, the workgroup's halves splitting 64-row stages), 256x256 tiles with split-K slabs (rounds 1-2), 256x128

@@ -132,7 +132,8 @@ Layout make_layout(void* base, void* wbase, int B, int f32) {
   // LayerNorm-backward partial slabs: one per workgroup of ln_bwd_kernel, or of the layer chain that ran instead (more above 8192)
   const size_t np = (size_t)(ln_bwd_nparts(B) > chain_workgroups(B) ? ln_bwd_nparts(B) : chain_workgroups(B));
   L.part_ln_o1 = f32buf(np * 2 * FUS); L.part_ln_t3 = f32buf(np * 2 * FUS); L.part_ln_a2 = f32buf(np * 2 * INTER);
-  L.part_w3 = f32buf(nblk * 3 * 256); L.part_b3 = f32buf(nblk * 3 * 4);
+  const size_t nhead = nblk > (size_t)chain_workgroups(B) ? nblk : (size_t)chain_workgroups(B);   // nig_bwd_kernel's blocks, or the chain's workgroups
+  L.part_w3 = f32buf(nhead * 3 * 256); L.part_b3 = f32buf(nhead * 3 * 4);
   L.slab = f32buf((size_t)SPLITK_MAX * MMDEER_FLAT_ELEMS);
   L.bytes = off;
   return L;
@@ -155,7 +156,7 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
 struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
 OptEntry g_opts[OPT_COUNT] = {
     {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
-    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"chain_min", 2049, {2049}}, {"dw_tile", 2, {2}}, {"dw_kg", 2, {2}}, {"chain_max", 8192, {8192}}, {"splitk_max", 8, {8}},
+    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"chain_min", 2049, {2049}}, {"dw_tile", 2, {2}}, {"dw_kg", 2, {2}}, {"chain_max", 8192, {8192}}, {"chain_nig", 1, {1}}, {"splitk_max", 8, {8}},
 };
 }  // namespace
 
@@ -713,11 +714,11 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   // Backward = a chain of dX GEMMs (each M = batch rows, plenty of tiles) and ONE grouped launch of all
   // weight-gradient problems (few output tiles each, reduction over the batch, split over K into slabs) followed by
   // one deterministic slab reduction.
-  auto reduce_head = [&](ReduceTable& t) {
+  auto reduce_head = [&](ReduceTable& t, int nparts) {
     int k = t.nseg;
-    t.src[k] = L.part_w3; t.dst[k] = G + kParams[P_EV2_W].off; t.nparts[k] = nblk; t.n[k] = 768; t.stride[k] = 768; ++k;
+    t.src[k] = L.part_w3; t.dst[k] = G + kParams[P_EV2_W].off; t.nparts[k] = nparts; t.n[k] = 768; t.stride[k] = 768; ++k;
     for (int d = 0; d < 3; ++d) {
-      t.src[k] = L.part_b3 + d * 4; t.dst[k] = G + kParams[P_EV2_B + d].off; t.nparts[k] = nblk; t.n[k] = 4; t.stride[k] = 12; ++k;
+      t.src[k] = L.part_b3 + d * 4; t.dst[k] = G + kParams[P_EV2_B + d].off; t.nparts[k] = nparts; t.n[k] = 4; t.stride[k] = 12; ++k;
     }
     t.nseg = k;
   };
@@ -760,13 +761,16 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
 
   if (phase != 2) {
   // ================= bucket 0: DEER head =================
-  // B1: last head layer + NIG activations (+ loss gradient)
-  TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->targets ? a->global_stats : nullptr, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
-                     L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
+  // B1: last head layer + NIG activations (+ loss gradient): a launch of its own, or (bf16 chain plan, loss mode, option chain_nig)
+  // the prologue of the backward chain below -- the head kernel is 8 us of mostly fixed launch cost at B = 4096
+  const bool bchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= opt(OPT_CHAIN_MAX) && !a->g_fused;
+  const bool nigfold = bchain && opt(OPT_CHAIN_NIG) && a->targets;
+  if (!nigfold)
+    TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->targets ? a->global_stats : nullptr, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
+                       L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
   // B2-B10 are local to a sample like the forward's layers: in bf16 mode (chain_min <= B <= chain_max, no outside gradient on fused_features)
   // ONE launch of the layer-chain kernel walks the head's four dX products, both LayerNorm backwards and the three trimodal dX
   // products with the rows resident in LDS, and writes the same workspace buffers (the weight-gradient launch reads them)
-  const bool bchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= opt(OPT_CHAIN_MAX) && !a->g_fused;
   if (bchain) {
     ChainArgs c{};
     c.X = reinterpret_cast<const bf16_t*>(L.dz2); c.ldx = 3 * EV2; c.K0 = 3 * EV2; c.B = B; c.groups = 1; c.group_stride = 0;
@@ -800,6 +804,14 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     c.seg[k++] = dxseg(P_TFF_W, FUS, FUS, L.dpool, nullptr, 0);
     c.seg[k++] = dxseg(P_TOUT_W, FUS, FUS, L.dobar, nullptr, 0);         // attention out_proj (pooled context)
     c.nseg = k;
+    if (nigfold) {
+      ChainNig& g = c.nig;
+      g.enabled = 1;
+      g.e2 = reinterpret_cast<const bf16_t*>(L.e2); g.w3 = reinterpret_cast<const bf16_t*>(X.W(P_EV2_W)); g.evid = L.evid;
+      g.targets = a->targets; g.stats = L.stats; g.gstats = a->global_stats; g.nblk = nblk;
+      g.dz2 = reinterpret_cast<bf16_t*>(L.dz2); g.partial_w = L.part_w3; g.partial_b = L.part_b3;
+      g.loss_out = a->loss_out; g.bin_counts = a->bin_counts; g.mask_scale = X.mask_scale; g.cfg = cfg;
+    }
 #ifdef MMDEER_STAMPS
     c.stamps = reinterpret_cast<unsigned long long*>(L.davin);   // diagnostic library: untouched until phase 2 (tools/chain_stamps.py bwd)
 #endif
@@ -833,7 +845,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     add_dw(r);
     add_dw(X.dw(L.dh2, HID, L.h1, f32, HID, P_FP1_W, P_FP1_B, G, B));
     add_dw(X.dw(L.dh1, HID, L.fused, f32, FUS, P_FP0_W, P_FP0_B, G, B));
-    reduce_head(rt);
+    reduce_head(rt, nigfold ? chain_workgroups(B) : nblk);
   }
   TRY(flush(0, false));
 

@@ -2,6 +2,7 @@
 // Linear (+ReLU +Dropout) (+LayerNorm) layers with the activations resident in LDS; only the weights stream.
 #pragma once
 #include "common.h"
+#include "nig.h"
 
 namespace mmdeer {
 
@@ -48,6 +49,28 @@ struct ChainSeg {
   float lnb_mask_scale;    // > 0: the (y > 0) * scale mask of the Linear-ReLU-Dropout in front of the LayerNorm
 };
 
+// Backward chains only: the chain's input rows are not read but COMPUTED in the prologue -- the backward of the head's last layer
+// (64 -> 4 per emotion dimension), NIG activations and MultiTaskDEERLoss, i.e. what nig_bwd_kernel (nig.hip) does in a launch of
+// its own: d e2 = d evidence . W3 masked by (e2 > 0) goes into the input panel (and to `dz2`, which the weight-gradient launch
+// reads), the workgroup's partial of dW3 / db3 to partial_w / partial_b [workgroup][3][4][64] / [workgroup][3][4].
+struct ChainNig {
+  int enabled;
+  const bf16_t* e2;        // [B][192] forward activations of the heads' second layers
+  const bf16_t* w3;        // [3][4][64] packed last-layer weights
+  const float* evid;       // [B][3][4] raw evidence of the forward
+  const float* targets;    // [B][3]
+  const float* stats;      // [nblk][3][NIG_NSTAT] block partials of the forward's loss statistics
+  const float* gstats;     // optional: the global batch's statistics instead (exact-global data-parallel mode)
+  int nblk;
+  bf16_t* dz2;             // [B][192]
+  float* partial_w;
+  float* partial_b;
+  float* loss_out;         // NIG_LOSS_OUT floats, written by workgroup 0
+  int* bin_counts;         // [3][10] or null
+  float mask_scale;
+  LossCfg cfg;
+};
+
 // Host-side description of a chain (api.hip fills it; launch_chain() validates it and derives the kernel's tables).
 struct ChainArgs {
   const bf16_t* X;         // chain input [rows][ldx]
@@ -58,6 +81,7 @@ struct ChainArgs {
   int nseg;
   DropCtx drop;
   unsigned long long* stamps;   // diagnostic builds (-DMMDEER_STAMPS) only: cycle-counter samples of workgroup 0; else null
+  ChainNig nig;            // enabled: X is unused, K0 = ldx = 192, groups = 1
   ChainSeg seg[CHAIN_MAX_SEGS];
 };
 

@@ -57,6 +57,7 @@
 #include "gemm_kernel.inc"
 #include "chain.h"
 #include "options.h"
+#include "nig_dev.h"
 
 namespace mmdeer {
 namespace {
@@ -118,6 +119,7 @@ struct ChainKArgs {
   ChainSegK seg[CHAIN_MAX_SEGS];
   ChainEndK end[CHAIN_MAX_ENDS];
   ChainVecK vec[CHAIN_MAX_VECS];
+  ChainNig nig;      // behind the tables: not copied to LDS, read as kernel arguments
 };
 static_assert(__builtin_offsetof(ChainKArgs, seg) % 16 == 0, "tables must be 16-byte aligned");
 static_assert(sizeof(ChainKArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -307,6 +309,98 @@ __device__ __forceinline__ void chain_ln_bwd_fold(float* red, int wave, int lane
   }
 }
 
+// The head's last-layer backward as the prologue of a backward chain (ChainNig, chain.h): the arithmetic of nig_bwd_kernel
+// (nig.hip) on this workgroup's MS samples.  The LAST 3 MS / 16 waves own one (16-row block, dimension) each, four lanes per
+// (sample, dimension) as in the stand-alone kernel, so d e2 comes out bit for bit the same; it is written to the input panel
+// (bf16, the layout the DMA path produces: chunk c of row r in slot c ^ (r & 7) of image d) and to global memory.  Those waves
+// work through the transcendental part of the loss terms while the FIRST waves fetch and sum the batch statistics
+// (compute_finals); the barriers wait for LDS only, never for the stores to memory.
+// `scratch`: >= MS * 195 floats of LDS nobody uses before the first segment's epilogue (the output panel).
+template <int MS>
+__device__ __forceinline__ void chain_nig_head(const ChainNig& g, unsigned char* pin, float* scratch, int row0, int B, int tid, unsigned long long* stp) {
+#ifdef MMDEER_STAMPS
+#define NSTAMP(i) do { if (stp && blockIdx.x == 0 && tid == 0) stp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NSTAMP(i) do {} while (0)
+#endif
+  NSTAMP(110);
+  __shared__ float gs[3][NIG_NSTAT];
+  __shared__ f32x4 sdE[MS * 3];
+  __shared__ Finals F;
+  const int wave = tid >> 6, lane = tid & 63, q = lane & 3;
+  const int qw = wave - (8 - 3 * (MS / 16));
+  const bool quad_on = qw >= 0;
+  const int d = quad_on ? qw % 3 : 0;
+  const int r = quad_on ? 16 * (qw / 3) + (lane >> 2) : 0;
+  const int b = row0 + r;
+  const bool active = quad_on && b < B;
+  const int bc = b < B ? b : B - 1;
+  const long long o = (long long)bc * 3 + d;
+  // only the quad waves load and do the arithmetic (a wave-uniform branch): eight waves doing it would share four SIMDs
+  float w[4][16], x[16];
+  f32x4 ev{0.f, 0.f, 0.f, 0.f};
+  float y = 0.f;
+  Nig n{0.f, 1.f, 2.f, 1.f};
+  Terms t{};
+  if (quad_on) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) load_chunk16<false>(g.w3, d * 256 + c * 64 + q * 16, w[c]);
+    load_chunk16<false>(g.e2, (long long)bc * 192 + d * 64 + q * 16, x);
+    ev = *reinterpret_cast<const f32x4*>(g.evid + o * 4);
+    y = g.targets[o];
+    n = nig_act(ev);
+    t = loss_terms(n, y);
+  }
+  const int stat_n = g.gstats ? (int)g.gstats[3 * NIG_NSTAT] : B;
+  NSTAMP(111);
+  compute_finals(g.gstats ? g.gstats : g.stats, g.gstats ? 1 : g.nblk, stat_n, g.cfg, F, gs);
+  NSTAMP(112);
+  if (blockIdx.x == 0 && tid == 0) write_loss(F, g.loss_out, g.bin_counts);
+  if (quad_on) {
+    const f32x4 gr = loss_grad(n, t, d, stat_n, g.cfg, F);
+    f32x4 dE{gr.x, gr.y * softplus_grad(ev.y), gr.z * softplus_grad(ev.z), gr.w * softplus_grad(ev.w)};
+    if (!active) dE = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dz[16];
+    float* xt = scratch + r * 195 + d * 64 + q * 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      xt[j] = active ? x[j] : 0.f;
+      const float v = nig_dx(dE, w[0][j], w[1][j], w[2][j], w[3][j]);
+      dz[j] = x[j] > 0.f ? v * g.mask_scale : 0.f;
+    }
+    if (active) store_chunk16<false>(g.dz2, (long long)b * 192 + d * 64 + q * 16, dz);
+    unsigned char* prow = pin + d * (MS * 128) + (r >> 3) * 1024 + (r & 7) * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      *reinterpret_cast<nig_u32x4*>(prow + (((2 * q + h) ^ (r & 7)) * 16)) =
+          nig_u32x4{pack_bf2(dz[8 * h], dz[8 * h + 1]), pack_bf2(dz[8 * h + 2], dz[8 * h + 3]), pack_bf2(dz[8 * h + 4], dz[8 * h + 5]),
+                    pack_bf2(dz[8 * h + 6], dz[8 * h + 7])};
+    if (q == 0) sdE[r * 3 + d] = dE;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  NSTAMP(114);
+  // this workgroup's partial of dW3[d][c][j] = sum_s dE[s][d][c] * e2[s][64 d + j] and of db3[d][c]
+  for (int e = tid; e < 768; e += 512) {
+    const int dd = e >> 8, c = (e >> 6) & 3, j = e & 63;
+    const float* sde = reinterpret_cast<const float*>(sdE) + dd * 4 + c;
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < MS; s += 2) {
+      acc0 = fmaf(sde[12 * s], scratch[s * 195 + dd * 64 + j], acc0);
+      acc1 = fmaf(sde[12 * s + 12], scratch[(s + 1) * 195 + dd * 64 + j], acc1);
+    }
+    g.partial_w[(long long)blockIdx.x * 768 + e] = acc0 + acc1;
+  }
+  if (tid < 12) {
+    const float* sde = reinterpret_cast<const float*>(sdE) + tid;     // tid = 4 d + c
+    float bs = 0.f;
+    for (int s = 0; s < MS; ++s) bs += sde[12 * s];
+    g.partial_b[(long long)blockIdx.x * 12 + tid] = bs;
+  }
+  // no barrier here: the caller's prologue barrier follows, and the scratch area is next written by the first segment's epilogue
+}
+
 // NST ring slots of 16 KiB (NST - 1 stages in flight), VECF floats of bias / gamma / beta.  Instantiated as <6, 4864>; a
 // seven-slot ring for the chains with few vectors (<7, 2560>, 156 KiB of LDS) was 4-5 us per step SLOWER on the same box.
 // TS = 1: 16 samples per workgroup (B <= 4096: one round of 256 workgroups); TS = 2: 32 samples (4096 < B <= 8192:
@@ -353,7 +447,8 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
 
   // ---- input panel
   int rows_in = a.groups * MS;
-  {
+  const bool nig_in = a.nig.enabled != 0;      // the input rows are computed below (the head's last-layer backward), not read
+  if (!nig_in) {
     const int rg = rows_in >> 3, np = (a.K0 >> 6) * rg;
     const int img = rows_in * 128;
     for (int q = wave; q < np; q += 8) {
@@ -438,6 +533,12 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
   p_load();
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t) issue(t);
+  // backward head chain: the input rows are computed while the vectors and the ring's first stages are in flight (its loads and
+  // stores are younger than those DMAs: the counted waits below can only become stricter by them)
+  if (nig_in) {
+    chain_nig_head<MS>(a.nig, lds, reinterpret_cast<float*>(lds + PAN), row0, B, tid, a.stamps);
+    stamp(115);
+  }
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FLY) : "memory");   // the vectors (and anything older) have landed; the ring's
   __builtin_amdgcn_s_barrier();                                           // first stages are waited for stage by stage in the loop
   stamp(2);
@@ -718,12 +819,23 @@ void chain_seg_defaults(ChainSeg& s) {
 
 int launch_chain(const ChainArgs& a, hipStream_t stream) {
   MMDEER_CHECK(a.nseg >= 1 && a.nseg <= CHAIN_MAX_SEGS, "chain: 1..%d segments (got %d)", CHAIN_MAX_SEGS, a.nseg);
-  MMDEER_CHECK(a.B > 0 && a.X && ((uintptr_t)a.X % 16) == 0 && a.ldx % 8 == 0, "chain: input rows must be 16-byte aligned");
+  if (a.nig.enabled) {
+    const ChainNig& g = a.nig;
+    MMDEER_CHECK(a.K0 == 192 && a.groups == 1, "chain: the NIG head produces 192-wide input rows of one group");
+    MMDEER_CHECK(g.e2 && g.w3 && g.evid && g.targets && (g.stats || g.gstats) && g.dz2 && g.partial_w && g.partial_b && g.nblk >= 1,
+                 "chain: NIG head: NULL argument");
+    MMDEER_CHECK(((uintptr_t)g.e2 % 16) == 0 && ((uintptr_t)g.w3 % 16) == 0 && ((uintptr_t)g.evid % 16) == 0 && ((uintptr_t)g.dz2 % 16) == 0,
+                 "chain: NIG head: pointers must be 16-byte aligned");
+  } else {
+    MMDEER_CHECK(a.X && ((uintptr_t)a.X % 16) == 0 && a.ldx % 8 == 0, "chain: input rows must be 16-byte aligned");
+  }
+  MMDEER_CHECK(a.B > 0, "chain: empty batch");
   MMDEER_CHECK(a.groups == 1 || a.groups == 2, "chain: groups must be 1 or 2");
   MMDEER_CHECK(a.K0 % 64 == 0 && a.K0 * a.groups <= 512, "chain: input width %d x %d groups does not fit the panel", a.K0, a.groups);
   ChainKArgs k{};
   k.X = a.X; k.ldx = a.ldx; k.K0 = a.K0; k.B = a.B; k.groups = a.groups; k.group_stride = a.group_stride; k.drop = a.drop;
   k.stamps = a.stamps;
+  k.nig = a.nig;
   int vec = 0, nend = 0, nvec = 0;
   const int ts = chain_samples_per_workgroup(a.B) / 16;       // 16-sample blocks per workgroup
   int blocks_in = a.groups * ts, width_in = a.K0, layer_first_seg = 0;

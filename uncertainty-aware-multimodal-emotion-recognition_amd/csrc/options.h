@@ -25,6 +25,7 @@ enum OptId {
   OPT_DW_TILE,          // GemmTile of the weight-gradient launch: 2 = 128x128 tiles without split-K (default), 3 = 256x256 + split-K slabs, 4 = 256x128
   OPT_DW_KG,            // 128x128 weight-gradient tiles: 2 = the workgroup's halves split each 64-row stage of K (default), 1 = 32-row stages
   OPT_CHAIN_MAX,        // largest batch that takes the chains
+  OPT_CHAIN_NIG,        // 1 (with the backward chain, loss mode): the head's last-layer backward + loss gradient run in the chain's prologue
   OPT_SPLITK_MAX,       // largest number of split-K slices of a weight-gradient problem (slabs: 4 B per parameter per slice)
   OPT_COUNT
 };
