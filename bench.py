@@ -327,6 +327,8 @@ def main():
     ap.add_argument("--workload", default="train_step", choices=["train_step", "stackb_infer"],
                     help="train_step: the north-star line (default); stackb_infer: SURVEY 8f-1, CompleteDEERModel eval forward")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="keep the library's default launch plan instead of timing the plans on this GPU first (MultimodalDEER.autotune_launch_plan)")
     args = ap.parse_args()
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -405,6 +407,19 @@ def main():
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return float(dt) / n * 1e3
 
+    # Launch plan: the layer chains win or lose against the separate launches depending on the box (their bound, the L2 -> CU
+    # path, varies far more between boxes than MFMA or HBM rates): the plans are timed on this GPU before anything else and the
+    # fastest becomes the library's plan for the run (untimed set-up, like the data-parallel plan choice below).  An explicit
+    # MMDEER_CHAIN / MMDEER_CHAIN_BWD in the environment (the A/B tools) or --no-autotune keeps the plan as set.
+    launch_plan = None
+    if not args.eager and not args.no_autotune and not any(k in os.environ for k in ("MMDEER_CHAIN", "MMDEER_CHAIN_BWD")):
+        def rmax(x):
+            if world == 1:
+                return x
+            tt = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt)
+        launch_plan = model.autotune_launch_plan(a, v, t, y, reduce_max=rmax, **sc)
     # One step = ~35 kernels of 4-40 us: launched one by one the host needs about as long as the GPU, so the step is
     # captured once into a HIP graph (dropout masks advance through a device-side counter) and replayed.
     ev = comm.events if comm else None
@@ -620,6 +635,10 @@ def main():
                        "parallelism": (f"dp{world} (one process per GPU, gradient all-reduce over RCCL, {args.grad_comm} payload, "
                                         f"{comm_mode})" if world > 1 else "single")},
             "launch": "eager" if replay is None else "hip-graph replay",
+            # which launch plan ran: chosen by timing the plans on this GPU (untimed set-up), or the library's current options
+            "launch_plan": launch_plan if launch_plan is not None else
+                           {"plan": "as set", "options": {k: _lib.get_option(k) for k in ("chain", "chain_bwd", "chain_nig")},
+                            "why": "--no-autotune / --eager / MMDEER_CHAIN* given"},
             "grad_exchange": comm_mode + (", exact-global loss statistics" if exact else ""),
             "final_loss": round(loss, 6),
             "train_step_with_optimizer_ms": round(full_elapsed / K * 1e3, 4),     # fwd + bwd + clip + AdamW + weight pack

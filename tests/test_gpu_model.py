@@ -453,6 +453,42 @@ def test_two_call_backward_reads_nothing_stale_from_the_workspace(B, dtype):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+def test_autotune_launch_plan_picks_a_plan_and_keeps_the_results():
+    """MultimodalDEER.autotune_launch_plan times the captured step under the three launch plans on this GPU and sets the library's
+    options to the fastest (bench.py does that before its warm-up).  Whatever it picks, the forward results are those of the
+    default plan bit for bit; outside the chains' range nothing is timed."""
+    saved = {k: _lib.get_option(k) for k in ("chain", "chain_bwd")}
+    try:
+        b = synth.make_batch(4096, seed=31)
+        a, v, t, y = (torch.from_numpy(b[k]).to(DEV) for k in ("audio", "video", "text", "targets"))
+        m = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=9)).to(DEV).train()
+        calls = []
+        plan = m.autotune_launch_plan(a, v, t, y, replays=5, reduce_max=lambda x: calls.append(x) or x)
+        names = [n for n, _ in MultimodalDEER.LAUNCH_PLANS]
+        assert plan["plan"] in names and sorted(plan["ms"]) == sorted(names) and len(calls) == 6
+        assert all(0.05 < ms < 5.0 for ms in plan["ms"].values()), plan
+        assert plan["ms"][plan["plan"]] == min(plan["ms"].values())
+        for k, val in plan["options"].items():
+            assert _lib.get_option(k) == val
+        m2 = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=9)).to(DEV).train()
+        d_tuned = m2.train_step(a, v, t, y)
+        for k, val in saved.items():
+            _lib.set_option(k, val)
+        m3 = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=9)).to(DEV).train()
+        d_default = m3.train_step(a, v, t, y)
+        torch.cuda.synchronize()
+        for k in d_default:
+            if torch.is_tensor(d_default[k]):
+                assert torch.equal(d_tuned[k], d_default[k]), k
+        assert float(d_tuned["total_loss"]) == float(d_default["total_loss"])
+        # fp32 / small batches: the chains do not apply, nothing to choose
+        small = m.autotune_launch_plan(a[:64], v[:64], t[:64], y[:64])
+        assert small["ms"] == {} and small["plan"] == "separate launches"
+    finally:
+        for k, val in saved.items():
+            _lib.set_option(k, val)
+
+
 def test_eval_forward_with_chains_is_bit_identical():
     """The inference path takes the forward chains as well (no dropout: every site is off): all outputs of forward() in eval mode
     must equal the separate-launch plan's bit for bit, also on a ragged batch."""

@@ -315,7 +315,7 @@ __device__ __forceinline__ void chain_ln_bwd_fold(float* red, int wave, int lane
 // (bf16, the layout the DMA path produces: chunk c of row r in slot c ^ (r & 7) of image d) and to global memory.  Those waves
 // work through the transcendental part of the loss terms while the FIRST waves fetch and sum the batch statistics
 // (compute_finals); the barriers wait for LDS only, never for the stores to memory.
-// `scratch`: >= MS * 195 floats of LDS nobody uses before the first segment's epilogue (the output panel).
+// `scratch`: the output panel (MS KiB of LDS nobody uses before the first segment's epilogue).
 template <int MS>
 __device__ __forceinline__ void chain_nig_head(const ChainNig& g, unsigned char* pin, float* scratch, int row0, int B, int tid, unsigned long long* stp) {
 #ifdef MMDEER_STAMPS
@@ -324,9 +324,14 @@ __device__ __forceinline__ void chain_nig_head(const ChainNig& g, unsigned char*
 #define NSTAMP(i) do {} while (0)
 #endif
   NSTAMP(110);
-  __shared__ float gs[3][NIG_NSTAT];
-  __shared__ f32x4 sdE[MS * 3];
-  __shared__ Finals F;
+  // LDS scratch behind the MS x 195 floats of e2 rows: statistics sums, d evidence of every (sample, dimension), the finals, and
+  // compute_finals' own scratch -- all inside the kernel's one LDS array (see the note at compute_finals, nig_dev.h)
+  float* sb = scratch + MS * 195;
+  float (*gs)[NIG_NSTAT] = reinterpret_cast<float (*)[NIG_NSTAT]>(sb);     sb += 108;
+  f32x4* const sdE = reinterpret_cast<f32x4*>(sb);                           sb += MS * 12;
+  Finals& F = *reinterpret_cast<Finals*>(sb);                                sb += (sizeof(Finals) + 15) / 16 * 4;
+  float* const ftmp = sb;
+  static_assert((MS * 195 + 108 + MS * 12 + (sizeof(Finals) + 15) / 16 * 4 + NIG_FINALS_TMP) * 4 <= MS * 1024, "NIG head scratch exceeds the output panel");
   const int wave = tid >> 6, lane = tid & 63, q = lane & 3;
   const int qw = wave - (8 - 3 * (MS / 16));
   const bool quad_on = qw >= 0;
@@ -353,7 +358,7 @@ __device__ __forceinline__ void chain_nig_head(const ChainNig& g, unsigned char*
   }
   const int stat_n = g.gstats ? (int)g.gstats[3 * NIG_NSTAT] : B;
   NSTAMP(111);
-  compute_finals(g.gstats ? g.gstats : g.stats, g.gstats ? 1 : g.nblk, stat_n, g.cfg, F, gs);
+  compute_finals(g.gstats ? g.gstats : g.stats, g.gstats ? 1 : g.nblk, stat_n, g.cfg, F, gs, ftmp);
   NSTAMP(112);
   if (blockIdx.x == 0 && tid == 0) write_loss(F, g.loss_out, g.bin_counts);
   if (quad_on) {

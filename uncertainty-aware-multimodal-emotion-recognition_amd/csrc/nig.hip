@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
                                                       float* partial_w, float* partial_b, float* loss_out,
                                                       int* bin_counts, int B, float mask_scale, LossCfg cfg) {
   __shared__ float gs[3][NIG_NSTAT];
+  __shared__ float ftmp[NIG_FINALS_TMP];
   __shared__ f32x4 sdE[NIG_ROWS];
   __shared__ Finals F;
   __shared__ float xt[NIG_ROWS][65];   // this block's e2 rows (fp32, +1 pad): reused by the weight-gradient partial
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
     GSTAMP(1);
     // exact-global mode: the statistics of all ranks' batches (already summed), N = the global batch size
     const int stat_n = gstats ? (int)gstats[3 * NIG_NSTAT] : B;
-    compute_finals(gstats ? gstats : stats, gstats ? 1 : nblk, stat_n, cfg, F, gs);
+    compute_finals(gstats ? gstats : stats, gstats ? 1 : nblk, stat_n, cfg, F, gs, ftmp);
     GSTAMP(2);
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) write_loss(F, loss_out, bin_counts);
     const Nig n = nig_act(ev);
@@ -168,8 +169,9 @@ __global__ __launch_bounds__(256) void nig_loss_grad_kernel(const float* gamma, 
                                                             float* dgamma, float* dnu, float* dalpha, float* dbeta,
                                                             float* loss_out, int* bin_counts, int B, LossCfg cfg) {
   __shared__ float gs[3][NIG_NSTAT];
+  __shared__ float ftmp[NIG_FINALS_TMP];
   __shared__ Finals F;
-  compute_finals(stats, gridDim.x, B, cfg, F, gs);
+  compute_finals(stats, gridDim.x, B, cfg, F, gs, ftmp);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) write_loss(F, loss_out, bin_counts);
   const int d = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B || !dgamma) return;

@@ -111,13 +111,18 @@ struct Finals {
   int counts[3][10];
 };
 
+// `tmp`: NIG_FINALS_TMP floats of LDS scratch.  (No static __shared__ in here: a second LDS object in chain.hip's kernel makes
+// the compiler attach alias scopes to every LDS access and then wait for ALL outstanding LDS-DMA transfers -- s_waitcnt vmcnt(0)
+// -- before each LDS read that might alias one: 267 such waits appeared in the chain kernel's stage loops and tile epilogues and
+// cost 25 us per step.  With the kernel's one LDS array as the only object there is no scope information and no such wait.)
+constexpr int NIG_FINALS_TMP = 3 * NIG_NSTAT + 30 + 3 + 3;
 __device__ __forceinline__ void compute_finals(const float* stats, int nblk, int B, const LossCfg& cfg, Finals& F,
-                                               float (*gs)[NIG_NSTAT]) {
+                                               float (*gs)[NIG_NSTAT], float* tmp) {
   // Identical in every workgroup (blockDim.x == 256), and every wave of it waits here: the serial part is kept short.
   // Measured on workgroup (0,0) at B = 4096 (tools/nig_stamps.py): one thread walking the 3 x 10 bins took 12.4k cycles
   // and the chain of nblk dependent adds 5.9k, of 30k for the whole kernel.
   constexpr int NV = 3 * NIG_NSTAT;
-  __shared__ float upper[NV], ece_c[30], dim_total[3], ubar_s[3];
+  float* const upper = tmp; float* const ece_c = tmp + NV; float* const dim_total = ece_c + 30; float* const ubar_s = dim_total + 3;
   {
     // 105 sums over the nblk block partials: the two halves of the workgroup take the two halves of the range with
     // 16 loads in flight per thread

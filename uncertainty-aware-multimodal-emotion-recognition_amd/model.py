@@ -503,6 +503,54 @@ class MultimodalDEER(nn.Module):
     def flat_grad(self) -> Optional[torch.Tensor]:
         return self._flat_grad
 
+    # launch plans autotune_launch_plan() chooses between (library options, include/mmdeer.h): identical results up to rounding
+    LAUNCH_PLANS = (("layer chains", dict(chain=1, chain_bwd=1)),
+                    ("forward chains only", dict(chain=1, chain_bwd=0)),
+                    ("separate launches", dict(chain=0)))
+
+    def autotune_launch_plan(self, audio, video, text, targets, replays: int = 20, reduce_max=None, stats_comm=None) -> Dict[str, object]:
+        """Time the captured training step under each launch plan on THIS GPU and make the fastest the library's plan.
+
+        The layer chains (csrc/chain.hip) are bound by the L2 -> CU path, whose rate differs from box to box far more than the
+        MFMA or HBM rates do: on the boxes of one pool the same build gained 15 us per step from them on one and lost 12 us on
+        another.  The plans compute the same step (forward bit for bit, gradients up to the summation
+        order of a few partials), so the choice is a pure timing decision, made once before a run like the data-parallel
+        exchange plan.  Every candidate is captured into a HIP graph and replayed ``replays`` times between two events;
+        ``reduce_max`` (optional callable float -> float, e.g. an all-reduce MAX) makes every rank see the same timings.
+        Returns {"plan": name, "options": {...}, "ms": {name: ms per step}}; plans that do not apply to this batch size /
+        dtype collapse into one and nothing is timed."""
+        B = int(audio.shape[0])
+        lo, hi = _lib.get_option("chain_min"), _lib.get_option("chain_max")
+        if self.compute_f32 or not (lo <= B <= hi) or not self.training:
+            return {"plan": "separate launches", "options": {}, "ms": {}, "why": "the layer chains do not apply to this dtype / batch size"}
+        graphs = []
+        for name, opts in self.LAUNCH_PLANS:
+            with _lib.options(**opts):
+                graphs.append((name, self.capture_train_step(audio, video, text, targets, stats_comm=stats_comm)))
+        # two interleaved rounds, the better one counts: the first plan timed must not pay for clocks that are still ramping up
+        ms: Dict[str, float] = {}
+        for _round in range(2):
+            for name, r in graphs:
+                for _ in range(5):
+                    r()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(replays):
+                    r()
+                e1.record()
+                torch.cuda.synchronize(audio.device)
+                t = e0.elapsed_time(e1) / replays
+                t = float(reduce_max(t)) if reduce_max is not None else t
+                ms[name] = round(min(t, ms.get(name, t)), 4)
+        del graphs
+        self._graph = None
+        best = min(ms, key=ms.get)
+        opts = dict(self.LAUNCH_PLANS)[best]
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        return {"plan": best, "options": dict(opts), "ms": ms,
+                "why": "fastest of the launch plans on this GPU (best of two interleaved rounds of %d graph replays each)" % replays}
+
     def capture_train_step(self, audio, video, text, targets, events=None, after=None, comm=None, stats_comm=None):
         """Capture ``train_step`` on these (static) input tensors into a HIP graph and return ``replay()``.
 
