@@ -23,8 +23,8 @@ timeout -k 10 200 python tools/chain_stamps.py 4096 > $OUT/chain_stamps.txt 2>&1
 timeout -k 10 120 tools/probes/calibrate > $OUT/calibration.txt 2>&1; echo "calibration rc=$?"
 timeout -k 10 300 python tools/stackb_fused_time.py > $OUT/stackb_train.txt 2>&1; echo "stack B training rc=$?"
 # data-parallel rehearsal on the one GPU (1-rank group, the collective really runs): single in-graph exchange vs overlapped plan
-MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_single.json 2> /dev/null; echo "dp single rc=$?"
-MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_overlap.json 2> /dev/null; echo "dp overlap rc=$?"
-MMDEER_FORCE_COMM=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_auto.json 2> /dev/null; echo "dp auto rc=$?"
+MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_single.json 2> $OUT/bench_dp1_single.err; echo "dp single rc=$?"
+MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_overlap.json 2> $OUT/bench_dp1_overlap.err; echo "dp overlap rc=$?"
+MMDEER_FORCE_COMM=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_auto.json 2> $OUT/bench_dp1_auto.err; echo "dp auto rc=$?"
 MMDEER_CHAIN=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_nochain.json 2> /dev/null; echo "bench without chains rc=$?"
 ls -la $OUT
