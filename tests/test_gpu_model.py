@@ -596,6 +596,56 @@ def test_exact_global_loss_over_two_shards_equals_the_global_batch():
     assert checked >= 30
 
 
+def test_exact_global_statistics_through_the_chain_prologue():
+    """The exact-global mode with the head's backward inside the backward chain (bf16, option chain_nig): the summed statistics
+    reach the chain's prologue instead of nig_bwd_kernel; loss record and every gradient upstream of the last head layer are bit
+    for bit those of the stand-alone launch."""
+    from mmdeer.spec import param_offsets
+    lo = min(o for (name, _s, _i), o in zip(param_table(), param_offsets()[0]) if ".evidence_net.6." in name)
+    sizes = (300, 420)
+    b = synth.make_batch(sum(sizes), seed=37)
+
+    class Exchange:
+        active = True
+
+        def __init__(self):
+            self.seen, self.total = None, None
+
+        def sum_small(self, t):
+            self.seen = t.clone()
+            if self.total is not None:
+                t.copy_(self.total)
+
+    res = {}
+    for nig in (1, 0):
+        with _lib.options(chain_min=1, chain_nig=nig):
+            out, start = [], 0
+            ex = [Exchange() for _ in sizes]
+            models = [MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=6)).to(DEV).train() for _ in sizes]
+            shards = []
+            for n in sizes:
+                shards.append(tuple(torch.from_numpy(b[k][start:start + n]).to(DEV) for k in ("audio", "video", "text", "targets")))
+                start += n
+            for m, sh, e in zip(models, shards, ex):
+                m.train_step(*sh, stats_comm=e)
+            total = ex[0].seen + ex[1].seen
+            for e in ex:
+                e.total = total
+            models = [MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=6)).to(DEV).train() for _ in sizes]    # same dropout step
+            for m, sh, e in zip(models, shards, ex):
+                d = m.train_step(*sh, stats_comm=e)
+                out.append((float(d["total_loss"]), m.flat_grad().clone()))
+            torch.cuda.synchronize()
+            res[nig] = out
+    assert float(total[105]) == sum(sizes)
+    for (l1, g1), (l0, g0) in zip(res[1], res[0]):
+        assert l1 == l0 and math.isfinite(l1)
+        assert torch.equal(g1[:lo], g0[:lo])
+        d = (g1[lo:].double() - g0[lo:].double()).norm() / g0[lo:].double().norm()
+        assert 0.0 < float(d) < 1e-5, float(d)
+    assert res[1][0][0] == res[1][1][0]              # both "ranks" report the global batch's loss
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_gradient_through_fused_features_reaches_the_fusion_parameters(dtype):
     """fused_features is a differentiable output (fusion.py:164-171 hands it to whatever head the caller builds): a loss
