@@ -419,7 +419,13 @@ def main():
             tt = torch.tensor([x], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt)
-        launch_plan = model.autotune_launch_plan(a, v, t, y, reduce_max=rmax, **sc)
+        try:
+            launch_plan = model.autotune_launch_plan(a, v, t, y, reduce_max=rmax, **sc)
+        except Exception as e:               # noqa: BLE001  -- the default plan is always a valid one
+            print(f"[bench] launch-plan autotuning failed ({type(e).__name__}: {e}); keeping the library's default plan", file=sys.stderr)
+            torch.cuda.synchronize()
+            launch_plan = {"plan": "as set", "options": {k: _lib.get_option(k) for k in ("chain", "chain_bwd", "chain_nig")},
+                           "why": f"autotuning failed: {type(e).__name__}"}
     # One step = ~35 kernels of 4-40 us: launched one by one the host needs about as long as the GPU, so the step is
     # captured once into a HIP graph (dropout masks advance through a device-side counter) and replayed.
     ev = comm.events if comm else None
