@@ -575,10 +575,12 @@ class MultimodalDEER(nn.Module):
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         in_kernel = not self.compute_f32     # bf16: the first kernel of the forward bumps the counter itself
-        # With a collective in the capture the process has other threads that talk to the runtime (the communicator's watchdog
+        # With a collective in the capture (or a process group alive at all) the process has other threads that talk to the runtime (the communicator's watchdog
         # polls the events of earlier eager collectives): in the default "global" mode such a call from another thread, landing
         # while this one captures, invalidates the capture.  Only this thread's calls matter here.
-        mode = "thread_local" if (after is not None or comm is not None or stats_comm is not None) else "global"
+        import torch.distributed as _dist
+        with_comm = after is not None or comm is not None or stats_comm is not None or (_dist.is_available() and _dist.is_initialized())
+        mode = "thread_local" if with_comm else "global"
         with torch.cuda.graph(graph, capture_error_mode=mode):
             if not in_kernel:
                 self._graph_counter.add_(1)
