@@ -16,7 +16,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else bench.PROFILE_TAG
 src, dst = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profiles")
 sha = bench.kernel_sources_sha()
 for name in ("bench_b4096_bf16.json", "bench_b8192_bf16.json", "bench_b1024_fp32.json", "bench_b7_bf16.json", "step_trace.txt",
-             "pmc_fused_summary.txt", "pmc_step_summary.txt", "tf_stamps.txt", "chain_stamps.txt", "fwd_only.txt", "calibration.txt",
+             "pmc_fused_summary.txt", "pmc_step_summary.txt", "tf_stamps.txt", "chain_stamps.txt", "chain_stamps_bwd.txt", "fwd_only.txt", "calibration.txt",
              "stackb_train.txt", "bench_dp1_single.json", "bench_dp1_overlap.json", "bench_dp1_auto.json", "bench_b4096_nochain.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):

@@ -20,6 +20,7 @@ bash tools/gpu_pmc_step.sh > $OUT/pmc_step.log 2>&1; echo "pmc step rc=$?"
 cp gpurun_out/pmc_step_summary.txt $OUT/ 2>/dev/null
 timeout -k 10 200 python tools/tf_stamps.py > $OUT/tf_stamps.txt 2>&1; echo "stamps rc=$?"
 timeout -k 10 200 python tools/chain_stamps.py 4096 > $OUT/chain_stamps.txt 2>&1; echo "chain stamps rc=$?"
+timeout -k 10 200 python tools/chain_stamps.py 4096 bwd > $OUT/chain_stamps_bwd.txt 2>&1; echo "chain stamps (backward head chain) rc=$?"
 timeout -k 10 120 tools/probes/calibrate > $OUT/calibration.txt 2>&1; echo "calibration rc=$?"
 timeout -k 10 300 python tools/stackb_fused_time.py > $OUT/stackb_train.txt 2>&1; echo "stack B training rc=$?"
 # data-parallel rehearsal on the one GPU (1-rank group, the collective really runs): single in-graph exchange vs overlapped plan
