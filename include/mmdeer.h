@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 13
+#define MMDEER_ABI_VERSION 14
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20).
  * RESTRICTION: mmdeer_forward / mmdeer_backward / mmdeer_adamw_step (the Stack C entry points) are compiled for exactly this
@@ -597,8 +597,9 @@ typedef struct mmdeer_stackb_forward_args {
 size_t mmdeer_stackb_workspace_bytes(int batch, int compute_f32, int audio_ld);
 int mmdeer_stackb_forward(const mmdeer_stackb_forward_args* a);
 
-/* ---- gradient exchange: the data-parallel step has ONE collective, an all-reduce of the flat gradient
- * buffer.  These wrap an RCCL communicator for hosts without torch.distributed; RCCL is bound at run time (dlopen), so
+/* ---- gradient exchange: the data-parallel step has ONE exchange, of the flat gradient buffer: one
+ * all-reduce, or reduce-scatter + all-gather (every rank reduces 1/N of the buffer from all peers at once and then fetches
+ * the other shards: all seven xGMI links of a GPU carry data at the same time, where a ring is bound by one link).  These wrap an RCCL communicator for hosts without torch.distributed; RCCL is bound at run time (dlopen), so
  * the library loads without it and these calls then fail with a message.  Rank 0 draws the id, the host distributes
  * its MMDEER_COMM_ID_BYTES bytes to the other ranks by whatever side channel it has (file, socket, MPI, a
  * torch.distributed broadcast), every rank calls mmdeer_comm_init with its HIP device current.  mmdeer_allreduce works
@@ -609,6 +610,14 @@ int mmdeer_comm_unique_id(void* id_out);
 int mmdeer_comm_init(mmdeer_comm** comm, int rank, int world_size, const void* id);
 int mmdeer_comm_destroy(mmdeer_comm* comm);
 int mmdeer_allreduce(void* buf, long long count, int dtype_f32, int average, mmdeer_comm* comm, void* stream);
+int mmdeer_comm_rank(const mmdeer_comm* comm);    /* -1 for NULL */
+int mmdeer_comm_world(const mmdeer_comm* comm);
+/* Reduce-scatter: `send` holds world * recv_count elements; rank r receives the sum (or mean) over ranks of elements
+ * [r * recv_count, (r + 1) * recv_count) in `recv` (in place when recv == send + r * recv_count).  All-gather: every rank
+ * contributes send_count elements, `recv` receives world * send_count (rank r's at r * send_count; in place when
+ * send == recv + rank * send_count).  Enqueue-only on `stream`, capturable like mmdeer_allreduce. */
+int mmdeer_reduce_scatter(const void* send, void* recv, long long recv_count, int dtype_f32, int average, mmdeer_comm* comm, void* stream);
+int mmdeer_allgather(const void* send, void* recv, long long send_count, int dtype_f32, mmdeer_comm* comm, void* stream);
 
 /* fp32 <-> bf16 conversion of a contiguous device buffer (n % 4 == 0) */
 int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream);

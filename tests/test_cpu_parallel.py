@@ -44,6 +44,19 @@ def _worker(rank, world, port, q):
         comm.wait(share)
         ok = ok and torch.equal(share, torch.full((n,), float(sum(range(1, world + 1)))))
         comm.exact_global = False
+        # reduce-scatter + all-gather (every rank reduces 1/N of the buffer, then fetches the others' shards): the same
+        # result as the all-reduce, mean and SUM, on a buffer whose length is not a multiple of world x 8 (the tail is padding)
+        from mmdeer.parallel import shard_elems
+        for m in (n, 8 * world * 5 + 12):
+            assert shard_elems(m, world) % 8 == 0 and world * shard_elems(m, world) >= m
+            for exact in (False, True):
+                rs = BucketedAllReduce(algo="rs_ag")
+                rs.exact_global = exact
+                g = torch.arange(m, dtype=torch.float32) * (rank + 1) + rank
+                rs.launch(g)
+                rs.wait(g)
+                tot = sum(torch.arange(m, dtype=torch.float32) * (r + 1) + r for r in range(world))
+                ok = ok and torch.allclose(g, tot if exact else tot / world)
         # weak-scaling data sharding: rank r draws rows [rB, (r+1)B) of one global stream
         B = 6
         mine = synth.make_batch(B, seed=42, row_offset=rank * B)["video"]
@@ -75,8 +88,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_gradient_exchange():
-    world, port = 2, _free_port()
+def test_two_rank_gloo_gradient_exchange(world=2):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -86,4 +99,9 @@ def test_two_rank_gloo_gradient_exchange():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(results) == [(0, True), (1, True)]
+    assert sorted(results) == [(r, True) for r in range(world)]
+
+
+def test_three_rank_gloo_gradient_exchange():
+    """An odd rank count: the reduce-scatter shards do not divide the buffer."""
+    test_two_rank_gloo_gradient_exchange(world=3)

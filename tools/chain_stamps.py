@@ -30,11 +30,12 @@ if bwd:
 torch.cuda.synchronize()
 ws = m._workspace(B, torch.device(dev))
 off = lib.mmdeer_workspace_offset(B, 0, b"davin" if bwd else b"slab")
-raw = ws.view(torch.uint8)[off:off + 8 * 128].cpu().numpy().view(np.uint64).astype(np.int64)
+raw = ws.view(torch.uint8)[off:off + 8 * 512].cpu().numpy().view(np.uint64).astype(np.int64)
 t0 = raw[0]
+print("(130+4s: segment s's layer-end barrier passed, 131+4s: its layer-end body done; 200+8s+w: wave w arrives at that barrier; 100-104: LayerNorm backward phases)")
 print("stamp  cycles-from-start  delta   (1: tables in LDS, 2: prologue done; 3+3s: segment s decoded, 4+3s: its tiles done, 5+3s: its layer end done)")
 prev = t0
-for i, x in enumerate(raw[:128]):
+for i, x in enumerate(raw[:512]):
     if x == 0 or abs(int(x) - int(t0)) > 10**9:
         continue
     print(f"{i:3d} {x - t0:10d} {x - prev:8d}")

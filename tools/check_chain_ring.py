@@ -1,0 +1,72 @@
+"""Static check of csrc/chain.hip's weight ring (run after every change of the kernel; tests/test_cpu_host.py runs it):
+the ring lives in the top VGPRs of each wave, v[224:255] (16-sample kernel) / v[240:255] (32-sample kernel), which the register
+allocator must never touch -- every instruction that names one of them has to come from the kernel's own inline asm, and the
+kernels must not use accumulation registers (an AGPR split would move the ring)."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "uncertainty-aware-multimodal-emotion-recognition_amd", "csrc", "chain.hip")
+LIMITS = {"chain_kernel_s16": 224, "chain_kernel_s32": 240}
+
+
+def device_asm() -> str:
+    hipcc = "/opt/rocm/bin/hipcc"
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "chain.s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-S",
+                        "--cuda-device-only", "-o", out, SRC], check=True, capture_output=True)
+        return open(out).read()
+
+
+def check(asm: str):
+    problems, seen = [], {}
+    kernel, in_asm = None, False
+    reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+    for ln, line in enumerate(asm.splitlines(), 1):
+        m = re.match(r"^(_ZN\S*?(chain_kernel_s\d+)\S*):", line)
+        if m:
+            kernel, in_asm = m.group(2), False
+            seen[kernel] = 0
+            continue
+        if line.startswith("\t.end_amdhsa_kernel") or line.startswith(".Lfunc_end"):
+            kernel = None
+        if kernel is None:
+            continue
+        if "#ASMSTART" in line:
+            in_asm = True
+            continue
+        if "#ASMEND" in line:
+            in_asm = False
+            continue
+        code = line.split(";")[0]
+        if "accvgpr" in code or re.search(r"\ba\d+\b|\ba\[\d+", code):
+            problems.append(f"{kernel}: accumulation register used at line {ln}: {line.strip()}")
+        hi = 0
+        for a, b, c in reg.findall(code):
+            hi = max(hi, int(a) if a else int(c))
+        if hi >= LIMITS[kernel]:
+            if in_asm:
+                seen[kernel] += 1
+            else:
+                problems.append(f"{kernel}: compiler-generated use of a ring register at line {ln}: {line.strip()}")
+    for k in LIMITS:
+        if seen.get(k, 0) == 0:
+            problems.append(f"{k}: no ring access found (kernel missing or renamed?)")
+    for k, lim in LIMITS.items():
+        m = re.search(r"\.name:\s+\S*" + k + r"\S*.*?\.vgpr_count:\s+(\d+)", asm, re.S)
+        m2 = re.search(r"\.agpr_count:\s+(\d+)\s+.*?\.name:\s+\S*" + k, asm, re.S)
+        if not m or int(m.group(1)) != 256:
+            problems.append(f"{k}: vgpr_count is {m.group(1) if m else '?'}, expected 256 (the ring must be inside the allocation)")
+    return problems, seen
+
+
+if __name__ == "__main__":
+    probs, seen = check(device_asm())
+    print("ring accesses per kernel:", seen)
+    for p in probs:
+        print("PROBLEM:", p)
+    sys.exit(1 if probs else 0)

@@ -222,6 +222,10 @@ SYMBOLS = [
     ("mmdeer_comm_init", c_int, [C.POINTER(c_void_p), c_int, c_int, c_void_p]),
     ("mmdeer_comm_destroy", c_int, [c_void_p]),
     ("mmdeer_allreduce", c_int, [c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p]),
+    ("mmdeer_comm_rank", c_int, [c_void_p]),
+    ("mmdeer_comm_world", c_int, [c_void_p]),
+    ("mmdeer_reduce_scatter", c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p]),
+    ("mmdeer_allgather", c_int, [c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p]),
     ("mmdeer_convert", c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p]),
     ("mmdeer_set_option", c_int, [c_char_p, c_int]),
     ("mmdeer_get_option", c_int, [c_char_p, C.POINTER(c_int)]),
@@ -260,7 +264,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 13:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 14:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         # The library itself reads no environment variable (include/mmdeer.h).  For the A/B tools the host forwards
         # MMDEER_<OPTION> (e.g. MMDEER_FUSED_ATTN=0) to mmdeer_set_option once, here.

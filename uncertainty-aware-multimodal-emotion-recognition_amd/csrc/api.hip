@@ -80,6 +80,8 @@ struct Layout {
   char* wqkv_hm; // bf16 mode: head-major image of the trimodal in_proj weight for the fused projection + attention kernels
   float* vpack;  // fp32 vectors, MMDEER_FLAT_ELEMS
   float* wscratch;   // ADAM_NPART floats: sum-of-squares partials of the optimiser step
+  char* wfpack;  // bf16 mode: fragment-major images (chain.h) of the matrices the forward layer chains stream, at their flat offsets
+  char* wtfpack; // bf16 mode: the same of the W^T matrices the backward chains stream
   size_t wbytes;     // size of the weights buffer
   // ---- per-batch workspace
   char* audio_pad;   // bf16 mode: the audio feature block as [B][AUD_PAD]
@@ -109,6 +111,8 @@ Layout make_layout(void* base, void* wbase, int B, int f32) {
   L.wa_pad = take((size_t)INTER * AUD_PAD * 2);
   L.wqkv_hm = take((size_t)3 * FUS * FUS * 2);
   L.wscratch = reinterpret_cast<float*>(take((size_t)ADAM_NPART * 4));
+  L.wfpack = take(f32 ? 0 : (size_t)MMDEER_FLAT_ELEMS * 2);
+  L.wtfpack = take(f32 ? 0 : (size_t)MMDEER_FLAT_ELEMS * 2);
   L.wbytes = off;
   off = 0;
   b = reinterpret_cast<char*>(base);
@@ -261,6 +265,9 @@ struct Exec {
   // dX = dY W, optionally masked by (Yprev > 0) * mask_scale.  Runs as an NT GEMM against the packed W^T
   // ([K_layer][N_layer], reduction-contiguous), i.e. on the LDS-DMA kernel in bf16 mode.
   const char* WT(int pid) const { return L->wtpack + (size_t)kParams[pid].off * es; }
+  // fragment-major images of W / W^T for the layer chains (bf16 mode; pack_frag_images below says which exist)
+  const bf16_t* WF(int pid, size_t elem_off = 0) const { return reinterpret_cast<const bf16_t*>(L->wfpack) + kParams[pid].off + elem_off; }
+  const bf16_t* WTF(int pid, size_t elem_off = 0) const { return reinterpret_cast<const bf16_t*>(L->wtfpack) + kParams[pid].off + elem_off; }
   GemmProblem dx(const void* dY, int ldy_in, int pidW, void* dX, int ldx, int M, const void* Ymask, int ldmask) const {
     GemmProblem p;
     gemm_problem_defaults(p);
@@ -364,6 +371,36 @@ int pack_transposed_weights(const void* const* params, const Layout& L, int f32,
   return launch_pack_transposed(tt, L.wtpack, f32, s);
 }
 
+// bf16 mode: fragment-major images (chain.h) of every matrix a layer chain streams, from the packed copies: W of the forward
+// chains (F2-F6, F9-F17) into L.wfpack, W^T of the backward chains (B2-B10, B13-B17) into L.wtfpack -- each image at the flat
+// offset of the (sub-)matrix it restates (the value rows of the AV in_proj at + 2 E E, head z of the stacked layers at + z N K)
+int pack_frag_images(const Layout& L, bool with_transposed, hipStream_t s) {
+  FragTable t{};
+  auto add = [&](const char* src_base, char* dst_base, long long src_off, int ld, int N, int K, long long dst_off) {
+    const int k = t.nmat++;
+    t.src[k] = reinterpret_cast<const bf16_t*>(src_base) + src_off;
+    t.dst[k] = reinterpret_cast<bf16_t*>(dst_base) + dst_off;
+    t.ld[k] = ld; t.N[k] = N; t.K[k] = K;
+  };
+  auto o = [&](int pid) { return kParams[pid].off; };
+  auto fwd = [&](int pid, int N, int K, long long sub = 0) { add(L.wpack, L.wfpack, o(pid) + sub, K, N, K, o(pid) + sub); };
+  fwd(P_AIN_W, INTER, INTER, (long long)2 * INTER * INTER);
+  fwd(P_AOUT_W, INTER, INTER); fwd(P_AVF_W, INTER, 2 * INTER); fwd(P_AVP_W, FUS, INTER);
+  fwd(P_TOUT_W, FUS, FUS); fwd(P_TFF_W, FUS, FUS); fwd(P_OP_W, FUS, FUS);
+  fwd(P_FP0_W, HID, FUS); fwd(P_FP1_W, HID, HID); fwd(P_EV0_W, 3 * EV1, HID);
+  for (int z = 0; z < 3; ++z) fwd(P_EV1_W, EV2, EV1, (long long)z * EV2 * EV1);
+  if (with_transposed) {   // W^T as stored by pack_transposed_weights: [cols of W][rows of W]
+    auto bwd = [&](int pid, int N, int K, long long sub = 0) { add(L.wtpack, L.wtfpack, o(pid) + sub, K, N, K, o(pid) + sub); };
+    for (int z = 0; z < 3; ++z) bwd(P_EV1_W, EV1, EV2, (long long)z * EV2 * EV1);
+    bwd(P_EV0_W, HID, 3 * EV1); bwd(P_FP1_W, HID, HID); bwd(P_FP0_W, FUS, HID);
+    bwd(P_OP_W, FUS, FUS); bwd(P_TFF_W, FUS, FUS); bwd(P_TOUT_W, FUS, FUS);
+    bwd(P_AVP_W, INTER, FUS); bwd(P_AVF_W, 2 * INTER, INTER); bwd(P_AOUT_W, INTER, INTER);
+    // value columns [2E, 3E) of the AV in_proj's W^T [256][768]
+    add(L.wtpack, L.wtfpack, o(P_AIN_W) + 2 * INTER, 3 * INTER, INTER, INTER, o(P_AIN_W) + (long long)2 * INTER * INTER);
+  }
+  return launch_pack_frag(t, s);
+}
+
 // bf16 mode: the [256][128] zero-padded copy of audio_projection.weight
 int pad_audio_weight(const void* const* params, const Layout& L, hipStream_t s) {
   PadTable pt{};
@@ -422,7 +459,7 @@ long long mmdeer_weights_offset(int compute_f32, const char* name) {
   char* const base = reinterpret_cast<char*>(uintptr_t(1) << 40);
   const Layout L = make_layout(base, base, 0, compute_f32 ? 1 : 0);
 #define WT(field) if (strcmp(name, #field) == 0) return reinterpret_cast<const char*>(L.field) - base;
-  WT(wpack) WT(wtpack) WT(vpack) WT(wa_pad) WT(wqkv_hm)
+  WT(wpack) WT(wtpack) WT(vpack) WT(wa_pad) WT(wqkv_hm) WT(wfpack) WT(wtfpack)
 #undef WT
   return -1;
 }
@@ -460,6 +497,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     // the parameters are unchanged, so an inference call followed by a training call on the same parameters would find
     // them missing (the backward pass then multiplied by whatever the buffer held)
     TRY(pack_transposed_weights(a->params, L, f32, s));
+    if (!f32) TRY(pack_frag_images(L, true, s));
   }
   const bool wa_pending = a->repack && !f32;   // the padded bf16 copy of audio_projection.weight follows the parameters
   if (B == 0) {
@@ -531,7 +569,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     {   // F2: value projection (rows [2E, 3E) of the packed in_proj), attention-weight dropout = one decision per (row, head)
       ChainSeg q;
       chain_seg_defaults(q);
-      q.W = reinterpret_cast<const bf16_t*>(X.W(P_AIN_W)) + (size_t)2 * INTER * INTER; q.bias = X.V(P_AIN_B) + 2 * INTER;
+      q.W = X.WF(P_AIN_W, (size_t)2 * INTER * INTER); q.bias = X.V(P_AIN_B) + 2 * INTER;
       q.N = INTER; q.K = INTER; q.ldw = INTER;
       q.drop_site = X.drop_on ? SITE_AV_ATTN : -1; q.drop_shift = 5;
       q.end_layer = 1; q.nout = INTER; q.stash = reinterpret_cast<bf16_t*>(L.avv); q.ld_stash = INTER;
@@ -540,7 +578,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     {   // F3: out_proj of both calls; group z lands in columns [256 z, 256 z + 256) of cat (fusion.py:262)
       ChainSeg q;
       chain_seg_defaults(q);
-      q.W = reinterpret_cast<const bf16_t*>(X.W(P_AOUT_W)); q.bias = X.V(P_AOUT_B); q.N = INTER; q.K = INTER; q.ldw = INTER;
+      q.W = X.WF(P_AOUT_W); q.bias = X.V(P_AOUT_B); q.N = INTER; q.K = INTER; q.ldw = INTER;
       q.fold_groups = 1;
       q.end_layer = 1; q.nout = 2 * INTER; q.stash = reinterpret_cast<bf16_t*>(L.cat); q.ld_stash = 2 * INTER;
       c.seg[k++] = q;
@@ -548,7 +586,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     {   // F4-F5: fusion_layers = Linear -> ReLU -> Dropout -> LayerNorm (fusion.py:263)
       ChainSeg q;
       chain_seg_defaults(q);
-      q.W = reinterpret_cast<const bf16_t*>(X.W(P_AVF_W)); q.bias = X.V(P_AVF_B); q.N = INTER; q.K = 2 * INTER; q.ldw = 2 * INTER;
+      q.W = X.WF(P_AVF_W); q.bias = X.V(P_AVF_B); q.N = INTER; q.K = 2 * INTER; q.ldw = 2 * INTER;
       q.relu = 1; q.drop_site = X.drop_on ? SITE_AV_FUSE : -1;
       q.end_layer = 1; q.nout = INTER; q.stash = reinterpret_cast<bf16_t*>(L.y_a2); q.ld_stash = INTER;
       q.gamma = X.V(P_AVF_G); q.beta = X.V(P_AVF_BT); q.xln = reinterpret_cast<bf16_t*>(L.av); q.out32 = a->audiovisual_features;
@@ -558,7 +596,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     {   // F6: audiovisual_projection -> token 0 (fusion.py:321, 325)
       ChainSeg q;
       chain_seg_defaults(q);
-      q.W = reinterpret_cast<const bf16_t*>(X.W(P_AVP_W)); q.bias = X.V(P_AVP_B); q.N = FUS; q.K = INTER; q.ldw = INTER;
+      q.W = X.WF(P_AVP_W); q.bias = X.V(P_AVP_B); q.N = FUS; q.K = INTER; q.ldw = INTER;
       q.end_layer = 1; q.nout = FUS; q.stash = reinterpret_cast<bf16_t*>(L.xtok); q.ld_stash = 2 * FUS;
       c.seg[k++] = q;
     }
@@ -614,7 +652,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     auto lin = [&](int pidW, int pidB, int N, int K, int relu, int site, void* stash) {
       ChainSeg q;
       chain_seg_defaults(q);
-      q.W = reinterpret_cast<const bf16_t*>(X.W(pidW)); q.bias = X.V(pidB); q.N = N; q.K = K; q.ldw = K;
+      q.W = X.WF(pidW); q.bias = X.V(pidB); q.N = N; q.K = K; q.ldw = K;
       q.relu = relu; q.drop_site = X.drop_on ? site : -1;
       q.end_layer = 1; q.nout = N; q.stash = reinterpret_cast<bf16_t*>(stash); q.ld_stash = N;
       return q;
@@ -778,7 +816,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     auto dxseg = [&](int pidW, int N, int K, void* stash, const void* ymask, int ldmask) {
       ChainSeg q;
       chain_seg_defaults(q);
-      q.W = reinterpret_cast<const bf16_t*>(X.WT(pidW)); q.N = N; q.K = K; q.ldw = K;
+      q.W = X.WTF(pidW); q.N = N; q.K = K; q.ldw = K;
       q.end_layer = 1; q.nout = N; q.stash = reinterpret_cast<bf16_t*>(stash); q.ld_stash = N;
       q.mask_y = reinterpret_cast<const bf16_t*>(ymask); q.ld_mask = ldmask; q.mask_scale = X.mask_scale;
       return q;
@@ -890,32 +928,32 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     ChainArgs c{};
     c.X = reinterpret_cast<const bf16_t*>(L.dxtok); c.ldx = 2 * FUS; c.K0 = FUS; c.B = B; c.groups = 1; c.group_stride = B;
     c.drop = X.dc;
-    auto dxs = [&](const char* wt, int N, int K, int ldw, void* stash, int ld_stash, int nout) {
+    auto dxs = [&](const bf16_t* wt, int N, int K, int ldw, void* stash, int ld_stash, int nout) {
       ChainSeg q;
       chain_seg_defaults(q);
-      q.W = reinterpret_cast<const bf16_t*>(wt); q.N = N; q.K = K; q.ldw = ldw;
+      q.W = wt; q.N = N; q.K = K; q.ldw = ldw;
       q.end_layer = 1; q.nout = nout; q.stash = reinterpret_cast<bf16_t*>(stash); q.ld_stash = ld_stash;
       return q;
     };
     int k = 0;
     {   // token 0 -> audiovisual features, then the LayerNorm of fusion_layers backwards (mask of its Linear-ReLU-Dropout)
-      ChainSeg q = dxs(X.WT(P_AVP_W), INTER, FUS, FUS, L.dav, INTER, INTER);
+      ChainSeg q = dxs(X.WTF(P_AVP_W), INTER, FUS, FUS, L.dav, INTER, INTER);
       q.lnb_gamma = X.V(P_AVF_G); q.lnb_y = reinterpret_cast<const bf16_t*>(L.y_a2); q.lnb_mean = L.mean_a2; q.lnb_rstd = L.rstd_a2;
       q.lnb_dz = reinterpret_cast<bf16_t*>(L.dz_a2); q.lnb_partial = L.part_ln_a2; q.lnb_mask_scale = X.mask_scale;
       c.seg[k++] = q;
     }
     {   // fusion_layers dX: W^T [512][256]; the 512 columns = d cat, unfolded into the two calls' rows ([2B,256] stacked)
-      ChainSeg q = dxs(X.WT(P_AVF_W), 2 * INTER, INTER, INTER, L.dcats, INTER, INTER);
+      ChainSeg q = dxs(X.WTF(P_AVF_W), 2 * INTER, INTER, INTER, L.dcats, INTER, INTER);
       q.fold_groups = 2;
       c.seg[k++] = q;
     }
     {   // AV out_proj; dX gets the regenerated attention-dropout factor of the forward value projection
-      ChainSeg q = dxs(X.WT(P_AOUT_W), INTER, INTER, INTER, L.davv, INTER, INTER);
+      ChainSeg q = dxs(X.WTF(P_AOUT_W), INTER, INTER, INTER, L.davv, INTER, INTER);
       if (X.drop_on) { q.drop_site = SITE_AV_ATTN; q.drop_shift = 5; }
       c.seg[k++] = q;
     }
     // AV value projection (columns [2E, 3E) of W^T [256][768])
-    c.seg[k++] = dxs(X.WT(P_AIN_W) + (size_t)2 * INTER * es, INTER, INTER, 3 * INTER, L.davin, INTER, INTER);
+    c.seg[k++] = dxs(X.WTF(P_AIN_W, (size_t)2 * INTER * INTER), INTER, INTER, INTER, L.davin, INTER, INTER);
     c.nseg = k;
     TRY(launch_chain(c, s));
   } else {
@@ -997,6 +1035,7 @@ int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
   TRY(launch_adamw_pack(t, L.wpack, f32, L.vpack, s));
   const void* const* cparams = const_cast<const void* const*>(a->params);
   if (a->pack_transposed) TRY(pack_transposed_weights(cparams, L, f32, s));
+  if (!f32) TRY(pack_frag_images(L, a->pack_transposed != 0, s));
   if (!f32) TRY(pad_audio_weight(cparams, L, s));
   return 0;
 }
@@ -1018,6 +1057,7 @@ int mmdeer_pack_weights(const void* const* params, void* weights, size_t weights
   }
   TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
   TRY(pack_transposed_weights(params, L, f32, s));
+  if (!f32) TRY(pack_frag_images(L, true, s));
   if (!f32) TRY(pad_audio_weight(params, L, s));
   return 0;
 }

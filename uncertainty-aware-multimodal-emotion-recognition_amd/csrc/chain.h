@@ -18,7 +18,7 @@ constexpr int CHAIN_VEC_FLOATS = 4864;   // LDS floats for every bias / gamma / 
 // finished panel: stored for the backward pass (`stash`), LayerNorm'ed in place (`gamma`), then it becomes the input
 // panel of the next layer.
 struct ChainSeg {
-  const bf16_t* W;       // [N][ldw] bf16 (K contiguous)
+  const bf16_t* W;       // the FRAGMENT-MAJOR image (launch_pack_frag below) of the [N][K] bf16 matrix; ldw is unused
   const float* bias;     // [N] or null
   bf16_t* stash;         // end_layer: the finished (pre-LayerNorm) rows -> [row][ld_stash], or null
   const float* gamma;    // end_layer: LayerNorm over the finished panel (width nout), or null
@@ -89,6 +89,21 @@ struct ChainArgs {
 // partial slab per workgroup).
 inline int chain_samples_per_workgroup(int B) { return B > 4096 ? 32 : 16; }
 inline int chain_workgroups(int B) { const int m = chain_samples_per_workgroup(B); return (B + m - 1) / m; }
+
+// Fragment-major weight images: what the chain kernel streams.  For a matrix W [N][K] (bf16, N % 16 == 0, K % 64 == 0) the 2 KiB
+// that ONE wave multiplies in ONE stage -- 16 output columns x 64 k -- are contiguous and in the lane order of the MFMA A operand:
+// 16-byte granule index = ((wt * (K / 64) + kt) * 2 + c) * 64 + lane holds W[16 wt + (lane & 15)][64 kt + 32 c + 8 (lane >> 4) ... + 8),
+// so each of a wave's two global_load_dwordx4 per stage reads one contiguous KiB (eight whole cache lines) straight into registers.
+// (Measured, tools/probes/wstream.hip: 54 B/clk per CU with every CU streaming the same 2 MB, against 39-44 through an LDS-DMA ring.)
+constexpr int FRAG_MAX = 32;
+struct FragTable {
+  int nmat;
+  const bf16_t* src[FRAG_MAX];   // [N][ld] row-major
+  bf16_t* dst[FRAG_MAX];         // N * K elements
+  int ld[FRAG_MAX], N[FRAG_MAX], K[FRAG_MAX];
+  int gstart[FRAG_MAX + 1];      // filled by the launcher: first granule of each matrix
+};
+int launch_pack_frag(FragTable& t, hipStream_t s);
 
 void chain_seg_defaults(ChainSeg& s);
 // Validates shapes / alignment, derives the kernel's tables and enqueues the chain on `stream`.

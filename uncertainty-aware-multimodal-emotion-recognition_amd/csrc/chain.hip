@@ -71,6 +71,50 @@ __device__ __forceinline__ void dma16(const void* src, void* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 
+// ---- the weight ring: D stages of 2 KiB per wave (16 output columns x 64 k, in the lane order of the MFMA A operand) in the wave's
+// TOP registers v[256 - 8 D : 255], loaded straight from the fragment-major weight image (chain.h) by global_load_dwordx4 and copied
+// to compiler-visible registers just before the MFMAs.  The kernel is compiled with amdgpu_num_vgpr(256 - 8 D): the register
+// allocator never touches the ring, everything that does is inline asm naming the registers, so no value the compiler knows of is
+// ever "in flight" -- it cannot move, copy or spill a register whose load has not landed -- and hand-counted vmcnt waits are the
+// only ordering the ring needs.  (Accumulation registers a[...] would be the natural home, but an asm statement that names one
+// makes the compiler split the file 128 + 128 and spill the kernel's own 180 VGPRs into AGPRs.)
+// Slot S = v[248 - 8 S : 255 - 8 S]: two dwordx4 per lane = the two 32-wide k-chunks of the stage.
+template <int S>
+__device__ __forceinline__ void wr_issue(const void* p) {
+  static_assert(S >= 0 && S < 4, "ring slots 0..3");
+  if constexpr (S == 0)
+    asm volatile("global_load_dwordx4 v[248:251], %0, off\n\tglobal_load_dwordx4 v[252:255], %0, off offset:1024" ::"v"(p)
+                 : "memory", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+  else if constexpr (S == 1)
+    asm volatile("global_load_dwordx4 v[240:243], %0, off\n\tglobal_load_dwordx4 v[244:247], %0, off offset:1024" ::"v"(p)
+                 : "memory", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247");
+  else if constexpr (S == 2)
+    asm volatile("global_load_dwordx4 v[232:235], %0, off\n\tglobal_load_dwordx4 v[236:239], %0, off offset:1024" ::"v"(p)
+                 : "memory", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239");
+  else
+    asm volatile("global_load_dwordx4 v[224:227], %0, off\n\tglobal_load_dwordx4 v[228:231], %0, off offset:1024" ::"v"(p)
+                 : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231");
+}
+// wait until at most N younger vector-memory operations are outstanding, then copy slot S into compiler-visible registers (s_nop: the
+// MFMAs that follow read what these VALU moves wrote, and the compiler's hazard recogniser does not look into the statement)
+template <int S, int N>
+__device__ __forceinline__ void wr_take(u32x4& f0, u32x4& f1) {
+  unsigned r0, r1, r2, r3, r4, r5, r6, r7;
+#define CH_TAKE(b0, b1, b2, b3, b4, b5, b6, b7)                                                                                  \
+  asm volatile("s_waitcnt vmcnt(%8)\n\tv_mov_b32 %0, v" #b0 "\n\tv_mov_b32 %1, v" #b1 "\n\tv_mov_b32 %2, v" #b2 "\n\tv_mov_b32 %3, v" #b3   \
+               "\n\tv_mov_b32 %4, v" #b4 "\n\tv_mov_b32 %5, v" #b5 "\n\tv_mov_b32 %6, v" #b6 "\n\tv_mov_b32 %7, v" #b7 "\n\ts_nop 1"         \
+               : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7)                                 \
+               : "n"(N)                                                                                                         \
+               : "memory")
+  if constexpr (S == 0) CH_TAKE(248, 249, 250, 251, 252, 253, 254, 255);
+  else if constexpr (S == 1) CH_TAKE(240, 241, 242, 243, 244, 245, 246, 247);
+  else if constexpr (S == 2) CH_TAKE(232, 233, 234, 235, 236, 237, 238, 239);
+  else CH_TAKE(224, 225, 226, 227, 228, 229, 230, 231);
+#undef CH_TAKE
+  f0 = u32x4{r0, r1, r2, r3};
+  f1 = u32x4{r4, r5, r6, r7};
+}
+
 __device__ __forceinline__ unsigned chain_drop_key(unsigned long long seed, unsigned long long off, int site) {
   unsigned k = mix32((unsigned)seed ^ 0x9E3779B9u);   // == drop_key() with the device counter already added to `off`
   k = mix32(k ^ (unsigned)(seed >> 32));
@@ -83,9 +127,9 @@ __device__ __forceinline__ unsigned chain_drop_key(unsigned long long seed, unsi
 // and read from there: the kernel walks them record after record, and as dependent scalar loads from the kernarg segment
 // each record was a ~1000-cycle round trip.  All fields are dwords (a sub-dword field would be a vector load).
 struct ChainSegK {           // one GEMM segment = ntiles column tiles of `nkt` weight stages each; 96 bytes
-  const bf16_t* W;
-  int ldw, nkt;              // stages per tile: K / 64 (128-column stages) or K / 128 (64-column stages)
-  int ntiles, kindb;         // column tiles (<= 4); 1: 64 columns x 128 k per stage
+  const bf16_t* W;           // fragment-major image of the segment's [N][K] matrix
+  int ldw, nkt;              // stages per tile: K / 64
+  int ntiles, kindb;         // column tiles (<= 4); 1: 64-column tiles (four column blocks of 16)
   int end;                   // index into ChainKArgs::end when this segment finishes a layer, else -1
   int N;
   int vec_off, dcol_off, nout_off, site;
@@ -406,16 +450,14 @@ __device__ __forceinline__ void chain_nig_head(const ChainNig& g, unsigned char*
   // no barrier here: the caller's prologue barrier follows, and the scratch area is next written by the first segment's epilogue
 }
 
-// NST ring slots of 16 KiB (NST - 1 stages in flight), VECF floats of bias / gamma / beta.  Instantiated as <6, 4864>; a
-// seven-slot ring for the chains with few vectors (<7, 2560>, 156 KiB of LDS) was 4-5 us per step SLOWER on the same box.
-// TS = 1: 16 samples per workgroup (B <= 4096: one round of 256 workgroups); TS = 2: 32 samples (4096 < B <= 8192:
-// twice the rows per streamed weight byte; the two 32-KiB panels leave four ring slots).
-template <int NST, int VECF, int TS>
-__global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
-  constexpr int MS = 16 * TS, LOG_MS = TS == 1 ? 4 : 5, FLY = 2 * (NST - 1);   // FLY: weight DMAs of one wave in flight
+// D: weight stages a wave keeps in flight (2 KiB each, in a[0 : 8 D)); VECF floats of bias / gamma / beta in LDS.
+// TS = 1: 16 samples per workgroup (B <= 4096: one round of 256 workgroups); TS = 2: 32 samples (4096 < B <= 8192: twice the rows
+// per streamed weight byte).
+template <int D, int VECF, int TS>
+__device__ __forceinline__ void chain_body(const ChainKArgs& a) {
+  constexpr int MS = 16 * TS, LOG_MS = TS == 1 ? 4 : 5, FLY = 2 * D;   // FLY: weight loads of one wave in flight
   constexpr int PAN = MS * 1024;           // MS rows x 512 columns (or 2 MS x 256) of bf16
-  constexpr int SLOT = 16384;
-  constexpr int RING = 2 * PAN, VEC = RING + NST * SLOT, TAB = VEC + VECF * 4;
+  constexpr int VEC = 2 * PAN, TAB = VEC + VECF * 4;
   constexpr int SEG_BYTES = (int)sizeof(ChainSegK);
   constexpr int END0 = CHAIN_MAX_SEGS * SEG_BYTES, VEC0 = END0 + CHAIN_MAX_ENDS * (int)sizeof(ChainEndK);
   constexpr int TAB_BYTES = VEC0 + CHAIN_MAX_VECS * (int)sizeof(ChainVecK);
@@ -434,13 +476,15 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
   const int nseg = a.nseg, nvec = a.nvec;
 #ifdef MMDEER_STAMPS
   unsigned long long* const stamps = a.stamps;
-  auto stamp = [&](int i) { if (stamps && blockIdx.x == 0 && tid == 0 && i < 128) stamps[i] = __builtin_readcyclecounter(); };
+  auto stamp = [&](int i) { if (stamps && blockIdx.x == 0 && tid == 0 && i < 512) stamps[i] = __builtin_readcyclecounter(); };
+  auto wstamp = [&](int i) { if (stamps && blockIdx.x == 0 && lane == 0 && i < 512) stamps[i] = __builtin_readcyclecounter(); };   // one per wave
 #else
   auto stamp = [&](int) {};
+  auto wstamp = [&](int) {};
 #endif
   stamp(0);
 
-  // dropout: the step counter is read ONCE, before any DMA is in flight (a tracked load later would drain the ring)
+  // dropout: the step counter is read ONCE, before anything else is in flight
   const unsigned long long dseed = a.drop.seed;
   const unsigned long long doff = a.drop.offset + (a.drop.offset_dev ? *a.drop.offset_dev : 0ull);
   const unsigned dthresh = a.drop.thresh;
@@ -486,44 +530,42 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
     return ph >= ntl ? ph - ntl : ph;
   };
 
-  // ---- weight stream: a cursor over (segment, column tile, stage); two DMA pieces per wave per stage
-  int p_si = 0, p_nt = 0, p_kt = 0, p_nkt = 0, p_ntiles = 0, p_step = 0, p_ldw = 0, p_kb = 0;
-  const bf16_t* p_W = nullptr;
-  const bf16_t* p0 = nullptr;
-  const bf16_t* p1 = nullptr;
+  // ---- weight stream: a cursor over (segment, column tile, stage).  A stage of a wave = the 16 output columns it multiplies x 64 k
+  // = 2 KiB contiguous in the fragment-major image (two dwordx4 per lane).  Every tile takes a multiple of D stages: behind its
+  // K / 64 real ones the last real stage is loaded again (and ignored), so a tile always starts in ring slot 0 and the slot of
+  // every stage is known at compile time.  64-column tiles (the evidence heads) have four column blocks: waves 4-7 load those of
+  // waves 0-3 (and ignore them) -- every wave sees the same number of loads per stage, the counted waits never differ.
+  int p_si = 0, p_nt = 0, p_kt = 0, p_nkt = 0, p_nv = 0, p_ntiles = 0, p_kb = 0;
+  const unsigned char* p_W = nullptr;
+  const unsigned char* p_cur = nullptr;
   auto p_tile = [&]() __attribute__((always_inline)) {
     const int ph = phys_tile(p_nt, p_ntiles);
-    // 128-column stages: a wave DMA-copies exactly the 16 weight rows it multiplies itself (pieces 2 wave, 2 wave + 1), so its own
-    // counted vmcnt wait orders the copy against its reads and nobody else touches those LDS rows: no barrier in the stage loop.
-    // 64-column stages (four active waves): the pieces are shared out over all eight waves and the loop keeps its barriers.
-    p0 = p_W + (long long)(ph * (p_kb ? 64 : 128) + wave * (p_kb ? 8 : 16) + r8) * p_ldw + kchunk;
-    p1 = p0 + (p_kb ? 64ll : 8ll * p_ldw);     // 64-column stages: the next 64 k; 128-column stages: the next 8 rows
+    const int wt = p_kb ? ph * 4 + (wave & 3) : ph * 8 + wave;       // 16-column block of the matrix
+    p_cur = p_W + ((long long)wt * p_nkt) * 2048 + lane * 16;
   };
   auto p_load = [&]() __attribute__((always_inline)) {
     const u32x4* rec = reinterpret_cast<const u32x4*>(tab + p_si * SEG_BYTES);
     const u32x4 q0 = rec[0], q1 = rec[1];
-    p_W = reinterpret_cast<const bf16_t*>(sp(q0.x, q0.y));
-    p_ldw = sc(q0.z); p_nkt = sc(q0.w); p_ntiles = sc(q1.x); p_kb = sc(q1.y);
-    p_step = p_kb ? 128 : 64;
+    p_W = reinterpret_cast<const unsigned char*>(sp(q0.x, q0.y));
+    p_nkt = sc(q0.w); p_ntiles = sc(q1.x); p_kb = sc(q1.y);
+    p_nv = (p_nkt + D - 1) / D * D;
     p_nt = 0;
     p_tile();
   };
-  auto issue = [&](int slot) __attribute__((always_inline)) {
-    unsigned char* d = lds + RING + slot * SLOT + wave * (p_kb ? 1024 : 2048);
-    dma16(p0, d);
-    dma16(p1, d + (p_kb ? 8192 : 1024));
-    p0 += p_step; p1 += p_step;
-    if (++p_kt == p_nkt) {
+  auto issue = [&](auto slotc) __attribute__((always_inline)) {
+    wr_issue<decltype(slotc)::value>(p_cur);
+    if (++p_kt < p_nkt) p_cur += 2048;          // padding stages load the last real one again
+    if (p_kt == p_nv) {
       p_kt = 0;
       if (++p_nt == p_ntiles) {
-        if (++p_si == nseg) p_si = 0;   // past the end the stream wraps around: four stages nobody reads, but every
-        p_load();                       // stage of the chain sees the same number of younger DMAs (constant waits)
+        if (++p_si == nseg) p_si = 0;   // past the end the stream wraps around: D stages nobody reads, but every
+        p_load();                       // stage of the chain sees the same number of younger loads (constant waits)
       } else {
         p_tile();
       }
     }
   };
-  // ---- every bias / gamma / beta of the chain into LDS, by DMA as well (vector e is wave e % 8's job); BEFORE the ring's first
+  // ---- every bias / gamma / beta of the chain into LDS by DMA (vector e is wave e % 8's job); BEFORE the ring's first
   //      stages, so that the wait below can leave those in flight
   for (int e = wave; e < nvec; e += 8) {
     const u32x4 q = *reinterpret_cast<const u32x4*>(tab + VEC0 + e * 16);
@@ -536,10 +578,11 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
     }
   }
   p_load();
-#pragma unroll
-  for (int t = 0; t < NST - 1; ++t) issue(t);
+  issue(std::integral_constant<int, 0>{});
+  issue(std::integral_constant<int, 1>{});
+  if constexpr (D == 4) { issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{}); }
   // backward head chain: the input rows are computed while the vectors and the ring's first stages are in flight (its loads and
-  // stores are younger than those DMAs: the counted waits below can only become stricter by them)
+  // stores are younger than those: the counted waits below can only become stricter by them)
   if (nig_in) {
     chain_nig_head<MS>(a.nig, lds, reinterpret_cast<float*>(lds + PAN), row0, B, tid, a.stamps);
     stamp(115);
@@ -551,29 +594,24 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
   // ---- the chain
   unsigned char* pin = lds;
   unsigned char* pout = lds + PAN;
-  int slot = 0;
-  bool prev_kb = false;
   const int swz0 = (lg ^ (li & 7)) * 16, swz1 = ((4 + lg) ^ (li & 7)) * 16;
-  auto wrap = [](int s_) -> int { return s_ >= NST ? s_ - NST : s_; };
 
   struct SegCtl { int N, ntiles, vec_off, dcol_off, nout_off, site, shift, relu, fold, kin_off, rows_out, has_bias, ld_mask, mask_col0; float mask_scale; const bf16_t* mask_y; };
 
-  // One segment.  The activation fragments of its 16 (or 32) rows stay in REGISTERS for all its column tiles: re-read from the
-  // panel at every stage they were half of the LDS traffic of the stage loop, and the loop is LDS-bandwidth-bound (8 waves x
-  // (2 KiB of weights + 2 KiB of activations) + 16 KiB written by the DMA per stage = 48 KiB at 128 B/clk).
-  // MB row blocks; KB: 64-column stages of 128 k, else 128 columns x 64 k; NKT stages per tile.
+  // One segment.  The activation fragments of its 16 (or 32) rows stay in REGISTERS for all its column tiles.
+  // MB row blocks; KB: 64-column tiles (four column blocks), else 128 columns; NKT real stages per tile.
   auto seg_body = [&](auto mbc, auto kbc, auto nktc, const SegCtl& sg) __attribute__((always_inline)) {
     constexpr int MB = decltype(mbc)::value;
     constexpr bool KB = decltype(kbc)::value;
     constexpr int NKT = decltype(nktc)::value;
-    constexpr int NCH = KB ? 4 : 2;               // 32-wide k-chunks per stage
-    const bool active = !KB || wave < 4;          // 64-column stages: four column blocks
+    constexpr int NV = (NKT + D - 1) / D * D;     // stages incl. padding: the tile ends in the ring slot it started in
+    const bool active = !KB || wave < 4;          // 64-column tiles: four column blocks
     const int img_in = rows_in * 128, img_out = sg.rows_out * 128;
-    u32x4 afr[NKT * NCH][MB];
+    u32x4 afr[NKT * 2][MB];
     {
       const unsigned char* sa = pin + (sg.kin_off >> 6) * img_in + li * 128;
 #pragma unroll
-      for (int c = 0; c < NKT * NCH; ++c)
+      for (int c = 0; c < NKT * 2; ++c)
 #pragma unroll
         for (int i = 0; i < MB; ++i) afr[c][i] = *reinterpret_cast<const u32x4*>(sa + (c >> 1) * img_in + i * 2048 + ((c & 1) ? swz1 : swz0));
     }
@@ -598,39 +636,44 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
           asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(mk[i]) : "v"(q) : "memory");
         }
       }
-      auto wfrag = [&](u32x4 (&fw)[NCH], int sl) __attribute__((always_inline)) {
-        const unsigned char* sw = lds + RING + sl * SLOT + (16 * wave + li) * 128;
+      auto stage = [&](auto ktc) __attribute__((always_inline)) {
+        constexpr int kt = decltype(ktc)::value;
+        constexpr int S = kt % D;
+        // this wave's stage has landed when at most FLY - 2 younger loads are outstanding; no barrier: a wave reads only what it
+        // loaded itself
+        if constexpr (kt < NKT) {
+          u32x4 f0{0u, 0u, 0u, 0u}, f1{0u, 0u, 0u, 0u};
+          if (active) wr_take<S, FLY - 2>(f0, f1);
+          else ch_wait_vm<FLY - 2>();
+          issue(std::integral_constant<int, S>{});
+          if (active) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) fw[c] = *reinterpret_cast<const u32x4*>(sw + (c >> 1) * 8192 + ((c & 1) ? swz1 : swz0));
-      };
+            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(f0, afr[2 * kt][i], acc[i]);
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        ch_wait_vm<FLY - 2>();                      // this wave's pieces of the stage have landed: NST - 2 younger stages in flight
-        // a barrier only where waves touch each other's LDS rows: this stage or the one before it is a shared-out 64-column stage
-        // (its readers must be done before anyone refills the slot), or the stage issued below is one (it overwrites rows of
-        // other waves, which must have finished the slot's previous stage)
-        if (KB || prev_kb || p_kb) __builtin_amdgcn_s_barrier();
-        prev_kb = KB;
-        u32x4 fw0[NCH];
-        if (active) wfrag(fw0, slot);
-        issue(wrap(slot + NST - 1));
-        if (active) {
-#pragma unroll
-          for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(fw0[c], afr[kt * NCH + c][i], acc[i]);
+            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(f1, afr[2 * kt + 1][i], acc[i]);
+          }
+        } else {      // padding stage: keeps the ring slot / wait count pattern, multiplies nothing
+          ch_wait_vm<FLY - 2>();
+          issue(std::integral_constant<int, S>{});
         }
-        slot = wrap(slot + 1);
-      }
+      };
+      stage(std::integral_constant<int, 0>{});
+      if constexpr (NV > 1) stage(std::integral_constant<int, 1>{});
+      if constexpr (NV > 2) stage(std::integral_constant<int, 2>{});
+      if constexpr (NV > 3) stage(std::integral_constant<int, 3>{});
+      if constexpr (NV > 4) stage(std::integral_constant<int, 4>{});
+      if constexpr (NV > 5) stage(std::integral_constant<int, 5>{});
+      if constexpr (NV > 6) stage(std::integral_constant<int, 6>{});
+      if constexpr (NV > 7) stage(std::integral_constant<int, 7>{});
       // ---- bias, ReLU, dropout, bf16 -> output panel
       if (active) {
         const int n0 = (KB ? nt * 64 : nt * 128) + 16 * wave + 4 * lg;
         const f32x4 bias4 = sg.has_bias ? *reinterpret_cast<const f32x4*>(vec + sg.vec_off + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned dcol = (unsigned)(sg.dcol_off + n0);
         const int colb = sg.nout_off + n0;
-        if (mask_y) {      // the mask loads are older than this tile's 2 NKT weight DMAs (at most 10 of them still in flight)
-          if constexpr (MB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(mk[0]) : "n"(2 * NKT < FLY ? 2 * NKT : FLY) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(mk[0]), "+v"(mk[1]) : "n"(2 * NKT < FLY ? 2 * NKT : FLY) : "memory");
+        if (mask_y) {      // the mask loads are older than this tile's 2 NV >= FLY weight loads, FLY of which are still in flight
+#pragma unroll
+          for (int i = 0; i < MB; ++i) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(mk[i]) : "n"(FLY) : "memory");
         }
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
@@ -680,9 +723,8 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       const u32x4 q5 = rec[5];
       sg.mask_y = reinterpret_cast<const bf16_t*>(sp(q5.x, q5.y)); sg.ld_mask = sc(q5.z); sg.mask_col0 = sc(q5.w);
     }
-    // a layer that ends in a LayerNorm backward: this lane's chunks of the forward's rows and the row statistics are requested
-    // now, before the segment's weight stages (>= NST - 1 of them: FLY younger DMAs), and waited for with vmcnt(FLY) at the layer end
-    // 16-sample workgroups request them NOW, before the segment's weight stages (>= NST - 1 of them: FLY younger DMAs), and wait with
+    // a layer that ends in a LayerNorm backward: this lane's chunks of the forward's rows and the row statistics.
+    // 16-sample workgroups request them NOW, before the segment's weight stages (>= D of them: FLY younger loads), and wait with
     // vmcnt(FLY) at the layer end; 32-sample workgroups have no registers to hold them across the segment (the compiler would spill
     // registers whose loads it does not know to be in flight) and request them at the layer end, draining the ring once.
     ChainLnbIn lnb[TS];
@@ -717,15 +759,17 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
         if (nkt == 4) CH_SEG(2 * TS, false, 4); else if (nkt == 2) CH_SEG(2 * TS, false, 2); else CH_SEG(2 * TS, false, 1);
       }
     } else {
-      if (mb == TS) { if (nkt == 2) CH_SEG(TS, true, 2); else CH_SEG(TS, true, 1); }
-      else CH_SEG(2 * TS, true, 1);
+      if (mb == TS) { if (nkt == 4) CH_SEG(TS, true, 4); else CH_SEG(TS, true, 2); }
+      else CH_SEG(2 * TS, true, 2);
     }
 #undef CH_SEG
     stamp(4 + 3 * si);
     if (endi >= 0) {
       const int rows_out = sg.rows_out, img_out = rows_out * 128;
+      wstamp(200 + 8 * si + wave);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();              // the output panel is complete
+      stamp(130 + 4 * si);
       const u32x4* er = reinterpret_cast<const u32x4*>(tab + END0 + endi * (int)sizeof(ChainEndK));
       const u32x4 e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
       bf16_t* stash = reinterpret_cast<bf16_t*>(sp(e0.x, e0.y));
@@ -767,6 +811,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
             const int r = 16 * ps + 2 * wave + (lane >> 5);
             chain_ln_bwd<8>(pout, img_out, lane, r, valid_of(r), grow_of(r), vec + gb_off, lnb[ps], lms, dz, gacc, bacc);
           }
+          stamp(104);
           chain_ln_bwd_fold<8>(reinterpret_cast<float*>(pin), wave, lane, tid, gacc, bacc, slab);
         } else {
           float gacc[8], bacc[8];
@@ -803,6 +848,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
       // A LayerNorm (forward or backward) rewrote the panel in place: everyone must see it before the next layer reads it.  A plain
       // stash copy only READ the panel, the next layer only reads it too, and what the next layer writes is the other panel, whose
       // last readers (this layer's fragment loads) are at least one barrier behind: no second barrier.
+      stamp(131 + 4 * si);
       if (has_ln) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -815,7 +861,52 @@ __global__ __launch_bounds__(512) void chain_kernel(const ChainKArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The two instantiations.  amdgpu_num_vgpr keeps the register allocator out of the weight ring's registers (see wr_issue).
+// 16 samples per workgroup, four stages in flight (v[224:255]); 32 samples per workgroup, two stages (v[240:255]).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(112))) void chain_kernel_s16(const ChainKArgs a) {
+  chain_body<4, CHAIN_VEC_FLOATS, 1>(a);
+}
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(120))) void chain_kernel_s32(const ChainKArgs a) {
+  chain_body<2, CHAIN_VEC_FLOATS, 2>(a);
+}
+
 }  // namespace
+
+namespace {
+struct FragKArgs { FragTable t; };
+// one thread per 16-byte granule of a fragment-major image (chain.h): granule g of matrix m = lane (g & 63) of chunk ((g >> 6) & 1)
+// of stage kt of 16-column block wt, with (g >> 7) = wt * (K / 64) + kt
+__global__ __launch_bounds__(256) void pack_frag_kernel(const FragKArgs a) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  int m = 0;
+  while (m + 1 < a.t.nmat && g >= a.t.gstart[m + 1]) ++m;
+  const int l = g - a.t.gstart[m];
+  if (l >= a.t.gstart[m + 1] - a.t.gstart[m]) return;
+  const int nkt = a.t.K[m] >> 6;
+  const int lane = l & 63, c = (l >> 6) & 1, rest = l >> 7;
+  const int kt = rest % nkt, wt = rest / nkt;
+  const int n = wt * 16 + (lane & 15), k = kt * 64 + c * 32 + (lane >> 4) * 8;
+  *reinterpret_cast<u32x4*>(a.t.dst[m] + (size_t)l * 8) = *reinterpret_cast<const u32x4*>(a.t.src[m] + (size_t)n * a.t.ld[m] + k);
+}
+}  // namespace
+
+int launch_pack_frag(FragTable& t, hipStream_t s) {
+  MMDEER_CHECK(t.nmat >= 0 && t.nmat <= FRAG_MAX, "pack_frag: too many matrices");
+  if (t.nmat == 0) return 0;
+  int g = 0;
+  for (int m = 0; m < t.nmat; ++m) {
+    MMDEER_CHECK(t.src[m] && t.dst[m] && ((uintptr_t)t.src[m] % 16) == 0 && ((uintptr_t)t.dst[m] % 16) == 0 && t.ld[m] % 8 == 0,
+                 "pack_frag: matrix %d pointers / leading dimension must be 16-byte aligned", m);
+    MMDEER_CHECK(t.N[m] > 0 && t.N[m] % 16 == 0 && t.K[m] > 0 && t.K[m] % 64 == 0, "pack_frag: matrix %d is %d x %d (N % 16, K % 64)", m, t.N[m], t.K[m]);
+    t.gstart[m] = g;
+    g += t.N[m] * t.K[m] / 8;
+  }
+  t.gstart[t.nmat] = g;
+  FragKArgs ka{t};
+  hipLaunchKernelGGL(pack_frag_kernel, dim3((g + 255) / 256), dim3(256), 0, s, ka);
+  MMDEER_HIP(hipGetLastError());
+  return 0;
+}
 
 void chain_seg_defaults(ChainSeg& s) {
   s = ChainSeg{};
@@ -847,7 +938,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   auto add_vec = [&](const float* src, int n) { ChainVecK& v = k.vec[nvec++]; v.src = src; v.off = vec; v.n4 = n / 4; vec += n; return v.off; };
   for (int i = 0; i < a.nseg; ++i) {
     const ChainSeg& s = a.seg[i];
-    MMDEER_CHECK(s.W && ((uintptr_t)s.W % 16) == 0 && s.ldw % 8 == 0, "chain: segment %d weights must be 16-byte aligned", i);
+    MMDEER_CHECK(s.W && ((uintptr_t)s.W % 16) == 0, "chain: segment %d weights (fragment-major image) must be 16-byte aligned", i);
     MMDEER_CHECK(s.N > 0 && s.N % 64 == 0 && s.K > 0 && s.K % 64 == 0 && (s.N % 128 == 0 || s.K % 128 == 0),
                  "chain: segment %d has unsupported N = %d, K = %d", i, s.N, s.K);
     MMDEER_CHECK(s.kin_off % 64 == 0 && s.kin_off + s.K <= width_in, "chain: segment %d reads columns [%d, %d) of a %d-wide panel", i,
@@ -858,12 +949,12 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     MMDEER_CHECK(mblocks <= blocks_in && (mblocks == ts || mblocks == 2 * ts), "chain: segment %d m-blocks", i);
     MMDEER_CHECK(nvec + 3 <= CHAIN_MAX_VECS, "chain: too many bias / gamma / beta vectors");
     const int vec_off = s.bias ? add_vec(s.bias, s.N) : 0;
-    const int kb = s.N % 128 != 0, ntl = kb ? s.N / 64 : s.N / 128, nkt = kb ? s.K / 128 : s.K / 64;
+    const int kb = s.N % 128 != 0, ntl = kb ? s.N / 64 : s.N / 128, nkt = s.K / 64;
     MMDEER_CHECK(ntl <= 4, "chain: segment %d has too many column tiles", i);
-    MMDEER_CHECK(kb ? (nkt <= 2 && mblocks * nkt <= 2 * ts) : ((nkt == 1 || nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8) && mblocks * nkt <= 8 * ts),
+    MMDEER_CHECK(kb ? ((nkt == 2 || nkt == 4) && mblocks * nkt <= 4 * ts) : ((nkt == 1 || nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8) && mblocks * nkt <= 8 * ts),
                  "chain: segment %d: K = %d with %d row blocks is not instantiated", i, s.K, mblocks);
     ChainSegK& td = k.seg[i];
-    td.W = s.W; td.ldw = s.ldw; td.nkt = nkt; td.ntiles = ntl; td.kindb = kb; td.end = -1;
+    td.W = s.W; td.ldw = s.K; td.nkt = nkt; td.ntiles = ntl; td.kindb = kb; td.end = -1;
     td.N = s.N; td.vec_off = vec_off; td.dcol_off = s.dcol_off; td.nout_off = s.nout_off;
     td.site = s.drop_site; td.shift = s.drop_shift; td.relu = s.relu; td.fold = s.fold_groups;
     td.mblocks = mblocks; td.kin_off = s.kin_off;
@@ -885,9 +976,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
         MMDEER_CHECK(s.lnb_y && s.lnb_mean && s.lnb_rstd && s.lnb_dz && s.lnb_partial && ((uintptr_t)s.lnb_gamma % 16) == 0 &&
                          ((uintptr_t)s.lnb_y % 16) == 0 && ((uintptr_t)s.lnb_dz % 16) == 0 && ((uintptr_t)s.lnb_partial % 16) == 0,
                      "chain: LayerNorm backward of segment %d: pointers / alignment", i);
-        int stages = 0;   // the layer's last segment must issue >= 5 stages behind the prefetch of the forward's rows
-        stages = ntl * nkt;
-        MMDEER_CHECK(stages >= 6, "chain: LayerNorm backward behind a segment of %d stages", stages);
+        // (the layer's last segment issues >= D weight stages behind the prefetch of the forward's rows: every tile does)
         e.has_ln = 2; e.xln = s.lnb_dz; e.out32 = s.lnb_partial; e.mean = const_cast<float*>(s.lnb_mean); e.rstd = const_cast<float*>(s.lnb_rstd);
         e.lnb_y = s.lnb_y; e.lnb_mask_scale = s.lnb_mask_scale;
         e.gb_off = add_vec(s.lnb_gamma, s.nout);
@@ -909,8 +998,8 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   MMDEER_CHECK(a.seg[a.nseg - 1].end_layer, "chain: the last segment must end its layer");
   MMDEER_CHECK(vec <= CHAIN_VEC_FLOATS, "chain: %d bias / gamma / beta floats exceed the LDS area (%d)", vec, CHAIN_VEC_FLOATS);
   k.nseg = a.nseg; k.nvec = nvec;
-  if (ts == 1) hipLaunchKernelGGL((chain_kernel<6, CHAIN_VEC_FLOATS, 1>), dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
-  else hipLaunchKernelGGL((chain_kernel<4, CHAIN_VEC_FLOATS, 2>), dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
+  if (ts == 1) hipLaunchKernelGGL(chain_kernel_s16, dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
+  else hipLaunchKernelGGL(chain_kernel_s32, dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
