@@ -83,8 +83,11 @@ size_t mmdeer_weights_bytes(int compute_f32);
  *   chain_nig (1)      0: the head's last-layer backward + loss gradient as a launch of their own also when the backward chain runs
  *   dw_tile (2)        weight-gradient launch: 2 = 128x128 tiles, K-slices of B rows (no split-K slabs for the B-row problems),
  *                      3 = 256x256 tiles + split-K slabs, 4 = 256x128 tiles; dw_kg (2): 1 = the 128x128 kernel on 32-row K stages
+ *   chain_depth (4)    weight stages a wave of the 16-sample chain kernel keeps in flight (2 or 4)
  *   xcd, nt128, nt192, glds, nt8 (1), t128 (512), tile (-1), ksteps (0), splitk_max (8)   GEMM tile / split-K selection
- * mmdeer_set_option / mmdeer_get_option return -1 for an unknown name; mmdeer_option_name(i) enumerates (NULL past the end). */
+ * mmdeer_set_option / mmdeer_get_option return -1 for an unknown name, mmdeer_set_option also for a value outside the option's
+ * range (every option has one: booleans 0..1, dw_tile 2..4, dw_kg 1..2, tile -1..4, splitk_max 1..8, chain_depth 2..4, ...; the
+ * message names it); mmdeer_option_name(i) enumerates (NULL past the end). */
 int mmdeer_set_option(const char* name, int value);
 int mmdeer_get_option(const char* name, int* value);
 const char* mmdeer_option_name(int i);

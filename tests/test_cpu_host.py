@@ -301,3 +301,32 @@ def test_option_table_matches_the_enum_order():
     enum = [e.lower() for e in re.findall(r"^\s+OPT_([A-Z0-9_]+)\b", open(os.path.join(root, "options.h")).read(), re.M) if e != "COUNT"]
     table = re.findall(r'\{"([a-z0-9_]+)",\s*-?\d+,', open(os.path.join(root, "api.hip")).read())
     assert enum == table and len(enum) >= 15
+
+
+def test_set_option_refuses_values_outside_the_range():
+    """several options index tables (dw_tile -> tile sizes of the weight-gradient launch); a value outside an option's
+    range must be refused with a message, and the option must keep its value."""
+    from mmdeer import _lib
+    lib = _lib.load()
+    for name, bad in (("dw_tile", 7), ("dw_tile", -1), ("dw_tile", 1), ("splitk_max", 0), ("splitk_max", 99), ("chain", 2),
+                      ("chain_min", 0), ("dw_kg", 3), ("tile", 5), ("chain_depth", 3 * 100)):
+        before = _lib.get_option(name)
+        assert lib.mmdeer_set_option(name.encode(), bad) == -1
+        assert name in lib.mmdeer_last_error().decode() and "outside" in lib.mmdeer_last_error().decode()
+        assert _lib.get_option(name) == before
+    assert lib.mmdeer_set_option(b"no_such_option", 1) == -1 and "unknown" in lib.mmdeer_last_error().decode()
+    with _lib.options(dw_tile=3, chain_depth=2):
+        assert _lib.get_option("dw_tile") == 3 and _lib.get_option("chain_depth") == 2
+
+
+def test_chain_weight_ring_registers_are_never_touched_by_the_compiler():
+    """csrc/chain.hip keeps its weight ring in v[224:255] / v[240:255] behind amdgpu_num_vgpr; tools/check_chain_ring.py reads the
+    device ISA and fails when the register allocator uses one of them (or an accumulation register) outside the kernel's asm."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_chain_ring", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                   "tools", "check_chain_ring.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    problems, seen = mod.check(mod.device_asm())
+    assert not problems, "\n".join(problems[:20])
+    assert all(n > 0 for n in seen.values()) and len(seen) >= 2

@@ -10,7 +10,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "uncertainty-aware-multimodal-emotion-recognition_amd", "csrc", "chain.hip")
-LIMITS = {"chain_kernel_s16": 224, "chain_kernel_s32": 240}
+LIMITS = {"chain_kernel_s16": 224, "chain_kernel_s32": 240, "chain_kernel_s16_d2": 240}
 
 
 def device_asm() -> str:
@@ -27,7 +27,7 @@ def check(asm: str):
     kernel, in_asm = None, False
     reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
     for ln, line in enumerate(asm.splitlines(), 1):
-        m = re.match(r"^(_ZN\S*?(chain_kernel_s\d+)\S*):", line)
+        m = re.match(r"^(_ZN\S*?\d+(chain_kernel_s\d+(?:_d2)?)E\S*):", line)
         if m:
             kernel, in_asm = m.group(2), False
             seen[kernel] = 0
@@ -57,8 +57,7 @@ def check(asm: str):
         if seen.get(k, 0) == 0:
             problems.append(f"{k}: no ring access found (kernel missing or renamed?)")
     for k, lim in LIMITS.items():
-        m = re.search(r"\.name:\s+\S*" + k + r"\S*.*?\.vgpr_count:\s+(\d+)", asm, re.S)
-        m2 = re.search(r"\.agpr_count:\s+(\d+)\s+.*?\.name:\s+\S*" + k, asm, re.S)
+        m = re.search(r"\.name:\s+\S*\d+" + k + r"E\S*.*?\.vgpr_count:\s+(\d+)", asm, re.S)
         if not m or int(m.group(1)) != 256:
             problems.append(f"{k}: vgpr_count is {m.group(1) if m else '?'}, expected 256 (the ring must be inside the allocation)")
     return problems, seen

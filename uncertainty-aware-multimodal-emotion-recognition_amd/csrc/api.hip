@@ -157,18 +157,31 @@ DropCtx make_drop(float p, uint64_t seed, uint64_t offset, const uint64_t* offse
 }
 
 // ------------------------------------------------------------------ launch-plan options (options.h)
-struct OptEntry { const char* name; int dflt; std::atomic<int> value; };
+struct OptEntry { const char* name; int dflt, lo, hi; std::atomic<int> value; };
+// name, default, smallest and largest accepted value (mmdeer_set_option refuses anything else: several of them index tables)
 OptEntry g_opts[OPT_COUNT] = {
-    {"fused_attn", 1, {1}}, {"qkv_recompute", 1, {1}}, {"xcd", 1, {1}}, {"nt128", 1, {1}}, {"nt192", 1, {1}}, {"glds", 1, {1}},
-    {"nt8", 1, {1}}, {"t128", 512, {512}}, {"tile", -1, {-1}}, {"ksteps", 0, {0}}, {"ln_fused", 1, {1}}, {"chain", 1, {1}}, {"chain_bwd", 1, {1}}, {"chain_min", 2049, {2049}}, {"dw_tile", 2, {2}}, {"dw_kg", 2, {2}}, {"chain_max", 8192, {8192}}, {"chain_nig", 1, {1}}, {"splitk_max", 8, {8}},
+    {"fused_attn", 1, 0, 1, {1}}, {"qkv_recompute", 1, 0, 1, {1}}, {"xcd", 1, 0, 1, {1}}, {"nt128", 1, 0, 1, {1}}, {"nt192", 1, 0, 1, {1}},
+    {"glds", 1, 0, 1, {1}}, {"nt8", 1, 0, 1, {1}}, {"t128", 512, 1, 1 << 30, {512}}, {"tile", -1, -1, 4, {-1}}, {"ksteps", 0, 0, 4096, {0}},
+    {"ln_fused", 1, 0, 1, {1}}, {"chain", 1, 0, 1, {1}}, {"chain_bwd", 1, 0, 1, {1}}, {"chain_min", 2049, 1, 1 << 30, {2049}},
+    {"dw_tile", 2, 2, 4, {2}}, {"dw_kg", 2, 1, 2, {2}}, {"chain_max", 8192, 1, 1 << 30, {8192}}, {"chain_nig", 1, 0, 1, {1}},
+    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 4, {4}},
 };
 }  // namespace
 
 int opt(OptId id) { return g_opts[id].value.load(std::memory_order_relaxed); }
 const char* opt_name(int i) { return (i >= 0 && i < OPT_COUNT) ? g_opts[i].name : nullptr; }
-int opt_set(const char* name, int value) {
+int opt_set(const char* name, int value) {     // 0 = ok, -1 = unknown name, -2 = value out of range
   for (auto& o : g_opts)
-    if (name && strcmp(name, o.name) == 0) { o.value.store(value, std::memory_order_relaxed); return 0; }
+    if (name && strcmp(name, o.name) == 0) {
+      if (value < o.lo || value > o.hi) return -2;
+      o.value.store(value, std::memory_order_relaxed);
+      return 0;
+    }
+  return -1;
+}
+int opt_range(const char* name, int* lo, int* hi) {
+  for (auto& o : g_opts)
+    if (name && strcmp(name, o.name) == 0) { if (lo) *lo = o.lo; if (hi) *hi = o.hi; return 0; }
   return -1;
 }
 int opt_get(const char* name, int* value) {
@@ -211,7 +224,7 @@ GemmTile pick_tile(const GemmGroup& g) {
   }
   // weight-gradient groups (both operands transposed): the strided loads and the packing LDS store cost the same per
   // K-tile whatever the tile size, so the largest tile wins; split-K supplies the parallelism
-  if (g.p[0].trans_a) return (GemmTile)opt(OPT_DW_TILE);   // 256x256 (falls back to 128x128 per sub-group where the kernel does not apply)
+  if (g.p[0].trans_a) { const int t = opt(OPT_DW_TILE); return (GemmTile)(t < 2 ? 2 : t > 4 ? 4 : t); }   // 256x256 (falls back to 128x128 per sub-group where the kernel does not apply)
   // bf16: 128x64 and 64x64 run on the LDS-DMA kernel, 128x128 only on the register-staged one (measured on the
   // trimodal in_proj, 768 tiles of 128x128: 28.5 us against 17 us as 1536 tiles of 128x64)
   const bool f32 = g.p[0].a_f32 && g.p[0].b_f32;
@@ -432,7 +445,13 @@ size_t mmdeer_workspace_bytes(int batch, int compute_f32) { return make_layout(n
 size_t mmdeer_weights_bytes(int compute_f32) { return make_layout(nullptr, nullptr, 0, compute_f32).wbytes; }
 
 int mmdeer_set_option(const char* name, int value) {
-  MMDEER_CHECK(opt_set(name, value) == 0, "set_option: unknown option '%s'", name ? name : "(null)");
+  const int rc = opt_set(name, value);
+  if (rc == -2) {
+    int lo = 0, hi = 0;
+    opt_range(name, &lo, &hi);
+    MMDEER_CHECK(false, "set_option: %s = %d is outside [%d, %d]", name, value, lo, hi);
+  }
+  MMDEER_CHECK(rc == 0, "set_option: unknown option '%s'", name ? name : "(null)");
   return 0;
 }
 int mmdeer_get_option(const char* name, int* value) {

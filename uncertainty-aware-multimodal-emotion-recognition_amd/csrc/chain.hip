@@ -313,43 +313,36 @@ __device__ __forceinline__ void chain_ln_bwd(unsigned char* pan, int img, int la
   for (int e = 0; e < NC * 8; ++e) { gacc[e] += d[e] * xh[e] * live; bacc[e] += d[e] * live; }
 }
 
-// gamma / beta partial sums over the workgroup's rows from the lanes' accumulated contributions: the two halves of a wave add
-// in LDS (lower half writes, upper half reads and adds -- plain LDS operations of ONE wave execute in order; an LDS atomic
-// here made the compiler wait for vmcnt(0), i.e. for the weight ring and every write-through store: 13k cycles), then the
-// eight waves' rows of `red` are summed column by column in a fixed order.
+// gamma / beta partial sums over the workgroup's rows from the lanes' accumulated contributions: every lane writes its row's
+// contribution to `red` (16 rows x KD floats of LDS scratch), one barrier, then thread `col` adds the 16 rows of its column in a
+// fixed order -- (row 2w + row 2w + 1) per wave pair of rows, then ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)) -- the order of the
+// first version of this fold, which paired the rows through dependent LDS read-modify-writes (4.1k cycles per LayerNorm; stamps).
 template <int NKT>
 __device__ __forceinline__ void chain_ln_bwd_fold(float* red, int wave, int lane, int tid, const float (&gacc)[NKT * 2],
                                                   const float (&bacc)[NKT * 2], float* slab) {
 #pragma clang fp contract(off)
   constexpr int KD = NKT * 64, NC = NKT / 4;
   const int l32 = lane & 31;
+  float* mine = red + (2 * wave + (lane >> 5)) * KD;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    float* mine = red + wave * KD;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int c = l32 + 32 * j;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = pass == 0 ? gacc[8 * j + e] : bacc[8 * j + e];
       f32x4* dst = reinterpret_cast<f32x4*>(mine + 8 * c);
-      if (lane < 32) { dst[0] = f32x4{v[0], v[1], v[2], v[3]}; dst[1] = f32x4{v[4], v[5], v[6], v[7]}; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane >= 32) {
-        const f32x4 a0 = dst[0], a1 = dst[1];
-        dst[0] = f32x4{a0.x + v[0], a0.y + v[1], a0.z + v[2], a0.w + v[3]};
-        dst[1] = f32x4{a1.x + v[4], a1.y + v[5], a1.z + v[6], a1.w + v[7]};
-      }
+      if (pass == 0) { dst[0] = f32x4{gacc[8 * j], gacc[8 * j + 1], gacc[8 * j + 2], gacc[8 * j + 3]}; dst[1] = f32x4{gacc[8 * j + 4], gacc[8 * j + 5], gacc[8 * j + 6], gacc[8 * j + 7]}; }
+      else { dst[0] = f32x4{bacc[8 * j], bacc[8 * j + 1], bacc[8 * j + 2], bacc[8 * j + 3]}; dst[1] = f32x4{bacc[8 * j + 4], bacc[8 * j + 5], bacc[8 * j + 6], bacc[8 * j + 7]}; }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int col = tid; col < KD; col += 512) {
-      const float t = ((red[col] + red[KD + col]) + (red[2 * KD + col] + red[3 * KD + col])) +
-                      ((red[4 * KD + col] + red[5 * KD + col]) + (red[6 * KD + col] + red[7 * KD + col]));
-      slab[pass * KD + col] = t;
+      float w[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w[q] = red[(2 * q) * KD + col] + red[(2 * q + 1) * KD + col];
+      slab[pass * KD + col] = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();      // everyone has read `red` before the next pass (or the next LayerNorm) overwrites it
   }
 }
 
@@ -457,7 +450,8 @@ template <int D, int VECF, int TS>
 __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   constexpr int MS = 16 * TS, LOG_MS = TS == 1 ? 4 : 5, FLY = 2 * D;   // FLY: weight loads of one wave in flight
   constexpr int PAN = MS * 1024;           // MS rows x 512 columns (or 2 MS x 256) of bf16
-  constexpr int VEC = 2 * PAN, TAB = VEC + VECF * 4;
+  // LDS: the two panels, 32 KiB of scratch for the LayerNorm-backward fold, the vectors, the tables
+  constexpr int RED = 2 * PAN, VEC = RED + 32768, TAB = VEC + VECF * 4;
   constexpr int SEG_BYTES = (int)sizeof(ChainSegK);
   constexpr int END0 = CHAIN_MAX_SEGS * SEG_BYTES, VEC0 = END0 + CHAIN_MAX_ENDS * (int)sizeof(ChainEndK);
   constexpr int TAB_BYTES = VEC0 + CHAIN_MAX_VECS * (int)sizeof(ChainVecK);
@@ -812,7 +806,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
             chain_ln_bwd<8>(pout, img_out, lane, r, valid_of(r), grow_of(r), vec + gb_off, lnb[ps], lms, dz, gacc, bacc);
           }
           stamp(104);
-          chain_ln_bwd_fold<8>(reinterpret_cast<float*>(pin), wave, lane, tid, gacc, bacc, slab);
+          chain_ln_bwd_fold<8>(reinterpret_cast<float*>(lds + RED), wave, lane, tid, gacc, bacc, slab);
         } else {
           float gacc[8], bacc[8];
 #pragma unroll
@@ -822,7 +816,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
             const int r = 16 * ps + 2 * wave + (lane >> 5);
             chain_ln_bwd<4>(pout, img_out, lane, r, valid_of(r), grow_of(r), vec + gb_off, lnb[ps], lms, dz, gacc, bacc);
           }
-          chain_ln_bwd_fold<4>(reinterpret_cast<float*>(pin), wave, lane, tid, gacc, bacc, slab);
+          chain_ln_bwd_fold<4>(reinterpret_cast<float*>(lds + RED), wave, lane, tid, gacc, bacc, slab);
         }
         stamp(103);
       } else if (has_ln) {
@@ -868,6 +862,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(112))) void cha
 }
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(120))) void chain_kernel_s32(const ChainKArgs a) {
   chain_body<2, CHAIN_VEC_FLOATS, 2>(a);
+}
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(120))) void chain_kernel_s16_d2(const ChainKArgs a) {   // option chain_depth = 2
+  chain_body<2, CHAIN_VEC_FLOATS, 1>(a);
 }
 
 }  // namespace
@@ -998,7 +995,8 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   MMDEER_CHECK(a.seg[a.nseg - 1].end_layer, "chain: the last segment must end its layer");
   MMDEER_CHECK(vec <= CHAIN_VEC_FLOATS, "chain: %d bias / gamma / beta floats exceed the LDS area (%d)", vec, CHAIN_VEC_FLOATS);
   k.nseg = a.nseg; k.nvec = nvec;
-  if (ts == 1) hipLaunchKernelGGL(chain_kernel_s16, dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
+  if (ts == 1 && opt(OPT_CHAIN_DEPTH) == 2) hipLaunchKernelGGL(chain_kernel_s16_d2, dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
+  else if (ts == 1) hipLaunchKernelGGL(chain_kernel_s16, dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
   else hipLaunchKernelGGL(chain_kernel_s32, dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
   MMDEER_HIP(hipGetLastError());
   return 0;

@@ -27,11 +27,13 @@ enum OptId {
   OPT_CHAIN_MAX,        // largest batch that takes the chains
   OPT_CHAIN_NIG,        // 1 (with the backward chain, loss mode): the head's last-layer backward + loss gradient run in the chain's prologue
   OPT_SPLITK_MAX,       // largest number of split-K slices of a weight-gradient problem (slabs: 4 B per parameter per slice)
+  OPT_CHAIN_DEPTH,      // weight stages a wave of the 16-sample layer-chain kernel keeps in flight: 4 (default) or 2
   OPT_COUNT
 };
 
 int opt(OptId id);                          // current value
-int opt_set(const char* name, int value);   // 0 = ok, -1 = unknown name
+int opt_set(const char* name, int value);   // 0 = ok, -1 = unknown name, -2 = value outside the option's range
+int opt_range(const char* name, int* lo, int* hi);
 int opt_get(const char* name, int* value);  // 0 = ok, -1 = unknown name
 const char* opt_name(int i);                // nullptr past the end
 
