@@ -40,7 +40,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-PROFILE_TAG = "r03"      # profiles/<tag>_* : the committed records of this round (tools/collect_profiles.py writes them)
+PROFILE_TAG = "r04"      # profiles/<tag>_* : the committed records of this round (tools/collect_profiles.py writes them)
 
 
 def _file_stamp(path):
@@ -245,9 +245,11 @@ def bench_stackb(args, dev, world, rank):
 
 
 def spawn_ranks(n, argv):
-    """`python bench.py --gpus N` (N > 1, not under a launcher): start N rank processes -- one per GPU -- as CHILD
-    processes of this one, which has not touched the GPU, and return their exit code.  The same command line the driver
-    uses for its own N > 1 runs (torch.distributed.run, 127.0.0.1 rendezvous)."""
+    """`python bench.py --gpus N` (N > 1, or the 1-rank rehearsal MMDEER_FORCE_COMM=1, not under a launcher): start N rank
+    processes -- one per GPU -- as CHILD processes of this one, which has not touched the GPU, and return their exit code.  The
+    same command line the driver uses for its own N > 1 runs (torch.distributed.run, 127.0.0.1 rendezvous) on a port the kernel
+    hands out at this moment (the tools that rehearse the data-parallel path go through here: a fixed --master-port reused by
+    back-to-back runs is one way to an exit status 1 with the reason on a stderr nobody kept)."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -334,7 +336,8 @@ def main():
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
-    if args.gpus > 1 and not under_launcher:
+    rehearsal = os.environ.get("MMDEER_FORCE_COMM") == "1" and not args.plumbing
+    if (args.gpus > 1 or rehearsal) and not under_launcher:
         # N ranks as child processes, started BEFORE anything here touches the GPU (device_count does not initialise it)
         if not args.plumbing and torch.cuda.device_count() < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
@@ -437,26 +440,35 @@ def main():
         def exchange():
             comm.launch(model.flat_grad())
             comm.wait()
+
+        def exchange_us(algo):
+            """One eager exchange with `algo` (allocates its staging buffer outside any capture), then the median of 10 timed ones."""
+            comm.algo = algo
+            exchange()
+            torch.cuda.synchronize()
+            xe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            if world > 1:
+                dist.barrier()
+            for e0, e1 in xe:
+                e0.record(); exchange(); e1.record()
+            torch.cuda.synchronize()
+            x = torch.tensor([sorted(e0.elapsed_time(e1) for e0, e1 in xe)[len(xe) // 2] * 1e3], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            return round(float(x), 1)
         # the communicator is set up by one eager step + exchange OUTSIDE any capture; the exchange alone is then timed with
         # events on the launch stream (max over ranks): what one all-reduce of the flat gradient costs when nothing hides it
         model.train_step(a, v, t, y, **sc)
-        exchange()
-        torch.cuda.synchronize()
-        xe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
-        if world > 1:
-            dist.barrier()
-        for e0, e1 in xe:
-            e0.record(); exchange(); e1.record()
-        torch.cuda.synchronize()
-        xus = torch.tensor([sorted(e0.elapsed_time(e1) for e0, e1 in xe)[len(xe) // 2] * 1e3], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(xus, op=dist.ReduceOp.MAX)
+        x_us = {"allreduce": exchange_us("allreduce"), "rs_ag": exchange_us("rs_ag")}
+        comm.algo = "allreduce"
         flat_elems = int(model.flat_grad().numel())
-        dp = {"nranks": dist.get_world_size(), "backend": f"{dist.get_backend()} ({comm.backend} all-reduce)",
+        dp = {"nranks": dist.get_world_size(),
+              "backend": f"{dist.get_backend()} for bootstrap / barriers; exchange through {'the C-ABI communicator (mmdeer_comm_*)' if comm.backend == 'rccl' else 'torch.distributed'}",
               "payload": args.grad_comm, "payload_bytes": flat_elems * (2 if args.grad_comm == "bf16" else 4),
-              "exchange_us": round(float(xus), 1),
-              "exchange_us_note": "median over 10 host-enqueued exchanges (cast + all-reduce + cast back) timed with HIP events on "
-                                  "the launch stream, max over ranks: includes the host latency of the collective call"}
+              "exchange_us": x_us["allreduce"], "exchange_us_by_algo": x_us,
+              "exchange_us_note": "median over 10 host-enqueued exchanges (cast + collective(s) + cast back) timed with HIP events on "
+                                  "the launch stream, max over ranks: includes the host latency of the collective call; allreduce = one "
+                                  "all-reduce, rs_ag = reduce-scatter + all-gather"}
     if not args.eager:
         if comm and os.environ.get("MMDEER_GRAPH_COMM", "1") == "1":
             # The exchange is captured into the step's graph (enqueued from the host after every replay it cost ~85 us per
@@ -467,29 +479,45 @@ def main():
             # BOTH are captured and timed over a few steps and the faster one is kept (MMDEER_DP_OVERLAP=0 / 1 forces
             # one); a plan whose capture fails is skipped, and without any the exchange is enqueued from the host.
             force_plan = os.environ.get("MMDEER_DP_OVERLAP")
+            force_algo = os.environ.get("MMDEER_DP_ALGO")          # allreduce | rs_ag: keeps only that single-exchange plan
             cands = []
             if force_plan != "1":
-                cands.append(("in-graph", dict(after=exchange)))
+                if force_algo in (None, "allreduce"):
+                    cands.append(("in-graph", dict(after=exchange), "allreduce"))
+                if force_algo in (None, "rs_ag"):
+                    cands.append(("in-graph reduce-scatter + all-gather", dict(after=exchange), "rs_ag"))
             if force_plan == "1" or (force_plan is None and world > 1):
-                cands.append(("overlapped in-graph", dict(comm=comm)))
-            plans, plan_ms = {}, {}
-            for name, kw in cands:
+                cands.append(("overlapped in-graph", dict(comm=comm), "allreduce"))
+            plans, plan_ms, plan_algo = {}, {}, {}
+            for name, kw, algo in cands:
                 try:
+                    comm.algo = algo            # frozen into the capture (the exchange closure reads it while capturing)
                     plans[name] = model.capture_train_step(a, v, t, y, events=ev, **kw, **sc)
+                    plan_algo[name] = algo
                 except Exception as e:               # noqa: BLE001
                     print(f"[bench] {name} exchange not capturable here ({type(e).__name__}: {e})", file=sys.stderr)
                     torch.cuda.synchronize()
-            compute_only = model.capture_train_step(a, v, t, y, events=ev, **sc)      # the step without any exchange
+            comm.algo = "allreduce"
+            try:                                                                       # the step without any exchange
+                compute_only = model.capture_train_step(a, v, t, y, events=ev, **sc)
+            except Exception as e:                   # noqa: BLE001  (this capture was the one outside any guard)
+                print(f"[bench] the step without exchange could not be captured ({type(e).__name__}: {e}); host-enqueued steps", file=sys.stderr)
+                torch.cuda.synchronize()
+                compute_only, plans = None, {}
+                dp["why"] = f"graph capture failed: {type(e).__name__}: {e}"
             for name, r in plans.items():
                 r(); r()
                 plan_ms[name] = round(timed(r, 10), 4)
-            compute_only(); compute_only()
-            compute_ms = round(timed(compute_only, 10), 4)
+            compute_ms = None
+            if compute_only is not None:
+                compute_only(); compute_only()
+                compute_ms = round(timed(compute_only, 10), 4)
             dp["compute_only_ms"] = compute_ms
             dp["plan_ms"] = plan_ms
             if plans:
                 best = min(plan_ms, key=plan_ms.get)
                 replay, comm_in_graph, comm_mode = plans[best], True, best
+                comm.algo = plan_algo[best]
                 dp["plan"] = best
                 dp["exposed_exchange_us"] = round((plan_ms[best] - compute_ms) * 1e3, 1)
                 dp["why"] = (f"forced by MMDEER_DP_OVERLAP={force_plan}" if force_plan is not None else
@@ -497,8 +525,10 @@ def main():
                               "fastest of the plans timed over 10 steps: " + ", ".join(f"{k} {v} ms" for k, v in plan_ms.items())))
             else:
                 replay, comm_mode = compute_only, "host-enqueued"
-                dp["plan"], dp["why"] = "host-enqueued", "no plan could be captured into the graph on this stack"
-        if replay is None:
+                comm.algo = min(x_us, key=x_us.get)
+                dp["plan"] = f"host-enqueued ({comm.algo})"
+                dp.setdefault("why", "no plan could be captured into the graph on this stack")
+        if replay is None and not (comm and os.environ.get("MMDEER_GRAPH_COMM", "1") == "1"):
             replay = model.capture_train_step(a, v, t, y, events=ev, **sc)
             comm_mode = "host-enqueued" if comm else "none"
             if dp is not None and "plan" not in dp:
@@ -640,6 +670,8 @@ def main():
                                    f"(it maintains the packed weight copies and is timed separately)", "global_batch": world * B,
                        "parallelism": (f"dp{world} (one process per GPU, gradient all-reduce over RCCL, {args.grad_comm} payload, "
                                         f"{comm_mode})" if world > 1 else "single")},
+            "inputs": "one resident batch replayed: the same (B,84)+(B,256)+(B,768) blocks every step (9 MB at B=4096 bf16, Infinity-Cache "
+                      "resident), fresh dropout masks per step; host-to-device copies are outside the metric (DESIGN.md section 7)",
             "launch": "eager" if replay is None else "hip-graph replay",
             # which launch plan ran: chosen by timing the plans on this GPU (untimed set-up), or the library's current options
             "launch_plan": launch_plan if launch_plan is not None else

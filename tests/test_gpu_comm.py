@@ -32,6 +32,20 @@ def test_rccl_communicator_single_rank_allreduce_and_capture():
         g.replay(); g.replay()
         torch.cuda.synchronize()
         assert torch.equal(y, torch.full_like(y, 4.0))
+        # reduce-scatter / all-gather (in place; one rank: identities), also inside a capture
+        z = torch.arange(1 << 12, device="cuda:0", dtype=torch.float32)
+        mine = comm.reduce_scatter(z, average=True)
+        comm.all_gather(z)
+        torch.cuda.synchronize()
+        assert mine.data_ptr() == z.data_ptr() and torch.equal(z, torch.arange(1 << 12, device="cuda:0", dtype=torch.float32))
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            z.add_(1.0)
+            comm.reduce_scatter(z, average=False)
+            comm.all_gather(z)
+        g2.replay(); g2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(z, torch.arange(1 << 12, device="cuda:0", dtype=torch.float32) + 2.0)
         with pytest.raises(ValueError):
             comm.all_reduce(torch.ones(4, device="cuda:0", dtype=torch.float64))
         comm.all_reduce(torch.empty(0, device="cuda:0"))    # empty buffer: a no-op
@@ -63,12 +77,14 @@ def test_bucketed_allreduce_gpu_paths_on_a_one_rank_group():
     try:
         n = int(_lib.load().mmdeer_flat_elems())
         ref = torch.randn(n, device="cuda:0")
+        assert BucketedAllReduce(device=torch.device("cuda", 0), force=True).backend == "rccl"     # the GPU default: the C-ABI communicator
         for backend in ("torch", "rccl"):
             for payload in ("bf16", "fp32"):
                 comm = BucketedAllReduce(device=torch.device("cuda", 0), force=True, payload=payload, backend=backend)
                 assert comm.active and comm.world == 1 and comm.backend == backend
-                for exact in (False, True):
+                for exact, algo in ((False, "allreduce"), (True, "allreduce"), (False, "rs_ag"), (True, "rs_ag")):
                     comm.exact_global = exact
+                    comm.algo = algo
                     flat = ref.clone()
                     comm.launch(flat)
                     comm.wait(flat)
@@ -88,5 +104,47 @@ def test_bucketed_allreduce_gpu_paths_on_a_one_rank_group():
                     comm._rccl.close()
         with pytest.raises(ValueError):
             BucketedAllReduce(device=torch.device("cuda", 0), backend="mpi")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_step_capture_with_a_live_process_group_and_an_in_graph_exchange():
+    """ADVICE r3 / DESIGN section 6: a HIP-graph capture of the training step while a process group is alive (its watchdog thread polls
+    events of earlier eager collectives; in the default 'global' capture mode such a call from another thread invalidates a capture
+    that is in progress -- the one unexplained exit-1 rehearsal of round 3).  capture_train_step captures in 'thread_local' mode then;
+    here: eager collectives first (work for the watchdog), then captures with both exchange algorithms inside, and replays."""
+    import torch.distributed as dist
+
+    from mmdeer import synth
+    from mmdeer.model import ModelConfig, MultimodalDEER
+    from mmdeer.parallel import BucketedAllReduce
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        dev = torch.device("cuda", 0)
+        m = MultimodalDEER(ModelConfig(compute_dtype="bf16", dropout=0.3, seed=3)).to(dev).train()
+        b = synth.make_batch(300, seed=5)
+        a, v, t, y = (torch.from_numpy(b[k]).to(dev) for k in ("audio", "video", "text", "targets"))
+        comm = BucketedAllReduce(device=dev, force=True)
+        for _ in range(4):                               # eager collectives of torch.distributed itself: the watchdog has work
+            dist.all_reduce(torch.ones(1024, device=dev))
+        m.train_step(a, v, t, y)
+
+        def exchange():
+            comm.launch(m.flat_grad())
+            comm.wait()
+        for algo in ("allreduce", "rs_ag"):
+            comm.algo = algo
+            exchange()                                   # staging buffers are allocated outside the capture
+            replay = m.capture_train_step(a, v, t, y, after=exchange)
+            l0 = float(replay()["total_loss"])
+            dist.all_reduce(torch.ones(8, device=dev))   # ... and between replays
+            l1 = float(replay()["total_loss"])
+            torch.cuda.synchronize()
+            assert l0 == l0 and l1 == l1 and abs(l0 - l1) < 1.0     # fresh dropout masks per replay, same batch
+            g = m.flat_grad()
+            assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
     finally:
         dist.destroy_process_group()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the summaries of tools/gpu_round_profiles.sh (gpurun_out/round/) into profiles/ under round-numbered names and write
 the metadata bench.py checks before quoting them (which kernel sources, batch and dtype they were measured on).
-usage: collect_profiles.py r03"""
+usage: collect_profiles.py r04"""
 import glob
 import json
 import os

@@ -8,10 +8,10 @@ set -u
 ROOT=$(pwd); export TMPDIR=/tmp
 OUT=gpurun_out/round; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 500 python bench.py > $OUT/bench_b4096_bf16.json 2> $OUT/bench_b4096_bf16.err; echo "bench default rc=$?"
-timeout -k 10 300 python bench.py --batch 8192 --no-cpu-baseline > $OUT/bench_b8192_bf16.json 2> /dev/null; echo "bench B=8192 rc=$?"
-timeout -k 10 300 python bench.py --batch 1024 --dtype fp32 --no-cpu-baseline > $OUT/bench_b1024_fp32.json 2> /dev/null; echo "bench fp32 rc=$?"
-timeout -k 10 300 python bench.py --batch 7 --no-cpu-baseline > $OUT/bench_b7_bf16.json 2> /dev/null; echo "bench B=7 rc=$?"
-timeout -k 10 200 python tools/fwd_only.py > $OUT/fwd_only.txt 2> /dev/null; echo "fwd only rc=$?"
+timeout -k 10 300 python bench.py --batch 8192 --no-cpu-baseline > $OUT/bench_b8192_bf16.json 2> $OUT/bench_b8192_bf16.err; echo "bench B=8192 rc=$?"
+timeout -k 10 300 python bench.py --batch 1024 --dtype fp32 --no-cpu-baseline > $OUT/bench_b1024_fp32.json 2> $OUT/bench_b1024_fp32.err; echo "bench fp32 rc=$?"
+timeout -k 10 300 python bench.py --batch 7 --no-cpu-baseline > $OUT/bench_b7_bf16.json 2> $OUT/bench_b7_bf16.err; echo "bench B=7 rc=$?"
+timeout -k 10 200 python tools/fwd_only.py > $OUT/fwd_only.txt 2> $OUT/fwd_only.err; echo "fwd only rc=$?"
 ( cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $ROOT/$OUT/rocprof.log 2>&1; echo "rocprof rc=$?" )
 python tools/step_trace.py $OUT/prof/*/*_kernel_trace.csv 3 > $OUT/step_trace.txt 2>&1; echo "step trace rc=$?"
 bash tools/gpu_pmc_fused.sh > $OUT/pmc.log 2>&1; echo "pmc rc=$?"
@@ -23,9 +23,9 @@ timeout -k 10 200 python tools/chain_stamps.py 4096 > $OUT/chain_stamps.txt 2>&1
 timeout -k 10 200 python tools/chain_stamps.py 4096 bwd > $OUT/chain_stamps_bwd.txt 2>&1; echo "chain stamps (backward head chain) rc=$?"
 timeout -k 10 120 tools/probes/calibrate > $OUT/calibration.txt 2>&1; echo "calibration rc=$?"
 timeout -k 10 300 python tools/stackb_fused_time.py > $OUT/stackb_train.txt 2>&1; echo "stack B training rc=$?"
-# data-parallel rehearsal on the one GPU (1-rank group, the collective really runs): single in-graph exchange vs overlapped plan
-MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=0 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_single.json 2> $OUT/bench_dp1_single.err; echo "dp single rc=$?"
-MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_overlap.json 2> $OUT/bench_dp1_overlap.err; echo "dp overlap rc=$?"
-MMDEER_FORCE_COMM=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_auto.json 2> $OUT/bench_dp1_auto.err; echo "dp auto rc=$?"
-MMDEER_CHAIN=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_nochain.json 2> /dev/null; echo "bench without chains rc=$?"
+# data-parallel rehearsal on the one GPU (1-rank group, the collectives really run; bench.py starts its rank on a free port)
+MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=0 timeout -k 10 300 python bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_single.json 2> $OUT/bench_dp1_single.err; echo "dp single rc=$?"
+MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=1 timeout -k 10 300 python bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_overlap.json 2> $OUT/bench_dp1_overlap.err; echo "dp overlap rc=$?"
+MMDEER_FORCE_COMM=1 timeout -k 10 300 python bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_auto.json 2> $OUT/bench_dp1_auto.err; echo "dp auto rc=$?"
+MMDEER_CHAIN=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_nochain.json 2> $OUT/bench_b4096_nochain.err; echo "bench without chains rc=$?"
 ls -la $OUT

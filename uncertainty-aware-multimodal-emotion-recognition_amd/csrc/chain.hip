@@ -150,7 +150,10 @@ struct ChainVecK {           // one bias / gamma / beta vector to stage into LDS
   const float* src;
   int off, n4;               // LDS float offset, 16-byte chunks
 };
-static_assert(sizeof(ChainSegK) == 96 && sizeof(ChainEndK) == 80 && sizeof(ChainVecK) == 16, "table record sizes");
+// One table record per segment: its end part directly behind it (valid when seg.end >= 0), so that the whole record of the NEXT
+// segment sits at an address that depends on nothing but the segment index and can be requested before the layer end's barrier.
+struct ChainRecK { ChainSegK seg; ChainEndK end; };
+static_assert(sizeof(ChainSegK) == 96 && sizeof(ChainEndK) == 80 && sizeof(ChainVecK) == 16 && sizeof(ChainRecK) == 176, "table record sizes");
 
 struct ChainKArgs {
   const bf16_t* X;
@@ -160,12 +163,11 @@ struct ChainKArgs {
   int nseg, nvec;
   DropCtx drop;
   unsigned long long* stamps;
-  ChainSegK seg[CHAIN_MAX_SEGS];
-  ChainEndK end[CHAIN_MAX_ENDS];
+  ChainRecK rec[CHAIN_MAX_SEGS];
   ChainVecK vec[CHAIN_MAX_VECS];
   ChainNig nig;      // behind the tables: not copied to LDS, read as kernel arguments
 };
-static_assert(__builtin_offsetof(ChainKArgs, seg) % 16 == 0, "tables must be 16-byte aligned");
+static_assert(__builtin_offsetof(ChainKArgs, rec) % 16 == 0, "tables must be 16-byte aligned");
 static_assert(sizeof(ChainKArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 struct ChainLnOut {
@@ -452,8 +454,8 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   constexpr int PAN = MS * 1024;           // MS rows x 512 columns (or 2 MS x 256) of bf16
   // LDS: the two panels, 32 KiB of scratch for the LayerNorm-backward fold, the vectors, the tables
   constexpr int RED = 2 * PAN, VEC = RED + 32768, TAB = VEC + VECF * 4;
-  constexpr int SEG_BYTES = (int)sizeof(ChainSegK);
-  constexpr int END0 = CHAIN_MAX_SEGS * SEG_BYTES, VEC0 = END0 + CHAIN_MAX_ENDS * (int)sizeof(ChainEndK);
+  constexpr int SEG_BYTES = (int)sizeof(ChainRecK), END_OFF = (int)sizeof(ChainSegK);
+  constexpr int VEC0 = CHAIN_MAX_SEGS * SEG_BYTES;
   constexpr int TAB_BYTES = VEC0 + CHAIN_MAX_VECS * (int)sizeof(ChainVecK);
   static_assert(TAB_BYTES % 16 == 0 && TAB_BYTES / 16 <= 512, "one 16-byte chunk of the tables per thread");
   static_assert(TAB + TAB_BYTES <= 160 * 1024, "LDS budget");
@@ -503,7 +505,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   }
   // ---- the tables into LDS: one parallel vector load
   {
-    const unsigned char* src = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ChainKArgs, seg);
+    const unsigned char* src = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ChainKArgs, rec);
     if (tid < TAB_BYTES / 16) *reinterpret_cast<u32x4*>(lds + TAB + 16 * tid) = *reinterpret_cast<const u32x4*>(src + 16 * tid);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -702,9 +704,19 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     }
   };
 
+  // The table record of a segment (its end part included) is requested while the segment BEFORE it winds down -- in front of the
+  // layer end's barrier, where half the waves wait for the other half anyway -- and only converted to scalars here: read at the top
+  // of the loop and again behind the barrier, the three dependent LDS round trips and their waits were ~1500 cycles per layer.
+  u32x4 R[11];
+  auto fetch_rec = [&](int si_) __attribute__((always_inline)) {
+    const u32x4* rec = reinterpret_cast<const u32x4*>(tab + si_ * SEG_BYTES);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) R[k] = rec[k];
+  };
+  fetch_rec(0);
   for (int si = 0; si < nseg; ++si) {
-    const u32x4* rec = reinterpret_cast<const u32x4*>(tab + si * SEG_BYTES);
-    const u32x4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+    const u32x4 q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3], q4 = R[4], q5 = R[5];
+    const u32x4 e0 = R[6], e1 = R[7], e2 = R[8], e3 = R[9], e4 = R[10];
     const int nkt = sc(q0.w), kb = sc(q1.y), endi = sc(q1.z);
     SegCtl sg;
     sg.ntiles = sc(q1.x); sg.N = sc(q1.w);
@@ -713,10 +725,17 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     const int mb = sc(q3.w);
     sg.rows_out = sc(q4.x); sg.kin_off = sc(q4.y);
     sg.mask_scale = __uint_as_float((unsigned)sc(q4.z)); sg.has_bias = sc(q4.w);
-    {
-      const u32x4 q5 = rec[5];
-      sg.mask_y = reinterpret_cast<const bf16_t*>(sp(q5.x, q5.y)); sg.ld_mask = sc(q5.z); sg.mask_col0 = sc(q5.w);
-    }
+    sg.mask_y = reinterpret_cast<const bf16_t*>(sp(q5.x, q5.y)); sg.ld_mask = sc(q5.z); sg.mask_col0 = sc(q5.w);
+    // the end part, as scalars, now: stash / LayerNorm pointers, widths, kind
+    bf16_t* const stash = reinterpret_cast<bf16_t*>(sp(e0.x, e0.y));
+    bf16_t* const end_xln = reinterpret_cast<bf16_t*>(sp(e0.z, e0.w));
+    float* const end_out32 = reinterpret_cast<float*>(sp(e1.x, e1.y));
+    float* const end_mean = reinterpret_cast<float*>(sp(e1.z, e1.w));
+    float* const end_rstd = reinterpret_cast<float*>(sp(e2.x, e2.y));
+    const int ld_stash = sc(e2.z), nout = sc(e2.w);
+    const int gb_off = sc(e3.x), has_ln = endi >= 0 ? sc(e3.y) : 0;
+    const bf16_t* const end_lnb_y = reinterpret_cast<const bf16_t*>(sp(e3.z, e3.w));
+    const float lms = __uint_as_float((unsigned)sc(e4.x));
     // a layer that ends in a LayerNorm backward: this lane's chunks of the forward's rows and the row statistics.
     // 16-sample workgroups request them NOW, before the segment's weight stages (>= D of them: FLY younger loads), and wait with
     // vmcnt(FLY) at the layer end; 32-sample workgroups have no registers to hold them across the segment (the compiler would spill
@@ -724,13 +743,10 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     ChainLnbIn lnb[TS];
 #pragma unroll
     for (int ps = 0; ps < TS; ++ps) { lnb[ps].y[0] = lnb[ps].y[1] = u32x4{0u, 0u, 0u, 0u}; lnb[ps].mu = 0.f; lnb[ps].rs = 0.f; }
-    auto lnb_fetch = [&](int endi_) __attribute__((always_inline)) {
-      const u32x4* er = reinterpret_cast<const u32x4*>(tab + END0 + endi_ * (int)sizeof(ChainEndK));
-      const u32x4 e1 = er[1], e2 = er[2], e3 = er[3];
-      const bf16_t* ly = reinterpret_cast<const bf16_t*>(sp(e3.z, e3.w));
-      const float* lmean = reinterpret_cast<const float*>(sp(e1.z, e1.w));
-      const float* lrstd = reinterpret_cast<const float*>(sp(e2.x, e2.y));
-      const int nout = sc(e2.w);
+    auto lnb_fetch = [&]() __attribute__((always_inline)) {
+      const bf16_t* ly = end_lnb_y;
+      const float* lmean = end_mean;
+      const float* lrstd = end_rstd;
 #pragma unroll
       for (int ps = 0; ps < TS; ++ps) {       // 16 rows per pass: this lane's row is 16 ps + 2 wave + (lane >> 5)
         const int r = 16 * ps + 2 * wave + (lane >> 5);
@@ -742,7 +758,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
         asm volatile("global_load_dword %0, %1, off" : "=v"(lnb[ps].rs) : "v"(lrstd + gr) : "memory");
       }
     };
-    if (TS == 1 && endi >= 0 && sc(*reinterpret_cast<const unsigned*>(tab + END0 + endi * (int)sizeof(ChainEndK) + 52)) == 2) lnb_fetch(endi);
+    if (TS == 1 && has_ln == 2) lnb_fetch();
     stamp(3 + 3 * si);
 #define CH_SEG(MBv, KBv, NKTv) seg_body(std::integral_constant<int, MBv>{}, std::integral_constant<bool, KBv>{}, std::integral_constant<int, NKTv>{}, sg)
     if (!kb) {
@@ -758,32 +774,26 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     }
 #undef CH_SEG
     stamp(4 + 3 * si);
+    fetch_rec(si + 1 < nseg ? si + 1 : 0);       // the next segment's record: lands while this layer ends
     if (endi >= 0) {
       const int rows_out = sg.rows_out, img_out = rows_out * 128;
       wstamp(200 + 8 * si + wave);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();              // the output panel is complete
       stamp(130 + 4 * si);
-      const u32x4* er = reinterpret_cast<const u32x4*>(tab + END0 + endi * (int)sizeof(ChainEndK));
-      const u32x4 e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
-      bf16_t* stash = reinterpret_cast<bf16_t*>(sp(e0.x, e0.y));
-      const int ld_stash = sc(e2.z), nout = sc(e2.w);
-      const int gb_off = sc(e3.x), has_ln = sc(e3.y);
       if (has_ln == 2) {
         stamp(100);
         if constexpr (TS == 1) {
           asm volatile("s_waitcnt vmcnt(%4)" : "+v"(lnb[0].y[0]), "+v"(lnb[0].y[1]), "+v"(lnb[0].mu), "+v"(lnb[0].rs) : "n"(FLY) : "memory");
         } else {
-          lnb_fetch(endi);
+          lnb_fetch();
 #pragma unroll
           for (int ps = 0; ps < TS; ++ps)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(lnb[ps].y[0]), "+v"(lnb[ps].y[1]), "+v"(lnb[ps].mu), "+v"(lnb[ps].rs) : : "memory");
         }
         stamp(101);
-        const u32x4 e4 = er[4];
-        const float lms = __uint_as_float((unsigned)sc(e4.x));
-        bf16_t* dz = reinterpret_cast<bf16_t*>(sp(e0.z, e0.w));
-        float* slab = reinterpret_cast<float*>(sp(e1.x, e1.y)) + (long long)blockIdx.x * 2 * nout;
+        bf16_t* dz = end_xln;
+        float* slab = end_out32 + (long long)blockIdx.x * 2 * nout;
         if (stash) {       // the raw panel (d out of the LayerNorm) first: the teacher-forced tests and g_fused callers read it
           const int nch = nout >> 3;
           for (int rr = wave; rr < rows_out; rr += 8) {
@@ -821,22 +831,29 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
         stamp(103);
       } else if (has_ln) {
         ChainLnOut o;
-        o.stash = stash; o.xln = reinterpret_cast<bf16_t*>(sp(e0.z, e0.w)); o.out32 = reinterpret_cast<float*>(sp(e1.x, e1.y));
-        o.mean = reinterpret_cast<float*>(sp(e1.z, e1.w)); o.rstd = reinterpret_cast<float*>(sp(e2.x, e2.y));
+        o.stash = stash; o.xln = end_xln; o.out32 = end_out32;
+        o.mean = end_mean; o.rstd = end_rstd;
         o.ld_stash = ld_stash; o.gb_off = gb_off;
         for (int r = 2 * wave + (lane >> 5); r < rows_out; r += 16) {
           if (nout == 512) chain_ln<8>(pout, img_out, r, valid_of(r), grow_of(r), lane, vec, o);
           else chain_ln<4>(pout, img_out, r, valid_of(r), grow_of(r), lane, vec, o);
         }
       } else if (stash) {
+        // a wave copies rows wave, wave + 8, ...: every LDS read first, then the stores (row by row the two dependent LDS round trips
+        // were most of the copy's 1250 cycles)
         const int nch = nout >> 3;
-        for (int r = wave; r < rows_out; r += 8) {
-          if (!valid_of(r)) continue;
-          const long long gr = grow_of(r);
-          for (int cc = lane; cc < nch; cc += 64) {
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(pout + (cc >> 3) * img_out + r * 128 + (((cc & 7) ^ (r & 7)) * 16));
-            store_wt16(stash + gr * ld_stash + cc * 8, raw);
-          }
+        constexpr int NR = 4 * TS;                        // rows per wave: at most 2 groups x MS / 8; a row is <= 64 chunks: one per lane
+        u32x4 raw[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          const int r = wave + 8 * q;
+          if (r < rows_out && lane < nch) raw[q] = *reinterpret_cast<const u32x4*>(pout + (lane >> 3) * img_out + r * 128 + (((lane & 7) ^ (r & 7)) * 16));
+        }
+        stamp(132 + 4 * si);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          const int r = wave + 8 * q;
+          if (r < rows_out && lane < nch && valid_of(r)) store_wt16(stash + grow_of(r) * ld_stash + lane * 8, raw[q]);
         }
       }
       // A LayerNorm (forward or backward) rewrote the panel in place: everyone must see it before the next layer reads it.  A plain
@@ -950,7 +967,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     MMDEER_CHECK(ntl <= 4, "chain: segment %d has too many column tiles", i);
     MMDEER_CHECK(kb ? ((nkt == 2 || nkt == 4) && mblocks * nkt <= 4 * ts) : ((nkt == 1 || nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8) && mblocks * nkt <= 8 * ts),
                  "chain: segment %d: K = %d with %d row blocks is not instantiated", i, s.K, mblocks);
-    ChainSegK& td = k.seg[i];
+    ChainSegK& td = k.rec[i].seg;
     td.W = s.W; td.ldw = s.K; td.nkt = nkt; td.ntiles = ntl; td.kindb = kb; td.end = -1;
     td.N = s.N; td.vec_off = vec_off; td.dcol_off = s.dcol_off; td.nout_off = s.nout_off;
     td.site = s.drop_site; td.shift = s.drop_shift; td.relu = s.relu; td.fold = s.fold_groups;
@@ -965,8 +982,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
                    "chain: segment %d unfolds: one row group, N = 2 x the panel width", i);
       MMDEER_CHECK(s.nout % 64 == 0 && s.nout * blocks_out <= 512 * ts, "chain: layer ending at segment %d does not fit the panel", i);
       MMDEER_CHECK(!s.stash || (((uintptr_t)s.stash % 16) == 0 && s.ld_stash % 8 == 0), "chain: segment %d stash alignment", i);
-      MMDEER_CHECK(nend < CHAIN_MAX_ENDS, "chain: too many layers");
-      ChainEndK& e = k.end[nend];
+      ChainEndK& e = k.rec[i].end;
       e.stash = s.stash; e.ld_stash = s.ld_stash; e.nout = s.nout;
       if (s.lnb_gamma) {
         MMDEER_CHECK(!s.gamma && (s.nout == 256 || s.nout == 512) && blocks_out == ts, "chain: LayerNorm backward of segment %d: width %d, one row group", i, s.nout);
@@ -987,7 +1003,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
         add_vec(s.beta, s.nout);
       }
       td.end = nend++;
-      for (int t = layer_first_seg; t <= i; ++t) k.seg[t].rows_out = blocks_out * 16;   // every segment of the layer needs the output geometry
+      for (int t = layer_first_seg; t <= i; ++t) k.rec[t].seg.rows_out = blocks_out * 16;   // every segment of the layer needs the output geometry
       layer_first_seg = i + 1;
       blocks_in = blocks_out; width_in = s.nout;
     }
