@@ -107,8 +107,8 @@ def recorded_profile(batch, dtype):
             rec["mfma_tflops"] = {}
             for kname, fl in (("gemm_tt_dma_kernel<128, 128, 2>", 2.0 * B * w_sq), ("gemm_tt_dma_kernel<128, 128, 1>", 2.0 * B * w_sq),
                               ("gemm_tt_dma_kernel<256, 256, 1>", 2.0 * B * w_sq),
-                              ("chain_kernel<6, 4864, 1>", 2.0 * B * sum(chain_w.values()) / nchain),
-                              ("chain_kernel<4, 4864, 2>", 2.0 * B * sum(chain_w.values()) / nchain)):
+                              ("chain_kernel_s16", 2.0 * B * sum(chain_w.values()) / nchain),
+                              ("chain_kernel_s32", 2.0 * B * sum(chain_w.values()) / nchain)):
                 if kname in avg:
                     rec["mfma_tflops"][kname] = {"avg_us": round(avg[kname] * 1e6, 2), "tflops": round(fl / avg[kname] / 1e12, 1),
                                                  "frac_of_mfma_peak": round(fl / avg[kname] / BF16_MFMA_PEAK, 4),

@@ -348,6 +348,63 @@ def test_layer_chain_launch_is_bit_identical_to_the_separate_launches(B):
         assert torch.equal(on[2][k], off[2][k]), k
 
 
+def _input_chain_step(B, **opts):
+    """A training step on bf16 feature blocks (the bench's inputs) + the workspace buffers the input projections leave behind."""
+    lib = _lib.load()
+    b = synth.make_batch(B, seed=23)
+    a, v, t = (torch.from_numpy(b[k]).to(DEV).bfloat16() for k in ("audio", "video", "text"))
+    y = torch.from_numpy(b["targets"]).to(DEV)
+    m = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=6)).to(DEV).train()
+    with _lib.options(chain_min=1, **opts):
+        d = m.train_step(a, v, t, y)
+        torch.cuda.synchronize()
+    ws = m._workspace(B, torch.device(DEV)).view(torch.uint8)
+    bufs = {}
+    for name, nbytes in (("avin", 2 * B * 256 * 2), ("xtok", 2 * B * 512 * 2), ("audio_pad", B * 128 * 2)):
+        off = lib.mmdeer_workspace_offset(B, 0, name.encode())
+        bufs[name] = ws[off:off + nbytes].clone()
+    return float(d["total_loss"]), m.flat_grad().clone(), {k: d[k].clone() for k in ("gamma", "nu", "alpha", "beta") if k in d}, bufs
+
+
+@pytest.mark.parametrize("B", [300, 2500, 4096])
+def test_input_chain_is_bit_identical_to_the_pad_and_projection_launches(B):
+    """Option chain_in (bf16 feature blocks, B <= 4096): the audio-visual chain's launch starts from the raw text / video / 84-wide
+    audio rows -- text_projection, video_projection and audio_projection (on rows it pads in LDS) are its first two layers -- instead
+    of reading what a pad launch and the three-problem projection launch left.  Same k order in the MFMAs, same bias add: the stacked
+    attention input, token 1 of xtok, the padded audio copy the weight-gradient launch reads, the loss, the outputs and every
+    gradient must come out bit for bit (B = 300, 2500: ragged 16-sample blocks)."""
+    on, off = _input_chain_step(B, chain_in=1), _input_chain_step(B, chain_in=0)
+    for name in on[3]:
+        assert torch.equal(on[3][name], off[3][name]), name
+    assert on[0] == off[0]
+    for k in on[2]:
+        assert torch.equal(on[2][k], off[2][k]), k
+    assert torch.equal(on[1], off[1])
+
+
+def test_input_chain_graph_replay_matches_eager():
+    """The device-side dropout counter is advanced by the forward's last kernel (the NIG head) now that no pad launch precedes the
+    first mask: captured replays of the input-chain plan reproduce eager steps, loss and gradient, with fresh masks per replay."""
+    import copy
+    B = 600
+    with _lib.options(chain_min=1):
+        m1 = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=12)).to(DEV).train()
+        m2 = copy.deepcopy(m1)
+        b = synth.make_batch(B, seed=9)
+        a, v, t = (torch.from_numpy(b[k]).to(DEV).bfloat16() for k in ("audio", "video", "text"))
+        y = torch.from_numpy(b["targets"]).to(DEV)
+        replay = m1.capture_train_step(a, v, t, y)
+        m2.train_step(a, v, t, y)
+        losses = []
+        for _ in range(3):
+            d1 = replay()
+            d2 = m2.train_step(a, v, t, y)
+            assert float(d1["total_loss"]) == float(d2["total_loss"])
+            assert torch.equal(m1.flat_grad(), m2.flat_grad())
+            losses.append(float(d1["total_loss"]))
+        assert len(set(losses)) == 3
+
+
 @pytest.mark.parametrize("B", [300, 2500, 4096, 5000, 8192])
 def test_backward_chain_matches_the_separate_launches(B):
     """The backward's head / trimodal run (7 dX products with their (Y > 0) masks, two LayerNorm backwards with gamma / beta

@@ -82,6 +82,7 @@ struct Layout {
   float* wscratch;   // ADAM_NPART floats: sum-of-squares partials of the optimiser step
   char* wfpack;  // bf16 mode: fragment-major images (chain.h) of the matrices the forward layer chains stream, at their flat offsets
   char* wtfpack; // bf16 mode: the same of the W^T matrices the backward chains stream
+  char* wa_frag; // bf16 mode: fragment-major image of wa_pad (the input chain's audio projection)
   size_t wbytes;     // size of the weights buffer
   // ---- per-batch workspace
   char* audio_pad;   // bf16 mode: the audio feature block as [B][AUD_PAD]
@@ -113,6 +114,7 @@ Layout make_layout(void* base, void* wbase, int B, int f32) {
   L.wscratch = reinterpret_cast<float*>(take((size_t)ADAM_NPART * 4));
   L.wfpack = take(f32 ? 0 : (size_t)MMDEER_FLAT_ELEMS * 2);
   L.wtfpack = take(f32 ? 0 : (size_t)MMDEER_FLAT_ELEMS * 2);
+  L.wa_frag = take(f32 ? 0 : (size_t)INTER * AUD_PAD * 2);
   L.wbytes = off;
   off = 0;
   b = reinterpret_cast<char*>(base);
@@ -164,7 +166,7 @@ OptEntry g_opts[OPT_COUNT] = {
     {"glds", 1, 0, 1, {1}}, {"nt8", 1, 0, 1, {1}}, {"t128", 512, 1, 1 << 30, {512}}, {"tile", -1, -1, 4, {-1}}, {"ksteps", 0, 0, 4096, {0}},
     {"ln_fused", 1, 0, 1, {1}}, {"chain", 1, 0, 1, {1}}, {"chain_bwd", 1, 0, 1, {1}}, {"chain_min", 2049, 1, 1 << 30, {2049}},
     {"dw_tile", 2, 2, 4, {2}}, {"dw_kg", 2, 1, 2, {2}}, {"chain_max", 8192, 1, 1 << 30, {8192}}, {"chain_nig", 1, 0, 1, {1}},
-    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 4, {4}},
+    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 4, {4}}, {"chain_in", 1, 0, 1, {1}},
 };
 }  // namespace
 
@@ -402,6 +404,9 @@ int pack_frag_images(const Layout& L, bool with_transposed, hipStream_t s) {
   fwd(P_TOUT_W, FUS, FUS); fwd(P_TFF_W, FUS, FUS); fwd(P_OP_W, FUS, FUS);
   fwd(P_FP0_W, HID, FUS); fwd(P_FP1_W, HID, HID); fwd(P_EV0_W, 3 * EV1, HID);
   for (int z = 0; z < 3; ++z) fwd(P_EV1_W, EV2, EV1, (long long)z * EV2 * EV1);
+  // the input chain (F1 inside the audio-visual chain, B <= 4096): text and video projections, and the zero-padded audio projection
+  fwd(P_TXT_W, FUS, TXT); fwd(P_VID_W, INTER, VID);
+  add(L.wa_pad, L.wa_frag, 0, AUD_PAD, INTER, AUD_PAD, 0);       // needs pad_audio_weight first
   if (with_transposed) {   // W^T as stored by pack_transposed_weights: [cols of W][rows of W]
     auto bwd = [&](int pid, int N, int K, long long sub = 0) { add(L.wtpack, L.wtfpack, o(pid) + sub, K, N, K, o(pid) + sub); };
     for (int z = 0; z < 3; ++z) bwd(P_EV1_W, EV1, EV2, (long long)z * EV2 * EV1);
@@ -516,40 +521,43 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     // the parameters are unchanged, so an inference call followed by a training call on the same parameters would find
     // them missing (the backward pass then multiplied by whatever the buffer held)
     TRY(pack_transposed_weights(a->params, L, f32, s));
-    if (!f32) TRY(pack_frag_images(L, true, s));
+    if (!f32) {    // the padded bf16 copy of audio_projection.weight + the head-major in_proj image, then the fragment-major images
+      TRY(pad_audio_weight(a->params, L, s));
+      TRY(pack_frag_images(L, true, s));
+    }
   }
-  const bool wa_pending = a->repack && !f32;   // the padded bf16 copy of audio_projection.weight follows the parameters
-  if (B == 0) {
-    if (wa_pending) TRY(pad_audio_weight(a->params, L, s));
-    return 0;
-  }
+  if (B == 0) return 0;
   MMDEER_CHECK(a->audio && a->video && a->text, "audio / video / text must be non-NULL");
   MMDEER_CHECK(a->nig_out != nullptr, "nig_out is NULL");
 
   Exec X;
   X.B = B; X.f32 = f32; X.es = f32 ? 4 : 2; X.L = &L; X.s = s;
   X.drop_on = a->training && a->dropout_p > 0.f;
-  X.dc = make_drop(a->dropout_p, a->seed, a->offset, a->offset_dev);
+  // The device-side dropout step counter (HIP-graph replays) is advanced by the LAST kernel of the forward (the NIG head, which
+  // draws no mask) instead of its first: the forward's kernels add the pending 1 to the host-side offset, the backward's read the
+  // advanced counter -- every kernel of the step sees the same effective offset, and no kernel in front of the first mask has to
+  // exist just to bump it.
+  unsigned long long* const bump = (a->bump_offset_dev && a->offset_dev) ? reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(a->offset_dev)) : nullptr;
+  X.dc = make_drop(a->dropout_p, a->seed, a->offset + (bump ? 1 : 0), a->offset_dev);
   X.mask_scale = X.drop_on ? X.dc.scale : 1.f;
   const int in_f32 = a->inputs_bf16 ? 0 : 1;
   const size_t es = X.es;
+  const bool chains = !f32 && opt(OPT_CHAIN) && B >= opt(OPT_CHAIN_MIN) && B <= opt(OPT_CHAIN_MAX);
+  // The input chain: with bf16 feature blocks and 16-sample chain workgroups (B <= 4096) the three input projections run as the
+  // first two layers of the audio-visual chain below -- the workgroup reads its samples' text, video and raw 84-wide audio rows
+  // itself (padding the audio rows in LDS and leaving the padded copy for the weight-gradient launch): no pad launch, no F1 launch.
+  const bool in_chain = chains && opt(OPT_CHAIN_IN) && !in_f32 && chain_samples_per_workgroup(B) == 16;
 
-  // F0 (bf16 mode): 84-wide rows are not 16-byte aligned -- zero-pad the audio block (and, when the parameters
-  //     changed, the audio projection weight) to 128 columns so both run on the LDS-DMA kernels
-  if (!f32) {
+  // F0 (bf16 mode): 84-wide rows are not 16-byte aligned -- zero-pad the audio block to 128 columns so that it runs on the
+  //     LDS-DMA kernels
+  if (!f32 && !in_chain) {
     PadTable pt{};
     pt.src[0] = a->audio; pt.dst[0] = L.audio_pad; pt.src_f32[0] = in_f32; pt.rows[0] = B; pt.cols[0] = AUD; pt.ld_dst[0] = AUD_PAD;
     pt.nseg = 1;
-    if (a->bump_offset_dev && a->offset_dev) pt.bump = reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(a->offset_dev));
-    if (wa_pending) {
-      pt.src[1] = a->params[P_AUD_W]; pt.dst[1] = L.wa_pad; pt.src_f32[1] = 1; pt.rows[1] = INTER; pt.cols[1] = AUD; pt.ld_dst[1] = AUD_PAD;
-      pt.nseg = 2;
-    }
     TRY(launch_pad_cols(pt, s));
-    if (wa_pending) TRY(launch_pack_qkv_headmajor(reinterpret_cast<const float*>(a->params[P_TIN_W]), L.wqkv_hm, s));
   }
   // F1: the three input projections (fusion.py:236-237, 322) in one launch
-  {
+  if (!in_chain) {
     GemmGroup g{};
     g.nprob = 3;
     g.p[0] = X.fwd(a->video, in_f32, VID, P_VID_W, P_VID_B, L.avin, INTER, B, 0, -1);                       // rows [0,B)
@@ -576,7 +584,6 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   // whatever the batch: worth it while the chip holds all workgroups at once and most CUs have one (measured per step: B = 4096
   // -5 to -15 us depending on the box, 3072 -4 us, 2048 0, 1024 +1 us, 64 +12 us; 16-sample workgroups in two rounds at 8192:
   // +9 us, 32-sample workgroups: see DESIGN.md)
-  const bool chains = !f32 && opt(OPT_CHAIN) && B >= opt(OPT_CHAIN_MIN) && B <= opt(OPT_CHAIN_MAX);
   // F2-F6 are local to a sample (the AV "attention" has one key per query: softmax == 1, only the value and output projections
   // remain): in bf16 mode ONE launch walks them with the rows resident in LDS (chain.hip).  A workgroup holds the video and the
   // audio row of its 16 samples as two row groups; torch.cat of the two attention outputs is a re-view of the panel.
@@ -585,6 +592,33 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     c.X = reinterpret_cast<const bf16_t*>(L.avin); c.ldx = INTER; c.K0 = INTER; c.B = B; c.groups = 2; c.group_stride = B;
     c.drop = X.dc;
     int k = 0;
+    if (in_chain) {
+      c.X = reinterpret_cast<const bf16_t*>(a->text); c.ldx = TXT; c.K0 = TXT; c.groups = 1;
+      c.aux_video = reinterpret_cast<const bf16_t*>(a->video); c.aux_ldv = VID;
+      c.aux_audio = reinterpret_cast<const bf16_t*>(a->audio); c.aux_lda = AUD;
+      c.aux_audio_pad = reinterpret_cast<bf16_t*>(L.audio_pad);
+      {   // F1c: text_projection -> token 1 of xtok (fusion.py:322, 325)
+        ChainSeg q;
+        chain_seg_defaults(q);
+        q.W = X.WF(P_TXT_W); q.bias = X.V(P_TXT_B); q.N = FUS; q.K = TXT;
+        q.end_layer = 1; q.nout = FUS; q.stash = reinterpret_cast<bf16_t*>(L.xtok) + FUS; q.ld_stash = 2 * FUS;
+        c.seg[k++] = q;
+      }
+      {   // F1a: video_projection -> rows [0, B) of the stacked attention input (fusion.py:237)
+        ChainSeg q;
+        chain_seg_defaults(q);
+        q.W = X.WF(P_VID_W); q.bias = X.V(P_VID_B); q.N = INTER; q.K = VID; q.in_aux = 1; q.kin_off = 0;
+        c.seg[k++] = q;
+      }
+      {   // F1b: audio_projection on the padded rows -> rows [B, 2B) (fusion.py:236)
+        ChainSeg q;
+        chain_seg_defaults(q);
+        q.W = reinterpret_cast<const bf16_t*>(L.wa_frag); q.bias = X.V(P_AUD_B); q.N = INTER; q.K = AUD_PAD; q.in_aux = 1; q.kin_off = VID;
+        q.row_group = 1;
+        q.end_layer = 1; q.nout = INTER; q.stash = reinterpret_cast<bf16_t*>(L.avin); q.ld_stash = INTER;
+        c.seg[k++] = q;
+      }
+    }
     {   // F2: value projection (rows [2E, 3E) of the packed in_proj), attention-weight dropout = one decision per (row, head)
       ChainSeg q;
       chain_seg_defaults(q);
@@ -737,7 +771,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     }
   }
   // F18: last layer (64 -> 4), NIG activations, uncertainties and -- with targets -- the loss statistics
-  TRY(launch_nig_fwd(L.e2, X.W(P_EV2_W), X.V(P_EV2_B), 64, L.evid, a->nig_out, a->targets, L.stats, B, f32, s));
+  TRY(launch_nig_fwd(L.e2, X.W(P_EV2_W), X.V(P_EV2_B), 64, L.evid, a->nig_out, a->targets, L.stats, B, f32, bump, s));
   return 0;
 }
 
@@ -1054,8 +1088,8 @@ int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
   TRY(launch_adamw_pack(t, L.wpack, f32, L.vpack, s));
   const void* const* cparams = const_cast<const void* const*>(a->params);
   if (a->pack_transposed) TRY(pack_transposed_weights(cparams, L, f32, s));
-  if (!f32) TRY(pack_frag_images(L, a->pack_transposed != 0, s));
   if (!f32) TRY(pad_audio_weight(cparams, L, s));
+  if (!f32) TRY(pack_frag_images(L, a->pack_transposed != 0, s));
   return 0;
 }
 
@@ -1076,8 +1110,8 @@ int mmdeer_pack_weights(const void* const* params, void* weights, size_t weights
   }
   TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
   TRY(pack_transposed_weights(params, L, f32, s));
-  if (!f32) TRY(pack_frag_images(L, true, s));
   if (!f32) TRY(pad_audio_weight(params, L, s));
+  if (!f32) TRY(pack_frag_images(L, true, s));
   return 0;
 }
 

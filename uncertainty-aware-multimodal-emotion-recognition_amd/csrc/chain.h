@@ -33,6 +33,10 @@ struct ChainSeg {
   int ld_stash, nout;      // end_layer: leading dimension of stash, width of the finished panel
   int relu, drop_site, drop_shift, end_layer;
   int mblocks;             // 16-row blocks of the input panel this segment multiplies (0: all of them)
+  int in_aux;              // 1: the segment multiplies the chain's SECOND input panel (ChainArgs::aux_video: [video | padded audio],
+                           //    384 columns, one row group) instead of the current one
+  int row_group;           // 1: the segment's rows land in row group 1 of the output panel (rows + samples per workgroup), which then
+                           //    has two row groups -- the audio rows of the AV attention's stacked [video; audio] input
   int fold_groups;         // 1: rows of group z land in rows of group 0, columns + z * N (torch.cat of the two AV calls);
                            // 2: the inverse (its backward): columns [z N/2, (z+1) N/2) of the one group become the rows of group z
   // backward chains (dX = dY W through the packed W^T copies):
@@ -80,6 +84,10 @@ struct ChainArgs {
   long long group_stride;  // rows between the groups
   int nseg;
   DropCtx drop;
+  // optional second input panel (B <= 4096 only): the raw video block [B][aux_ldv] and the raw 84-wide audio block [B][aux_lda]
+  // (bf16; zero-padded to 128 columns in LDS, the padded rows also stored to aux_audio_pad [B][128] for the weight-gradient launch)
+  const bf16_t* aux_video; const bf16_t* aux_audio; bf16_t* aux_audio_pad;
+  int aux_ldv, aux_lda;
   unsigned long long* stamps;   // diagnostic builds (-DMMDEER_STAMPS) only: cycle-counter samples of workgroup 0; else null
   ChainNig nig;            // enabled: X is unused, K0 = ldx = 192, groups = 1
   ChainSeg seg[CHAIN_MAX_SEGS];

@@ -128,7 +128,7 @@ __device__ __forceinline__ unsigned chain_drop_key(unsigned long long seed, unsi
 // each record was a ~1000-cycle round trip.  All fields are dwords (a sub-dword field would be a vector load).
 struct ChainSegK {           // one GEMM segment = ntiles column tiles of `nkt` weight stages each; 96 bytes
   const bf16_t* W;           // fragment-major image of the segment's [N][K] matrix
-  int ldw, nkt;              // stages per tile: K / 64
+  int in_aux, nkt;           // in_aux: the segment multiplies the second input panel; stages per tile: K / 64
   int ntiles, kindb;         // column tiles (<= 4); 1: 64-column tiles (four column blocks of 16)
   int end;                   // index into ChainKArgs::end when this segment finishes a layer, else -1
   int N;
@@ -163,6 +163,9 @@ struct ChainKArgs {
   int nseg, nvec;
   DropCtx drop;
   unsigned long long* stamps;
+  // second input panel (16-sample workgroups only; ChainArgs::aux_video): [video 256 | audio 84 -> 128] of the workgroup's samples
+  const bf16_t* aux_video; const bf16_t* aux_audio; bf16_t* aux_audio_pad;
+  int aux_ldv, aux_lda;
   ChainRecK rec[CHAIN_MAX_SEGS];
   ChainVecK vec[CHAIN_MAX_VECS];
   ChainNig nig;      // behind the tables: not copied to LDS, read as kernel arguments
@@ -451,10 +454,13 @@ __device__ __forceinline__ void chain_nig_head(const ChainNig& g, unsigned char*
 template <int D, int VECF, int TS>
 __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   constexpr int MS = 16 * TS, LOG_MS = TS == 1 ? 4 : 5, FLY = 2 * D;   // FLY: weight loads of one wave in flight
-  constexpr int PAN = MS * 1024;           // MS rows x 512 columns (or 2 MS x 256) of bf16
-  // LDS: the two panels, 32 KiB of scratch for the LayerNorm-backward fold, the vectors, the tables
-  constexpr int RED = 2 * PAN, VEC = RED + 32768, TAB = VEC + VECF * 4;
-  constexpr int SEG_BYTES = (int)sizeof(ChainRecK), END_OFF = (int)sizeof(ChainSegK);
+  // a panel: MS rows x 512 columns (or 2 MS x 256) of bf16; 16-sample workgroups: x 768, the width of the text block the input
+  // chain starts from
+  constexpr int PAN = TS == 1 ? MS * 1536 : MS * 1024;
+  constexpr int AUXB = TS == 1 ? MS * 768 : 0;      // second input panel: MS rows x (256 + 128) columns
+  // LDS: the two panels, the second input panel, 32 KiB of scratch for the LayerNorm-backward fold, the vectors, the tables
+  constexpr int AUX = 2 * PAN, RED = AUX + AUXB, VEC = RED + 32768, TAB = VEC + VECF * 4;
+  constexpr int SEG_BYTES = (int)sizeof(ChainRecK);
   constexpr int VEC0 = CHAIN_MAX_SEGS * SEG_BYTES;
   constexpr int TAB_BYTES = VEC0 + CHAIN_MAX_VECS * (int)sizeof(ChainVecK);
   static_assert(TAB_BYTES % 16 == 0 && TAB_BYTES / 16 <= 512, "one 16-byte chunk of the tables per thread");
@@ -503,6 +509,25 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
       dma16(a.X + gr * a.ldx + image * 64 + kchunk, lds + image * img + g8 * 1024);
     }
   }
+  // ---- second input panel (input chain): the video rows by DMA, the 84-wide audio rows (168-byte rows: no 16-byte alignment) by
+  //      dword loads, zero-padded to 128 columns, into images 4-5; the padded rows also go to the workspace (weight gradient)
+  const bool has_aux = AUXB != 0 && a.aux_video != nullptr;
+  if (has_aux) {
+    {
+      const int image = wave >> 1, g8 = wave & 1;       // 4 images x 2 groups of 8 rows: one DMA piece per wave
+      const int r = g8 * 8 + r8;
+      const long long gr = valid_of(r) ? grow_of(r) : 0;
+      dma16(a.aux_video + gr * a.aux_ldv + image * 64 + kchunk, lds + AUX + image * (MS * 128) + g8 * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + 512 * q, r = e >> 6, dw = e & 63;
+      unsigned v = 0u;
+      if (dw * 2 < a.aux_lda && valid_of(r)) v = *reinterpret_cast<const unsigned*>(a.aux_audio + grow_of(r) * a.aux_lda + 2 * dw);
+      const int chunk = dw >> 2;
+      *reinterpret_cast<unsigned*>(lds + AUX + (4 + (chunk >> 3)) * (MS * 128) + r * 128 + (((chunk & 7) ^ (r & 7)) * 16) + (dw & 3) * 4) = v;
+    }
+  }
   // ---- the tables into LDS: one parallel vector load
   {
     const unsigned char* src = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ChainKArgs, rec);
@@ -511,6 +536,11 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   stamp(1);
+  if (has_aux && tid < 256) {       // the padded audio rows of this workgroup -> [B][128] (what pad_cols wrote as a launch of its own)
+    const int r = tid >> 4, c = tid & 15;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(lds + AUX + (4 + (c >> 3)) * (MS * 128) + r * 128 + (((c & 7) ^ (r & 7)) * 16));
+    if (valid_of(r)) store_wt16(a.aux_audio_pad + grow_of(r) * 128 + c * 8, v);
+  }
   const unsigned char* const tab = lds + TAB;
   auto sc = [](unsigned v) -> int { return __builtin_amdgcn_readfirstlane((int)v); };
   auto sp = [](unsigned lo, unsigned hi) -> unsigned long long {
@@ -592,7 +622,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   unsigned char* pout = lds + PAN;
   const int swz0 = (lg ^ (li & 7)) * 16, swz1 = ((4 + lg) ^ (li & 7)) * 16;
 
-  struct SegCtl { int N, ntiles, vec_off, dcol_off, nout_off, site, shift, relu, fold, kin_off, rows_out, has_bias, ld_mask, mask_col0; float mask_scale; const bf16_t* mask_y; };
+  struct SegCtl { int in_aux, N, ntiles, vec_off, dcol_off, nout_off, site, shift, relu, fold, kin_off, rows_out, has_bias, ld_mask, mask_col0; float mask_scale; const bf16_t* mask_y; };
 
   // One segment.  The activation fragments of its 16 (or 32) rows stay in REGISTERS for all its column tiles.
   // MB row blocks; KB: 64-column tiles (four column blocks), else 128 columns; NKT real stages per tile.
@@ -602,10 +632,10 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     constexpr int NKT = decltype(nktc)::value;
     constexpr int NV = (NKT + D - 1) / D * D;     // stages incl. padding: the tile ends in the ring slot it started in
     const bool active = !KB || wave < 4;          // 64-column tiles: four column blocks
-    const int img_in = rows_in * 128, img_out = sg.rows_out * 128;
+    const int img_in = sg.in_aux ? MS * 128 : rows_in * 128, img_out = sg.rows_out * 128;
     u32x4 afr[NKT * 2][MB];
     {
-      const unsigned char* sa = pin + (sg.kin_off >> 6) * img_in + li * 128;
+      const unsigned char* sa = (sg.in_aux ? lds + AUX : pin) + (sg.kin_off >> 6) * img_in + li * 128;
 #pragma unroll
       for (int c = 0; c < NKT * 2; ++c)
 #pragma unroll
@@ -661,6 +691,10 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
       if constexpr (NV > 5) stage(std::integral_constant<int, 5>{});
       if constexpr (NV > 6) stage(std::integral_constant<int, 6>{});
       if constexpr (NV > 7) stage(std::integral_constant<int, 7>{});
+      if constexpr (NV > 8) stage(std::integral_constant<int, 8>{});
+      if constexpr (NV > 9) stage(std::integral_constant<int, 9>{});
+      if constexpr (NV > 10) stage(std::integral_constant<int, 10>{});
+      if constexpr (NV > 11) stage(std::integral_constant<int, 11>{});
       // ---- bias, ReLU, dropout, bf16 -> output panel
       if (active) {
         const int n0 = (KB ? nt * 64 : nt * 128) + 16 * wave + 4 * lg;
@@ -697,6 +731,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
           int col = colb, orow = r;
           if (fold == 1) { col += (r >> LOG_MS) * N; orow = r & (MS - 1); }
           else if (fold == 2) { const int half = N >> 1, z = col >= half; col -= z * half; orow = r + z * MS; }
+          else if (fold == 3) orow = r + MS;        // the segment's rows are row group 1 of the output panel
           unsigned char* cell = pout + (col >> 6) * img_out + orow * 128 + ((((col & 63) >> 3) ^ (orow & 7)) * 16) + (col & 4) * 2;
           *reinterpret_cast<u32x2*>(cell) = u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
         }
@@ -719,7 +754,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     const u32x4 e0 = R[6], e1 = R[7], e2 = R[8], e3 = R[9], e4 = R[10];
     const int nkt = sc(q0.w), kb = sc(q1.y), endi = sc(q1.z);
     SegCtl sg;
-    sg.ntiles = sc(q1.x); sg.N = sc(q1.w);
+    sg.ntiles = sc(q1.x); sg.N = sc(q1.w); sg.in_aux = sc(q0.z);
     sg.vec_off = sc(q2.x); sg.dcol_off = sc(q2.y); sg.nout_off = sc(q2.z); sg.site = sc(q2.w);
     sg.shift = sc(q3.x); sg.relu = sc(q3.y); sg.fold = sc(q3.z);
     const int mb = sc(q3.w);
@@ -764,7 +799,8 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     if (!kb) {
       if (mb == TS) {
         if (nkt == 8) CH_SEG(TS, false, 8); else if (nkt == 6) CH_SEG(TS, false, 6); else if (nkt == 4) CH_SEG(TS, false, 4);
-        else if (nkt == 2) CH_SEG(TS, false, 2); else CH_SEG(TS, false, 1);
+        else if (nkt == 2) CH_SEG(TS, false, 2); else if (nkt == 1) CH_SEG(TS, false, 1);
+        else { if constexpr (TS == 1) CH_SEG(TS, false, 12); }
       } else {
         if (nkt == 4) CH_SEG(2 * TS, false, 4); else if (nkt == 2) CH_SEG(2 * TS, false, 2); else CH_SEG(2 * TS, false, 1);
       }
@@ -941,46 +977,60 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   }
   MMDEER_CHECK(a.B > 0, "chain: empty batch");
   MMDEER_CHECK(a.groups == 1 || a.groups == 2, "chain: groups must be 1 or 2");
-  MMDEER_CHECK(a.K0 % 64 == 0 && a.K0 * a.groups <= 512, "chain: input width %d x %d groups does not fit the panel", a.K0, a.groups);
+  const int ts = chain_samples_per_workgroup(a.B) / 16;       // 16-sample blocks per workgroup
+  const int pan_cols = ts == 1 ? 768 : 512;                   // panel width of one row group (chain_body: PAN)
+  MMDEER_CHECK(a.K0 % 64 == 0 && a.K0 * a.groups <= pan_cols, "chain: input width %d x %d groups does not fit the panel", a.K0, a.groups);
+  if (a.aux_video) {
+    MMDEER_CHECK(ts == 1 && !a.nig.enabled && a.groups == 1, "chain: the second input panel needs 16-sample workgroups and a single-group input");
+    MMDEER_CHECK(a.aux_audio && a.aux_audio_pad && ((uintptr_t)a.aux_video % 16) == 0 && a.aux_ldv % 8 == 0 && ((uintptr_t)a.aux_audio % 4) == 0 &&
+                     a.aux_lda % 2 == 0 && a.aux_lda <= 128 && ((uintptr_t)a.aux_audio_pad % 16) == 0,
+                 "chain: second input panel: pointers / alignment");
+  }
   ChainKArgs k{};
+  k.aux_video = a.aux_video; k.aux_audio = a.aux_audio; k.aux_audio_pad = a.aux_audio_pad; k.aux_ldv = a.aux_ldv; k.aux_lda = a.aux_lda;
   k.X = a.X; k.ldx = a.ldx; k.K0 = a.K0; k.B = a.B; k.groups = a.groups; k.group_stride = a.group_stride; k.drop = a.drop;
   k.stamps = a.stamps;
   k.nig = a.nig;
   int vec = 0, nend = 0, nvec = 0;
-  const int ts = chain_samples_per_workgroup(a.B) / 16;       // 16-sample blocks per workgroup
   int blocks_in = a.groups * ts, width_in = a.K0, layer_first_seg = 0;
+  bool layer_has_group1 = false;
   auto add_vec = [&](const float* src, int n) { ChainVecK& v = k.vec[nvec++]; v.src = src; v.off = vec; v.n4 = n / 4; vec += n; return v.off; };
   for (int i = 0; i < a.nseg; ++i) {
     const ChainSeg& s = a.seg[i];
     MMDEER_CHECK(s.W && ((uintptr_t)s.W % 16) == 0, "chain: segment %d weights (fragment-major image) must be 16-byte aligned", i);
     MMDEER_CHECK(s.N > 0 && s.N % 64 == 0 && s.K > 0 && s.K % 64 == 0 && (s.N % 128 == 0 || s.K % 128 == 0),
                  "chain: segment %d has unsupported N = %d, K = %d", i, s.N, s.K);
-    MMDEER_CHECK(s.kin_off % 64 == 0 && s.kin_off + s.K <= width_in, "chain: segment %d reads columns [%d, %d) of a %d-wide panel", i,
-                 s.kin_off, s.kin_off + s.K, width_in);
+    MMDEER_CHECK(!s.in_aux || a.aux_video, "chain: segment %d reads a second input panel the chain does not have", i);
+    MMDEER_CHECK(s.kin_off % 64 == 0 && s.kin_off + s.K <= (s.in_aux ? 384 : width_in), "chain: segment %d reads columns [%d, %d) of a %d-wide panel", i,
+                 s.kin_off, s.kin_off + s.K, s.in_aux ? 384 : width_in);
+    MMDEER_CHECK(s.row_group == 0 || (s.row_group == 1 && s.fold_groups == 0 && blocks_in == ts), "chain: segment %d row group", i);
     MMDEER_CHECK(s.nout_off % 64 == 0, "chain: segment %d output offset", i);
     MMDEER_CHECK(!s.bias || ((uintptr_t)s.bias % 16) == 0, "chain: segment %d bias alignment", i);
-    const int mblocks = s.mblocks ? s.mblocks : blocks_in;
+    const int mblocks = s.in_aux ? ts : s.mblocks ? s.mblocks : blocks_in;
+    layer_has_group1 = layer_has_group1 || s.row_group == 1;
     MMDEER_CHECK(mblocks <= blocks_in && (mblocks == ts || mblocks == 2 * ts), "chain: segment %d m-blocks", i);
     MMDEER_CHECK(nvec + 3 <= CHAIN_MAX_VECS, "chain: too many bias / gamma / beta vectors");
     const int vec_off = s.bias ? add_vec(s.bias, s.N) : 0;
     const int kb = s.N % 128 != 0, ntl = kb ? s.N / 64 : s.N / 128, nkt = s.K / 64;
     MMDEER_CHECK(ntl <= 4, "chain: segment %d has too many column tiles", i);
-    MMDEER_CHECK(kb ? ((nkt == 2 || nkt == 4) && mblocks * nkt <= 4 * ts) : ((nkt == 1 || nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8) && mblocks * nkt <= 8 * ts),
+    MMDEER_CHECK(kb ? ((nkt == 2 || nkt == 4) && mblocks * nkt <= 4 * ts)
+                    : (((nkt == 1 || nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8) && mblocks * nkt <= 8 * ts) || (nkt == 12 && ts == 1 && mblocks == 1)),
                  "chain: segment %d: K = %d with %d row blocks is not instantiated", i, s.K, mblocks);
     ChainSegK& td = k.rec[i].seg;
-    td.W = s.W; td.ldw = s.K; td.nkt = nkt; td.ntiles = ntl; td.kindb = kb; td.end = -1;
+    td.W = s.W; td.in_aux = s.in_aux ? 1 : 0; td.nkt = nkt; td.ntiles = ntl; td.kindb = kb; td.end = -1;
     td.N = s.N; td.vec_off = vec_off; td.dcol_off = s.dcol_off; td.nout_off = s.nout_off;
-    td.site = s.drop_site; td.shift = s.drop_shift; td.relu = s.relu; td.fold = s.fold_groups;
+    td.site = s.drop_site; td.shift = s.drop_shift; td.relu = s.relu; td.fold = s.row_group == 1 ? 3 : s.fold_groups;
     td.mblocks = mblocks; td.kin_off = s.kin_off;
     td.has_bias = s.bias != nullptr;
     td.mask_y = s.mask_y; td.ld_mask = s.ld_mask; td.mask_col0 = s.mask_col0; td.mask_scale = s.mask_scale;
     MMDEER_CHECK(!s.mask_y || (((uintptr_t)s.mask_y % 8) == 0 && s.ld_mask % 4 == 0 && s.mask_col0 % 4 == 0), "chain: segment %d mask alignment", i);
     if (s.end_layer) {
-      const int blocks_out = s.fold_groups == 1 ? blocks_in / 2 : s.fold_groups == 2 ? blocks_in * 2 : blocks_in;
+      const int blocks_out = s.fold_groups == 1 ? blocks_in / 2 : (s.fold_groups == 2 || layer_has_group1) ? blocks_in * 2 : blocks_in;
+      layer_has_group1 = false;
       MMDEER_CHECK(s.fold_groups != 1 || blocks_in == 2 * ts, "chain: segment %d folds the groups of a single-group panel", i);
       MMDEER_CHECK(s.fold_groups != 2 || (blocks_in == ts && s.nout_off == 0 && s.N == 2 * s.nout && s.nout % 64 == 0),
                    "chain: segment %d unfolds: one row group, N = 2 x the panel width", i);
-      MMDEER_CHECK(s.nout % 64 == 0 && s.nout * blocks_out <= 512 * ts, "chain: layer ending at segment %d does not fit the panel", i);
+      MMDEER_CHECK(s.nout % 64 == 0 && s.nout * blocks_out <= pan_cols * ts, "chain: layer ending at segment %d does not fit the panel", i);
       MMDEER_CHECK(!s.stash || (((uintptr_t)s.stash % 16) == 0 && s.ld_stash % 8 == 0), "chain: segment %d stash alignment", i);
       ChainEndK& e = k.rec[i].end;
       e.stash = s.stash; e.ld_stash = s.ld_stash; e.nout = s.nout;

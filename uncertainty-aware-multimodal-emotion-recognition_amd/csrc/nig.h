@@ -22,8 +22,9 @@ inline int nig_nblocks(int B) { return B > 0 ? (B + NIG_ROWS - 1) / NIG_ROWS : 1
 // evid: [B,3,4] fp32 raw evidence (saved for backward)
 // nig_out: [7][B][3] fp32 = mu, nu, alpha, beta, aleatoric, epistemic, total uncertainty
 // targets: [B,3] fp32 or null; stats: [nblk][3][NIG_NSTAT] fp32 block partials (written iff targets)
+// bump: optional device-side dropout step counter; one thread adds 1 (this is the forward's last kernel)
 int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_stride, float* evid, float* nig_out,
-                   const float* targets, float* stats, int B, int act_f32, hipStream_t s);
+                   const float* targets, float* stats, int B, int act_f32, unsigned long long* bump, hipStream_t s);
 
 // Backward of the head's last layer.  Two modes:
 //   loss mode  (targets != null): gradients of MultiTaskDEERLoss are formed in-kernel from `stats`;

@@ -31,8 +31,12 @@ namespace {
 // ------------------------------------------------------------------ forward (+ loss statistics)
 template <bool F32>
 __global__ __launch_bounds__(256) void nig_fwd_kernel(const void* e2, const void* w3, const float* b3, int b3_stride,
-                                                      float* evid, float* nig_out, const float* targets, float* stats, int B) {
+                                                      float* evid, float* nig_out, const float* targets, float* stats, int B,
+                                                      unsigned long long* bump) {
   const int d = blockIdx.y, tid = threadIdx.x, q = tid & 3;
+  // the device-side dropout step counter: advanced here, by the last kernel of the forward (nothing in this kernel reads it; the
+  // forward's kernels added the pending 1 on the host side, the backward's read the new value)
+  if (bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *bump += 1;
   const int b = blockIdx.x * NIG_ROWS + (tid >> 2);
   const bool active = b < B;
   const int bc = active ? b : B - 1;   // inactive quads read a valid row, their results are discarded
@@ -360,11 +364,11 @@ __global__ __launch_bounds__(256) void calibration_kernel(const float* gamma, co
 }  // namespace
 
 int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_stride, float* evid, float* nig_out,
-                   const float* targets, float* stats, int B, int act_f32, hipStream_t s) {
+                   const float* targets, float* stats, int B, int act_f32, unsigned long long* bump, hipStream_t s) {
   if (B == 0) return 0;
   dim3 grid(nig_nblocks(B), 3);
-  if (act_f32) hipLaunchKernelGGL(nig_fwd_kernel<true>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B);
-  else hipLaunchKernelGGL(nig_fwd_kernel<false>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B);
+  if (act_f32) hipLaunchKernelGGL(nig_fwd_kernel<true>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B, bump);
+  else hipLaunchKernelGGL(nig_fwd_kernel<false>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B, bump);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

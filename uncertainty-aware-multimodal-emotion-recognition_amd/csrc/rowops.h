@@ -67,7 +67,6 @@ struct PadTable {
   void* dst[PAD_MAX_SEGMENTS];
   int src_f32[PAD_MAX_SEGMENTS], rows[PAD_MAX_SEGMENTS], cols[PAD_MAX_SEGMENTS], ld_dst[PAD_MAX_SEGMENTS];
   int bstart[PAD_MAX_SEGMENTS + 1];   // filled by the launcher (256 destination chunks of 8 elements per block)
-  unsigned long long* bump;           // optional: thread 0 of block 0 adds 1 (the device-side dropout step counter)
 };
 int launch_pad_cols(PadTable& t, hipStream_t s);
 

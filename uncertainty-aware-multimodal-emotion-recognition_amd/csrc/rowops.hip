@@ -282,7 +282,6 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceTable 
 
 __global__ __launch_bounds__(256) void pad_cols_kernel(const PadTable t) {
   const auto& T = karg<PadTable>();
-  if (T.bump && blockIdx.x == 0 && threadIdx.x == 0) *T.bump += 1;   // every later kernel of the step reads the new value
   const int sg = (T.nseg > 1 && (int)blockIdx.x >= T.bstart[1]) ? 1 : 0;
   const int cols = T.cols[sg], ld = T.ld_dst[sg], cpr = ld >> 3;
   const long long c = (long long)(blockIdx.x - T.bstart[sg]) * 256 + threadIdx.x;
