@@ -78,7 +78,7 @@ size_t mmdeer_weights_bytes(int compute_f32);
  *   chain (1)          0: every sample-local layer as its own launch; 1 (bf16, chain_min <= B <= 8192): the runs F2-F6 and F9-F17
  *                      of the forward and, with chain_bwd (1), the head / trimodal and the audio-visual dX runs of the backward as
  *                      one launch each
- *   chain_min (2049)   smallest batch that takes the chains (the backward chain from 2561)
+ *   chain_min (512)    smallest batch that takes the chains
  *   chain_max (8192)   largest batch that takes the chains (beyond one round of 32-sample workgroups they lose)
  *   chain_nig (1)      0: the head's last-layer backward + loss gradient as a launch of their own also when the backward chain runs
  *   dw_tile (2)        weight-gradient launch: 2 = 128x128 tiles, K-slices of B rows (no split-K slabs for the B-row problems),

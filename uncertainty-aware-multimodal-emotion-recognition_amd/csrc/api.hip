@@ -136,9 +136,9 @@ Layout make_layout(void* base, void* wbase, int B, int f32) {
   L.dav = act(Bz, INTER); L.dz_a2 = act(Bz, INTER); L.dcats = act(2 * Bz, INTER); L.davv = act(2 * Bz, INTER);
   L.davin = act(2 * Bz, INTER);
   // LayerNorm-backward partial slabs: one per workgroup of ln_bwd_kernel, or of the layer chain that ran instead (more above 8192)
-  const size_t np = (size_t)(ln_bwd_nparts(B) > chain_workgroups(B) ? ln_bwd_nparts(B) : chain_workgroups(B));
+  const size_t np = (size_t)(ln_bwd_nparts(B) > chain_workgroups_max(B) ? ln_bwd_nparts(B) : chain_workgroups_max(B));
   L.part_ln_o1 = f32buf(np * 2 * FUS); L.part_ln_t3 = f32buf(np * 2 * FUS); L.part_ln_a2 = f32buf(np * 2 * INTER);
-  const size_t nhead = nblk > (size_t)chain_workgroups(B) ? nblk : (size_t)chain_workgroups(B);   // nig_bwd_kernel's blocks, or the chain's workgroups
+  const size_t nhead = nblk > (size_t)chain_workgroups_max(B) ? nblk : (size_t)chain_workgroups_max(B);   // nig_bwd_kernel's blocks, or the chain's workgroups
   L.part_w3 = f32buf(nhead * 3 * 256); L.part_b3 = f32buf(nhead * 3 * 4);
   L.slab = f32buf((size_t)SPLITK_MAX * MMDEER_FLAT_ELEMS);
   L.bytes = off;
@@ -164,9 +164,9 @@ struct OptEntry { const char* name; int dflt, lo, hi; std::atomic<int> value; };
 OptEntry g_opts[OPT_COUNT] = {
     {"fused_attn", 1, 0, 1, {1}}, {"qkv_recompute", 1, 0, 1, {1}}, {"xcd", 1, 0, 1, {1}}, {"nt128", 1, 0, 1, {1}}, {"nt192", 1, 0, 1, {1}},
     {"glds", 1, 0, 1, {1}}, {"nt8", 1, 0, 1, {1}}, {"t128", 512, 1, 1 << 30, {512}}, {"tile", -1, -1, 4, {-1}}, {"ksteps", 0, 0, 4096, {0}},
-    {"ln_fused", 1, 0, 1, {1}}, {"chain", 1, 0, 1, {1}}, {"chain_bwd", 1, 0, 1, {1}}, {"chain_min", 2049, 1, 1 << 30, {2049}},
+    {"ln_fused", 1, 0, 1, {1}}, {"chain", 1, 0, 1, {1}}, {"chain_bwd", 1, 0, 1, {1}}, {"chain_min", 512, 1, 1 << 30, {512}},
     {"dw_tile", 2, 2, 4, {2}}, {"dw_kg", 2, 1, 2, {2}}, {"chain_max", 8192, 1, 1 << 30, {8192}}, {"chain_nig", 1, 0, 1, {1}},
-    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 4, {4}}, {"chain_in", 1, 0, 1, {1}},
+    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 4, {4}}, {"chain_ts", 0, 0, 32, {0}}, {"chain_in", 1, 0, 1, {1}},
 };
 }  // namespace
 
@@ -833,7 +833,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   int ev_done = phase == 2 ? 2 : 0;   // first bucket whose event has not been recorded yet
   // backward chains (chain.hip): the head / trimodal run always when enabled; the audio-visual run only in the single-call mode
   // (in the two-call mode its first product, the token-0 dX, belongs to the first call)
-  const int bmin = opt(OPT_CHAIN_MIN) >= 2049 ? 2561 : opt(OPT_CHAIN_MIN);   // the backward chains pay later than the forward's: B = 2048 +5 us, 3072 -1 us
+  const int bmin = opt(OPT_CHAIN_MIN);
   const bool dchain = !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_BWD) && B >= bmin && B <= opt(OPT_CHAIN_MAX) && phase == 0;
   auto flush = [&](int bucket, bool last) -> int {
     if (!last) return 0;

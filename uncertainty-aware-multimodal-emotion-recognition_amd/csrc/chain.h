@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "nig.h"
+#include "options.h"
 
 namespace mmdeer {
 
@@ -95,8 +96,12 @@ struct ChainArgs {
 
 // Grid of a chain over B samples: 16-sample workgroups up to B = 4096, 32-sample workgroups above (one LayerNorm-backward
 // partial slab per workgroup).
-inline int chain_samples_per_workgroup(int B) { return B > 4096 ? 32 : 16; }
+inline int chain_samples_per_workgroup(int B) {
+  const int forced = opt(OPT_CHAIN_TS);          // option chain_ts: 16 / 32 force a workgroup size (A/B measurements), 0 = by batch size
+  return forced == 16 || forced == 32 ? forced : (B > 4096 ? 32 : 16);
+}
 inline int chain_workgroups(int B) { const int m = chain_samples_per_workgroup(B); return (B + m - 1) / m; }
+inline int chain_workgroups_max(int B) { return (B + 15) / 16; }     // whatever the option says: what per-workgroup buffers are sized for
 
 // Fragment-major weight images: what the chain kernel streams.  For a matrix W [N][K] (bf16, N % 16 == 0, K % 64 == 0) the 2 KiB
 // that ONE wave multiplies in ONE stage -- 16 output columns x 64 k -- are contiguous and in the lane order of the MFMA A operand:

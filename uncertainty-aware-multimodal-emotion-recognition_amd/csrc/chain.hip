@@ -633,14 +633,27 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     constexpr int NV = (NKT + D - 1) / D * D;     // stages incl. padding: the tile ends in the ring slot it started in
     const bool active = !KB || wave < 4;          // 64-column tiles: four column blocks
     const int img_in = sg.in_aux ? MS * 128 : rows_in * 128, img_out = sg.rows_out * 128;
-    u32x4 afr[NKT * 2][MB];
-    {
-      const unsigned char* sa = (sg.in_aux ? lds + AUX : pin) + (sg.kin_off >> 6) * img_in + li * 128;
+    // 16-sample workgroups: the fragments of ALL k stay in registers for the whole segment (64-96 VGPRs).  32-sample workgroups have
+    // twice the rows and no registers for that (the kernel spilled 49 VGPRs, reloaded behind vmcnt(0) in the loop): they read the two
+    // fragments of a stage from the panel one stage ahead -- LDS has the bandwidth now that the weight ring is gone.
+    constexpr bool AFR_REG = TS == 1;
+    const unsigned char* const sa = (sg.in_aux ? lds + AUX : pin) + (sg.kin_off >> 6) * img_in + li * 128;
+    u32x4 afr[AFR_REG ? NKT * 2 : 1][MB];
+    if constexpr (AFR_REG) {
 #pragma unroll
       for (int c = 0; c < NKT * 2; ++c)
 #pragma unroll
         for (int i = 0; i < MB; ++i) afr[c][i] = *reinterpret_cast<const u32x4*>(sa + (c >> 1) * img_in + i * 2048 + ((c & 1) ? swz1 : swz0));
     }
+    u32x4 fr[2][2][MB];      // !AFR_REG: fragments of stage kt in fr[kt & 1]
+    auto frag_load = [&](auto ktc) __attribute__((always_inline)) {
+      constexpr int kt = decltype(ktc)::value;
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        fr[kt & 1][0][i] = *reinterpret_cast<const u32x4*>(sa + kt * img_in + i * 2048 + swz0);
+        fr[kt & 1][1][i] = *reinterpret_cast<const u32x4*>(sa + kt * img_in + i * 2048 + swz1);
+      }
+    };
     const int site = sg.site, shift = sg.shift, relu = sg.relu, fold = sg.fold, N = sg.N;
     const unsigned dkey = site >= 0 ? chain_drop_key(dseed, doff, site) : 0u;
     for (int nti = 0; nti < sg.ntiles; ++nti) {
@@ -672,17 +685,26 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
           if (active) wr_take<S, FLY - 2>(f0, f1);
           else ch_wait_vm<FLY - 2>();
           issue(std::integral_constant<int, S>{});
+          if constexpr (!AFR_REG && kt + 1 < NKT) { if (active) frag_load(std::integral_constant<int, kt + 1>{}); }
           if (active) {
+            if constexpr (AFR_REG) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(f0, afr[2 * kt][i], acc[i]);
+              for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(f0, afr[2 * kt][i], acc[i]);
 #pragma unroll
-            for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(f1, afr[2 * kt + 1][i], acc[i]);
+              for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(f1, afr[2 * kt + 1][i], acc[i]);
+            } else {
+#pragma unroll
+              for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(f0, fr[kt & 1][0][i], acc[i]);
+#pragma unroll
+              for (int i = 0; i < MB; ++i) acc[i] = mma_chunk<bf16_t>(f1, fr[kt & 1][1][i], acc[i]);
+            }
           }
         } else {      // padding stage: keeps the ring slot / wait count pattern, multiplies nothing
           ch_wait_vm<FLY - 2>();
           issue(std::integral_constant<int, S>{});
         }
       };
+      if constexpr (!AFR_REG) { if (active) frag_load(std::integral_constant<int, 0>{}); }
       stage(std::integral_constant<int, 0>{});
       if constexpr (NV > 1) stage(std::integral_constant<int, 1>{});
       if constexpr (NV > 2) stage(std::integral_constant<int, 2>{});

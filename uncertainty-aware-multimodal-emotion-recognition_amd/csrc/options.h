@@ -21,13 +21,14 @@ enum OptId {
   OPT_LN_FUSED,         // 1: every LayerNorm of the forward runs inside the GEMM that consumes it (gemm_ln.hip, bf16 mode)
   OPT_CHAIN,            // 1: the row-local layer chains of the forward run as single launches (chain.hip, bf16 mode)
   OPT_CHAIN_BWD,        // 1 (with chain = 1): the head / trimodal dX products and LayerNorm backwards of the backward pass as one chain launch
-  OPT_CHAIN_MIN,        // smallest batch that takes the chains (default 2049; the backward chain from 2561; tests lower it)
+  OPT_CHAIN_MIN,        // smallest batch that takes the chains (default 512: measured wins down to there; tests lower it)
   OPT_DW_TILE,          // GemmTile of the weight-gradient launch: 2 = 128x128 tiles without split-K (default), 3 = 256x256 + split-K slabs, 4 = 256x128
   OPT_DW_KG,            // 128x128 weight-gradient tiles: 2 = the workgroup's halves split each 64-row stage of K (default), 1 = 32-row stages
   OPT_CHAIN_MAX,        // largest batch that takes the chains
   OPT_CHAIN_NIG,        // 1 (with the backward chain, loss mode): the head's last-layer backward + loss gradient run in the chain's prologue
   OPT_SPLITK_MAX,       // largest number of split-K slices of a weight-gradient problem (slabs: 4 B per parameter per slice)
   OPT_CHAIN_DEPTH,      // weight stages a wave of the 16-sample layer-chain kernel keeps in flight: 4 (default) or 2
+  OPT_CHAIN_TS,         // 0: 16-sample chain workgroups up to B = 4096, 32-sample ones above; 16 / 32: that size at every batch
   OPT_CHAIN_IN,         // 1 (with chain = 1, bf16 feature blocks, B <= 4096): the three input projections and the audio padding run
                         // inside the audio-visual chain's launch instead of as pad + F1 launches
   OPT_COUNT
