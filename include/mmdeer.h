@@ -36,8 +36,10 @@ extern "C" {
  * geometry -- audio 84, video 256, text 768 -> intermediate 256 -> fusion 512 x 8 heads -> head 256 / 128 / 64 / 4 x 3
  * dimensions: the parameter table (MMDEER_NUM_PARAMS_ABI rows at fixed flat offsets), the workspace layout, the fused
  * projection + attention kernel (512-wide rows, head dimension 64, two tokens) and the NIG head kernels are sized by these
- * constants.  The reference's constructor takes other widths (fusion.py:47-50); the host mirror refuses them with
- * NotImplementedError (mmdeer/model.py) instead of running a slower generic plan.  The single operators below
+ * constants.  The reference's constructor takes other widths (fusion.py:47-50): for other audio / video / text widths (multiples
+ * of 4; fusion 512, intermediate 256, 8 heads) the host mirror runs the fusion as a sequence of the single operators below
+ * (mmdeer/generic_fusion.py: mmdeer_gemm, mmdeer_layernorm_*, mmdeer_trimodal_attn_*; pinned by tests/golden/fusion_geom.npz,
+ * captured from the reference at 40 / 128 / 300); other fusion / head widths raise NotImplementedError.  The single operators
  * (mmdeer_gemm, mmdeer_layernorm_*, mmdeer_nig_loss, ...) and the Stack B entry points take any sizes that meet their
  * alignment rules (stackb.CompleteDEERModel runs other widths and depths: tests/test_gpu_stackb.py). */
 #define MMDEER_AUDIO_DIM 84

@@ -21,6 +21,8 @@ What is captured (SURVEY 8c golden-vector plan):
     too-small set (`python tests/golden/make_golden.py metrics` regenerates only this one).
   * stackb_B9.npz         -- complete_project.CompleteDEERModel, eval-mode forward with
     closed-form parameters (`python tests/golden/make_golden.py stackb` regenerates only this one).
+  * fusion_geom.npz       -- fusion.HierarchicalMultimodalFusion at audio 40 / video 128 / text 300: eval outputs and train-mode
+    (dropout 0) gradients (`python tests/golden/make_golden.py fusion_geom`).
 """
 import os
 import sys
@@ -373,7 +375,53 @@ def capture_fusion_alt():
     return out
 
 
+FUSION_GEOM = dict(audio_dim=40, video_dim=128, text_dim=300)
+
+
+def capture_fusion_geom():
+    """HierarchicalMultimodalFusion on ANOTHER geometry than the default: audio 40 / video 128 / text 300
+    (fusion 512, intermediate 256, 8 heads), closed-form parameters, B = 9.  Eval-mode outputs; and with dropout = 0.0 in train mode
+    the gradients of sum(fused * c0 + audiovisual * c1 + trimodal * c2) with respect to every parameter (digests for the large
+    matrices) and every input."""
+    import json
+    out = {}
+    B = 9
+    xs = {k: synth.normal(810 + i, B * d).reshape(B, d).astype(np.float32) for i, (k, d) in enumerate(FUSION_GEOM.items())}
+    shapes = None
+    for mode in ("eval", "train"):
+        mod = ref_fusion.HierarchicalMultimodalFusion(fusion_dim=512, intermediate_dim=256, num_attention_heads=8,
+                                                      dropout=0.3 if mode == "eval" else 0.0, use_uncertainty_weighting=True, **FUSION_GEOM)
+        sd = fill_module(mod, "fgeom")
+        shapes = {k: list(v.shape) for k, v in sd.items()}
+        ins = {k: torch.from_numpy(v).requires_grad_(mode == "train") for k, v in xs.items()}
+        if mode == "eval":
+            mod.eval()
+            with torch.no_grad():
+                o = mod(ins["audio_dim"], ins["video_dim"], ins["text_dim"])
+            for k in ("fused_features", "audiovisual_features", "trimodal_features", "trimodal_attention_weights"):
+                out["eval." + k] = tnp(o[k])
+            out["eval.av_attention.audio_to_video"] = tnp(o["av_attention_weights"]["audio_to_video"])
+            out["eval.av_attention.video_to_audio"] = tnp(o["av_attention_weights"]["video_to_audio"])
+        else:
+            mod.train()
+            o = mod(ins["audio_dim"], ins["video_dim"], ins["text_dim"])
+            loss = 0.0
+            for j, k in enumerate(("fused_features", "audiovisual_features", "trimodal_features")):
+                c = torch.from_numpy(synth.normal(830 + j, o[k].numel()).reshape(o[k].shape).astype(np.float32))
+                loss = loss + (o[k] * c).sum()
+            loss.backward()
+            out["train.loss"] = np.float64(float(loss))
+            store_grads(out, "train", mod, {k: v for k, v in ins.items()})
+    with open(os.path.join(HERE, "fusion_geom_state_dict_names.json"), "w") as fh:
+        json.dump(shapes, fh, indent=0)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "fusion_geom":
+        np.savez_compressed(os.path.join(HERE, "fusion_geom.npz"), **capture_fusion_geom())
+        print("fusion_geom.npz", os.path.getsize(os.path.join(HERE, "fusion_geom.npz")), "bytes")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "side":
         np.savez_compressed(os.path.join(HERE, "side_kernels.npz"), **capture_side())
         print("side_kernels.npz", os.path.getsize(os.path.join(HERE, "side_kernels.npz")), "bytes")

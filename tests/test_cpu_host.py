@@ -232,8 +232,13 @@ def test_create_fusion_module_factory():
 
     from mmdeer.model import HierarchicalMultimodalFusion, create_fusion_module
 
-    with pytest.raises(NotImplementedError, match="libmmdeer_hip.so is specialised"):
-        create_fusion_module("hierarchical", {})                       # the reference's defaults are 256/256/256 inputs
+    gen = create_fusion_module("hierarchical", {})                     # the reference's defaults are 256/256/256 inputs: the operator path
+    assert isinstance(gen, HierarchicalMultimodalFusion) and gen.audio_visual_fusion.audio_projection.weight.shape == (256, 256)
+    assert gen.uncertainty_gate.modality_encoders[2][0].weight.shape == (128, 256)
+    with pytest.raises(NotImplementedError, match="fusion_dim = 512"):
+        create_fusion_module("hierarchical", {"fusion_dim": 256})      # the attention operators are built for 64-wide heads
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gen(torch.zeros(2, 256), torch.zeros(2, 256), torch.zeros(2, 256))
     m = create_fusion_module("Hierarchical", {"audio_dim": 84, "video_dim": 256, "text_dim": 768, "dropout": 0.1})
     assert isinstance(m, HierarchicalMultimodalFusion)
     assert "trimodal_fusion.modality_attention.in_proj_weight" in m.state_dict()

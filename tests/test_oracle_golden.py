@@ -355,6 +355,69 @@ def test_alternative_fusions(golden_dir, tag):
     check_fusion_alt_grads(g, tag, {k: v.grad for k, v in P.items()}, [x.grad for x in xs], rtol=2e-4, atol_frac=2e-5)
 
 
+# ---------------------------------------------------------------------------------------------- a3 on another geometry
+FUSION_GEOM = (("audio_dim", 40), ("video_dim", 128), ("text_dim", 300))
+
+
+def fusion_geom_case(golden_dir, dtype=torch.float32):
+    """(parameters under the oracle's 'fusion.' prefix, inputs, the three cotangents) of tests/golden/fusion_geom.npz: everything is
+    closed-form (synth.module_fill / synth.normal), only the expected values come from the file."""
+    import json
+    with open(os.path.join(golden_dir, "fusion_geom_state_dict_names.json")) as fh:
+        shapes = json.load(fh)
+    P = {k: torch.from_numpy(v).to(dtype) for k, v in synth.module_fill("fgeom", shapes).items()}
+    B = 9
+    xs = [torch.from_numpy(synth.normal(810 + i, B * d).reshape(B, d).astype(np.float32)).to(dtype) for i, (_k, d) in enumerate(FUSION_GEOM)]
+    cs = [torch.from_numpy(synth.normal(830 + j, B * w).reshape(B, w).astype(np.float32)).to(dtype) for j, w in enumerate((512, 256, 512))]
+    return P, xs, cs
+
+
+def check_fusion_geom_grads(g, grads, dxs, rtol, atol_frac):
+    seen = 0
+    for k in (g.files if hasattr(g, "files") else list(g)):
+        if not k.startswith("train."):
+            continue
+        kind, _, name = k[len("train."):].partition(".")
+        if kind == "grad":
+            ref = g[k]
+            scale = max(float(np.abs(ref).max()), 1e-12)
+            np.testing.assert_allclose(grads[name].detach().cpu().numpy(), ref, rtol=rtol, atol=atol_frac * scale + 1e-7, err_msg=k)
+        elif kind == "gradnorm":
+            v = grads[name].detach().double().cpu().reshape(-1)
+            assert float(v.norm()) == pytest.approx(float(g[k]), rel=rtol), k
+            ref = g[f"train.gradsample.{name}"]
+            idx = torch.linspace(0, v.numel() - 1, 1024).round().long()
+            np.testing.assert_allclose(v[idx].numpy(), ref, rtol=rtol, atol=atol_frac * float(np.abs(ref).max()) + 1e-7, err_msg=k)
+        elif kind == "gradnone":
+            assert grads.get(name) is None or float(grads[name].abs().sum()) == 0.0, k
+        else:
+            continue
+        seen += 1
+    assert seen >= 20
+    for (key, _d), dx in zip(FUSION_GEOM, dxs):
+        ref = g[f"train.dx.{key}"]
+        np.testing.assert_allclose(dx.detach().cpu().numpy(), ref, rtol=rtol, atol=atol_frac * float(np.abs(ref).max()), err_msg=key)
+
+
+def test_hierarchical_fusion_on_another_geometry(golden_dir):
+    """fusion.HierarchicalMultimodalFusion(audio_dim=40, video_dim=128, text_dim=300) (fusion.py:47-50 takes any widths): the oracle's
+    fusion_forward is shape-generic -- eval outputs and the gradients of the imported reference at that geometry."""
+    g = _load(golden_dir, "fusion_geom.npz")
+    P, xs, cs = fusion_geom_case(golden_dir)
+    Pf = {"fusion." + k: v.clone().requires_grad_(True) for k, v in P.items()}
+    with torch.no_grad():
+        o = O.fusion_forward(Pf, *xs, masks=None)
+    for k in ("fused_features", "audiovisual_features", "trimodal_features", "trimodal_attention_weights"):
+        np.testing.assert_allclose(o[k].numpy(), g["eval." + k], rtol=2e-5, atol=2e-5 * float(np.abs(g["eval." + k]).max()), err_msg=k)
+    np.testing.assert_allclose(o["av_attention_weights"]["audio_to_video"].numpy(), g["eval.av_attention.audio_to_video"])
+    xg = [x.clone().requires_grad_(True) for x in xs]
+    o = O.fusion_forward(Pf, *xg, masks=None)
+    loss = sum((o[k] * c).sum() for k, c in zip(("fused_features", "audiovisual_features", "trimodal_features"), cs))
+    assert float(loss) == pytest.approx(float(g["train.loss"]), rel=1e-5)
+    loss.backward()
+    check_fusion_geom_grads(g, {k[len("fusion."):]: v.grad for k, v in Pf.items()}, [x.grad for x in xg], rtol=3e-4, atol_frac=3e-5)
+
+
 # ---------------------------------------------------------------------------------------------- side rows: backward (a8, a14)
 def side_shapes(tag):
     """state_dict shapes of deer.CrossModalAttention(256, 8) ('cma') / encoders.EnhancedAudioEncoder() ('aenc')."""

@@ -655,9 +655,11 @@ class HierarchicalMultimodalFusion(nn.Module):
     same constructor arguments, ``forward(audio, video, text, uncertainties=None)`` and output dictionary
     (fusion.py:164-171), and ``state_dict()`` has exactly the reference class's keys, so its checkpoints load.
 
-    The arithmetic is the fused fusion + head pass of ``MultimodalDEER`` (the head is a few launches and its outputs are
-    dropped); ``fused_features`` is differentiable -- a caller's own head trains the fusion through it
-    (``mmdeer_backward``'s ``g_fused``).  ``audiovisual_features`` / ``trimodal_features`` are returned as values only."""
+    Default geometry (84 / 256 / 768 -> 256 -> 512, 8 heads): the arithmetic is the fused fusion + head pass of ``MultimodalDEER``
+    (the head is a few launches and its outputs are dropped); ``fused_features`` is differentiable -- a caller's own head trains the
+    fusion through it (``mmdeer_backward``'s ``g_fused``); ``audiovisual_features`` / ``trimodal_features`` are returned as values
+    only.  Other ``audio_dim`` / ``video_dim`` / ``text_dim``: the operator path of ``generic_fusion.GenericHierarchicalFusion``
+    (every output differentiable; pinned by tests/golden/fusion_geom.npz, captured from the reference at 40 / 128 / 300)."""
 
     KEYS = ("fused_features", "audiovisual_features", "trimodal_features", "av_attention_weights",
             "trimodal_attention_weights", "uncertainty_weights")
@@ -666,36 +668,55 @@ class HierarchicalMultimodalFusion(nn.Module):
                  num_attention_heads: int = 8, dropout: float = 0.3, use_uncertainty_weighting: bool = True,
                  compute_dtype: str = "fp32", seed: int = 0):
         super().__init__()
-        if intermediate_dim != DEFAULT_DIMS.inter:
-            raise NotImplementedError("libmmdeer_hip.so is specialised for intermediate_dim = 256")
+        self.use_uncertainty_weighting = use_uncertainty_weighting
+        default_geometry = (audio_dim, video_dim, text_dim, fusion_dim, intermediate_dim, num_attention_heads) == (
+            DEFAULT_DIMS.audio, DEFAULT_DIMS.video, DEFAULT_DIMS.text, DEFAULT_DIMS.fusion, DEFAULT_DIMS.inter, 8)
+        if not default_geometry:
+            # other input widths (fusion.py:47-50 takes any): the operator path -- one C-ABI call per layer, forward and backward
+            # (generic_fusion.py).  Same output dictionary, same state_dict keys for these dimensions.
+            from .generic_fusion import GenericHierarchicalFusion
+            gen = GenericHierarchicalFusion(audio_dim, video_dim, text_dim, fusion_dim, intermediate_dim, num_attention_heads, dropout,
+                                            use_uncertainty_weighting, compute_dtype, seed)
+            self.__dict__["_core"] = None
+            self.__dict__["_generic"] = gen
+            for name, child in gen.named_children():
+                self.add_module(name, child)
+            return
+        self.__dict__["_generic"] = None
         core = MultimodalDEER(ModelConfig(audio_dim=audio_dim, video_dim=video_dim, text_dim=text_dim, fusion_dim=fusion_dim,
                                           attention_heads=num_attention_heads, dropout=dropout, compute_dtype=compute_dtype,
                                           seed=seed))
         self.__dict__["_core"] = core             # not a registered child: the head's parameters stay out of state_dict()
         for name, child in core.fusion.named_children():
             self.add_module(name, child)          # the fusion's own parameter tree, shared with the core
-        self.use_uncertainty_weighting = use_uncertainty_weighting
 
     def _apply(self, fn, *args, **kwargs):
         super()._apply(fn, *args, **kwargs)
-        self._core.head._apply(fn, *args, **kwargs)   # .to(device) / .float() reach the hidden head as well
+        if self._core is not None:
+            self._core.head._apply(fn, *args, **kwargs)   # .to(device) / .float() reach the hidden head as well
         return self
 
     def train(self, mode: bool = True):
         super().train(mode)
-        self._core.train(mode)
+        if self._core is not None:
+            self._core.train(mode)
+        else:
+            self._generic.train(mode)
         return self
 
     def forward(self, audio_features, video_features, text_features, uncertainties=None) -> Dict[str, torch.Tensor]:
-        if uncertainties is not None:
+        if self.use_uncertainty_weighting and uncertainties is not None:
             # Same failure as the reference: with `uncertainties` given and use_uncertainty_weighting=True its forward calls
             # self.uncertainty_gate(audio, video, text, uncertainties) positionally (fusion.py:148-150) against
             # forward(self, *modality_features, uncertainties) (:384) and dies with exactly this TypeError.  Algebraically the
             # branch would scale the features by (1 + 0.1 / 3) (the mean of a softmax over three is 1/3, :173-185); it has no
-            # working caller anywhere in the reference, so it is not built and parity stays unpinned.
+            # working caller anywhere in the reference, so it is not built and parity stays unpinned.  With
+            # use_uncertainty_weighting=False the reference never enters the branch (:147) and `uncertainties` is ignored.
             raise TypeError("forward() missing 1 required keyword-only argument: 'uncertainties' "
                             "[UncertaintyAwareGating is unreachable in the reference (fusion.py:148-150 vs :384); "
                             "call with uncertainties=None]")
+        if self._generic is not None:
+            return self._generic(audio_features, video_features, text_features)
         out = self._core(audio_features, video_features, text_features)
         return {k: out[k] for k in self.KEYS}
 
