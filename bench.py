@@ -586,6 +586,38 @@ def main():
     torch.cuda.synchronize()
     step_ms = sorted(se[i].elapsed_time(se[i + 1]) for i in range(K))
 
+    # ---- every launch of the step, measured in THIS run: the library's launch trace (mmdeer_trace_begin / _end) records an event
+    #      behind every launch of eager steps on the launch stream; consecutive events = that launch (kernel + the gap to the next
+    #      enqueue: the GPU runs these launches back to back while the host stays ahead; a replayed graph has no gaps at all)
+    launch_us = None
+    try:
+        import ctypes as C
+        lib_t = _lib.load()
+        NE, NS = 32, 20
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(NE + 1)] for _ in range(NS)]
+        for row in evs:
+            for x in row:
+                x.record()
+        torch.cuda.synchronize()
+        labels, counts = None, []
+        for i in range(NS):
+            evs[i][0].record()
+            arr = (C.c_void_p * NE)(*[x.cuda_event for x in evs[i][1:]])
+            _lib.check(lib_t.mmdeer_trace_begin(arr, NE))
+            model.train_step(a, v, t, y, **sc)
+            n = lib_t.mmdeer_trace_end()
+            counts.append(n)
+            if labels is None:
+                labels = [lib_t.mmdeer_trace_label(k).decode() for k in range(n)]
+        torch.cuda.synchronize()
+        if labels and all(c == len(labels) for c in counts):
+            launch_us = {}
+            for k, name in enumerate(labels):
+                d = sorted(evs[i][k].elapsed_time(evs[i][k + 1]) * 1e3 for i in range(2, NS))      # the first steps warm the eager path up
+                launch_us[f"{k:02d} {name}"] = round(d[len(d) // 2], 2)
+    except Exception as e:               # noqa: BLE001  (diagnostics only)
+        print(f"[bench] launch trace failed ({type(e).__name__}: {e})", file=sys.stderr)
+
     # ---- the roofline kernel, measured in THIS run.  bf16 fused plan: N back-to-back launches of tri_fused_kernel<0> on the
     #      step's own operands (xtok / obar / probs of the workspace, the packed head-major weight image and the fp32 bias of
     #      the weights buffer) captured into one HIP graph; events around a replay / N.  Replayed launches run gap-free (the
@@ -678,6 +710,9 @@ def main():
                            {"plan": "as set", "options": {k: _lib.get_option(k) for k in ("chain", "chain_bwd", "chain_nig")},
                             "why": "--no-autotune / --eager / MMDEER_CHAIN* given"},
             "grad_exchange": comm_mode + (", exact-global loss statistics" if exact else ""),
+            # per-launch durations of eager steps of this run (median over 18 steps, HIP events behind every launch: kernel + the gap
+            # to the next one; the replayed graph the metric times has no gaps)
+            "launch_us": launch_us,
             "final_loss": round(loss, 6),
             "train_step_with_optimizer_ms": round(full_elapsed / K * 1e3, 4),     # fwd + bwd + clip + AdamW + weight pack
             "optimizer_ms": round((full_elapsed - own_elapsed) / K * 1e3, 4),

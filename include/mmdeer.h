@@ -94,6 +94,14 @@ int mmdeer_set_option(const char* name, int value);
 int mmdeer_get_option(const char* name, int* value);
 const char* mmdeer_option_name(int i);
 
+/* Launch trace: between mmdeer_trace_begin(events, n) and mmdeer_trace_end() the calling thread's mmdeer_forward / mmdeer_backward
+ * record the caller's events (hipEvent_t handles, in order) on the call's stream, one behind every launch or group of launches,
+ * and remember a label for each: durations between consecutive events are the launches of THAT run (bench.py reports them in its
+ * line).  mmdeer_trace_end returns the number of events recorded; mmdeer_trace_label(i) stays valid until the next trace_begin. */
+int mmdeer_trace_begin(void** events, int n_events);
+int mmdeer_trace_end(void);
+const char* mmdeer_trace_label(int i);
+
 /* Byte offset of a named buffer inside the workspace of (batch, compute_f32), -1 for an unknown name: lets a test read the
  * activations and activation-gradients a step left behind (tests/test_gpu_bf16_layers.py checks every kernel of the bench
  * configuration on its own stored inputs).  Names (csrc/api.hip Layout; act dtype unless noted): audio_pad [B,128] bf16,

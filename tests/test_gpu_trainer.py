@@ -73,6 +73,18 @@ def test_trainer_validation_frequency_patience_and_resume(tmp_path):
     assert torch.equal(tr3.optimizer._exp_avg.cpu(), tr2.optimizer._exp_avg.cpu()) and ck["epoch"] == 4
     for (n1, p1), (_, p2) in zip(tr3.model.named_parameters(), tr2.model.named_parameters()):
         assert torch.equal(p1, p2), n1
+    # a finished run's checkpoint resumed with the same num_epochs has nothing left -- said aloud, not silently skipped;
+    # loaded with resume=False (evaluation / fine-tuning from the weights) the next train() runs all its epochs
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        h3 = tr3.train(loaders(64, 32, 1, False), {})
+    assert any("nothing left to train" in str(x.message) for x in w) and len(h3["train_loss"]) == len(ck["training_history"]["train_loss"])
+    tr4 = DEERTrainer(mk(), TrainingConfig(num_epochs=2, checkpoint_dir=str(tmp_path / "c4"), **cfg), "cuda:0")
+    tr4.load_checkpoint(str(tmp_path / "c2" / "final_model.pt"), resume=False)
+    n0 = len(tr4.history["train_loss"])
+    h4 = tr4.train(loaders(64, 32, 1, False), {})
+    assert len(h4["train_loss"]) == n0 + 2
 
 
 def test_trainer_resume_with_dropout_continues_the_mask_stream(tmp_path):

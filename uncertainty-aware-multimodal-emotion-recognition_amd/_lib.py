@@ -227,6 +227,9 @@ SYMBOLS = [
     ("mmdeer_reduce_scatter", c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p]),
     ("mmdeer_allgather", c_int, [c_void_p, c_void_p, c_ll, c_int, c_void_p, c_void_p]),
     ("mmdeer_convert", c_int, [c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p]),
+    ("mmdeer_trace_begin", c_int, [C.POINTER(c_void_p), c_int]),
+    ("mmdeer_trace_end", c_int, []),
+    ("mmdeer_trace_label", c_char_p, [c_int]),
     ("mmdeer_set_option", c_int, [c_char_p, c_int]),
     ("mmdeer_get_option", c_int, [c_char_p, C.POINTER(c_int)]),
     ("mmdeer_option_name", c_char_p, [c_int]),

@@ -32,6 +32,21 @@ void set_error(const char* fmt, ...) {
 
 namespace {
 
+// ------------------------------------------------------------------ launch trace (mmdeer_trace_begin / _end, include/mmdeer.h)
+// While a trace is open on the calling thread, mmdeer_forward / mmdeer_backward record the caller's next event behind every launch
+// (or group of launches) and remember its label: the host turns consecutive events into per-launch durations of ITS run.
+constexpr int TRACE_MAX = 32;
+struct Trace { void** ev = nullptr; int max = 0, n = 0; const char* label[TRACE_MAX]; };
+thread_local Trace g_trace;
+int trace_mark(const char* label, hipStream_t s) {
+  Trace& t = g_trace;
+  if (!t.ev || t.n >= t.max || t.n >= TRACE_MAX) return 0;
+  if (hipEventRecord((hipEvent_t)t.ev[t.n], s) != hipSuccess) { set_error("trace: hipEventRecord failed"); return -1; }
+  t.label[t.n++] = label;
+  return 0;
+}
+#define MARK(label) do { if (trace_mark(label, s) != 0) return -1; } while (0)
+
 // ------------------------------------------------------------------ parameter table
 struct ParamInfo { const char* name; int rows, cols; long long off; int is_matrix; };
 #define X(idx, ident, rows, cols, off, ismat, name) {name, rows, cols, off, ismat},
@@ -386,48 +401,54 @@ int pack_transposed_weights(const void* const* params, const Layout& L, int f32,
   return launch_pack_transposed(tt, L.wtpack, f32, s);
 }
 
-// bf16 mode: fragment-major images (chain.h) of every matrix a layer chain streams, from the packed copies: W of the forward
-// chains (F2-F6, F9-F17) into L.wfpack, W^T of the backward chains (B2-B10, B13-B17) into L.wtfpack -- each image at the flat
-// offset of the (sub-)matrix it restates (the value rows of the AV in_proj at + 2 E E, head z of the stacked layers at + z N K)
-int pack_frag_images(const Layout& L, bool with_transposed, hipStream_t s) {
-  FragTable t{};
-  auto add = [&](const char* src_base, char* dst_base, long long src_off, int ld, int N, int K, long long dst_off) {
-    const int k = t.nmat++;
-    t.src[k] = reinterpret_cast<const bf16_t*>(src_base) + src_off;
-    t.dst[k] = reinterpret_cast<bf16_t*>(dst_base) + dst_off;
-    t.ld[k] = ld; t.N[k] = N; t.K[k] = K;
-  };
+// bf16 mode: EVERY derived image of the packed weights in ONE launch (chain.h: launch_repack), all from L.wpack -- the bf16 copies
+// the optimiser step or the parameter pack has just written:
+//   L.wtpack   W^T of the matrices whose dX the backward needs (the three first head layers stacked as one [256][384] image)
+//   L.wfpack   fragment-major images of the matrices the forward chains stream (F1 when it runs in the chain, F2-F6, F9-F17)
+//   L.wtfpack  the same of the W^T matrices the backward chains stream (B2-B10, B13-B17)
+//   L.wqkv_hm  head-major image of the trimodal in_proj (tri_fused.hip); L.wa_pad / L.wa_frag: the audio projection zero-padded to K = 128
+// each image at the flat offset of the (sub-)matrix it restates (the value rows of the AV in_proj at + 2 E E, head z of the stacked
+// layers at + z N K).
+int repack_images(const Layout& L, bool with_transposed, hipStream_t s) {
+  RepackTable t{};
   auto o = [&](int pid) { return kParams[pid].off; };
-  auto fwd = [&](int pid, int N, int K, long long sub = 0) { add(L.wpack, L.wfpack, o(pid) + sub, K, N, K, o(pid) + sub); };
-  fwd(P_AIN_W, INTER, INTER, (long long)2 * INTER * INTER);
-  fwd(P_AOUT_W, INTER, INTER); fwd(P_AVF_W, INTER, 2 * INTER); fwd(P_AVP_W, FUS, INTER);
-  fwd(P_TOUT_W, FUS, FUS); fwd(P_TFF_W, FUS, FUS); fwd(P_OP_W, FUS, FUS);
-  fwd(P_FP0_W, HID, FUS); fwd(P_FP1_W, HID, HID); fwd(P_EV0_W, 3 * EV1, HID);
-  for (int z = 0; z < 3; ++z) fwd(P_EV1_W, EV2, EV1, (long long)z * EV2 * EV1);
-  // the input chain (F1 inside the audio-visual chain, B <= 4096): text and video projections, and the zero-padded audio projection
-  fwd(P_TXT_W, FUS, TXT); fwd(P_VID_W, INTER, VID);
-  add(L.wa_pad, L.wa_frag, 0, AUD_PAD, INTER, AUD_PAD, 0);       // needs pad_audio_weight first
-  if (with_transposed) {   // W^T as stored by pack_transposed_weights: [cols of W][rows of W]
-    auto bwd = [&](int pid, int N, int K, long long sub = 0) { add(L.wtpack, L.wtfpack, o(pid) + sub, K, N, K, o(pid) + sub); };
-    for (int z = 0; z < 3; ++z) bwd(P_EV1_W, EV1, EV2, (long long)z * EV2 * EV1);
-    bwd(P_EV0_W, HID, 3 * EV1); bwd(P_FP1_W, HID, HID); bwd(P_FP0_W, FUS, HID);
-    bwd(P_OP_W, FUS, FUS); bwd(P_TFF_W, FUS, FUS); bwd(P_TOUT_W, FUS, FUS);
-    bwd(P_AVP_W, INTER, FUS); bwd(P_AVF_W, 2 * INTER, INTER); bwd(P_AOUT_W, INTER, INTER);
-    // value columns [2E, 3E) of the AV in_proj's W^T [256][768]
-    add(L.wtpack, L.wtfpack, o(P_AIN_W) + 2 * INTER, 3 * INTER, INTER, INTER, o(P_AIN_W) + (long long)2 * INTER * INTER);
+  const bf16_t* wp = reinterpret_cast<const bf16_t*>(L.wpack);
+  auto job = [&](long long src_off, int ld_src, int rows, int cols, int cols_valid, int transpose, int layout, char* dst_base, long long dst_off,
+                 int ld_dst = 0, int dst_col = 0) {
+    RepackJob& J = t.job[t.njobs++];
+    J.src = wp + src_off; J.ld_src = ld_src; J.rows = rows; J.cols = cols; J.cols_valid = cols_valid;
+    J.transpose = transpose; J.layout = layout;
+    J.dst = reinterpret_cast<bf16_t*>(dst_base) + dst_off; J.ld_dst = ld_dst; J.dst_col = dst_col;
+  };
+  auto frag = [&](int pid, int N, int K, long long sub = 0) { job(o(pid) + sub, K, N, K, K, 0, 1, L.wfpack, o(pid) + sub); };
+  frag(P_AIN_W, INTER, INTER, (long long)2 * INTER * INTER);
+  frag(P_AOUT_W, INTER, INTER); frag(P_AVF_W, INTER, 2 * INTER); frag(P_AVP_W, FUS, INTER);
+  frag(P_TOUT_W, FUS, FUS); frag(P_TFF_W, FUS, FUS); frag(P_OP_W, FUS, FUS);
+  frag(P_FP0_W, HID, FUS); frag(P_FP1_W, HID, HID); frag(P_EV0_W, 3 * EV1, HID);
+  for (int z = 0; z < 3; ++z) frag(P_EV1_W, EV2, EV1, (long long)z * EV2 * EV1);
+  frag(P_TXT_W, FUS, TXT); frag(P_VID_W, INTER, VID);                              // the input chain
+  job(o(P_AUD_W), AUD, INTER, AUD_PAD, AUD, 0, 0, L.wa_pad, 0, AUD_PAD, 0);        // [256][84] -> [256][128]
+  job(o(P_AUD_W), AUD, INTER, AUD_PAD, AUD, 0, 1, L.wa_frag, 0);
+  job(o(P_TIN_W), FUS, 3 * FUS, FUS, FUS, 0, 2, L.wqkv_hm, 0, FUS, 0);
+  if (with_transposed) {
+    // W^T copies (what pack_transposed_weights writes in fp32 mode): [cols of W][rows of W]
+    for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
+      if (!kParams[i].is_matrix || i == P_AUD_W || i == P_VID_W || i == P_TXT_W || i >= P_EV2_W) continue;
+      const int rows = kParams[i].rows, cols = kParams[i].cols;
+      if (i >= P_EV0_W && i < P_EV0_W + 3) job(o(i), cols, rows, cols, cols, 1, 0, L.wtpack, o(P_EV0_W), 3 * EV1, (i - P_EV0_W) * EV1);
+      else job(o(i), cols, rows, cols, cols, 1, 0, L.wtpack, o(i), rows, 0);
+    }
+    // fragment-major images of W^T (N' = cols of W, K' = rows of W)
+    auto fragt = [&](int pid, int rows, int cols, long long sub = 0) { job(o(pid) + sub, cols, rows, cols, cols, 1, 1, L.wtfpack, o(pid) + sub); };
+    for (int z = 0; z < 3; ++z) fragt(P_EV1_W, EV2, EV1, (long long)z * EV2 * EV1);
+    fragt(P_EV0_W, 3 * EV1, HID); fragt(P_FP1_W, HID, HID); fragt(P_FP0_W, HID, FUS);
+    fragt(P_OP_W, FUS, FUS); fragt(P_TFF_W, FUS, FUS); fragt(P_TOUT_W, FUS, FUS);
+    fragt(P_AVP_W, FUS, INTER); fragt(P_AVF_W, INTER, 2 * INTER); fragt(P_AOUT_W, INTER, INTER);
+    fragt(P_AIN_W, INTER, INTER, (long long)2 * INTER * INTER);                    // the value rows [2E, 3E) of the AV in_proj
   }
-  return launch_pack_frag(t, s);
+  return launch_repack(t, s);
 }
 
-// bf16 mode: the [256][128] zero-padded copy of audio_projection.weight
-int pad_audio_weight(const void* const* params, const Layout& L, hipStream_t s) {
-  PadTable pt{};
-  pt.src[0] = params[P_AUD_W]; pt.dst[0] = L.wa_pad; pt.src_f32[0] = 1; pt.rows[0] = INTER; pt.cols[0] = AUD; pt.ld_dst[0] = AUD_PAD;
-  pt.nseg = 1;
-  if (launch_pad_cols(pt, s) != 0) return -1;
-  // ... and the head-major image of the trimodal in_proj weight (tri_fused.hip)
-  return launch_pack_qkv_headmajor(reinterpret_cast<const float*>(params[P_TIN_W]), L.wqkv_hm, s);
-}
 
 }  // namespace
 }  // namespace mmdeer
@@ -464,6 +485,15 @@ int mmdeer_get_option(const char* name, int* value) {
   return 0;
 }
 const char* mmdeer_option_name(int i) { return opt_name(i); }
+
+int mmdeer_trace_begin(void** events, int n_events) {
+  MMDEER_CHECK(events != nullptr && n_events > 0, "trace_begin: no events");
+  g_trace = Trace{};
+  g_trace.ev = events; g_trace.max = n_events;
+  return 0;
+}
+int mmdeer_trace_end(void) { const int n = g_trace.n; g_trace.ev = nullptr; return n; }
+const char* mmdeer_trace_label(int i) { return (i >= 0 && i < g_trace.n && i < TRACE_MAX) ? g_trace.label[i] : ""; }
 
 long long mmdeer_workspace_offset(int batch, int compute_f32, const char* name) {
   if (!name || batch < 0) return -1;
@@ -520,11 +550,8 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     // W^T copies for the backward dX GEMMs.  Always, not only when THIS call trains: the caller skips the repack while
     // the parameters are unchanged, so an inference call followed by a training call on the same parameters would find
     // them missing (the backward pass then multiplied by whatever the buffer held)
-    TRY(pack_transposed_weights(a->params, L, f32, s));
-    if (!f32) {    // the padded bf16 copy of audio_projection.weight + the head-major in_proj image, then the fragment-major images
-      TRY(pad_audio_weight(a->params, L, s));
-      TRY(pack_frag_images(L, true, s));
-    }
+    if (f32) TRY(pack_transposed_weights(a->params, L, f32, s));
+    else TRY(repack_images(L, true, s));       // bf16: W^T, fragment-major, head-major and padded images in one launch
   }
   if (B == 0) return 0;
   MMDEER_CHECK(a->audio && a->video && a->text, "audio / video / text must be non-NULL");
@@ -555,6 +582,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     pt.src[0] = a->audio; pt.dst[0] = L.audio_pad; pt.src_f32[0] = in_f32; pt.rows[0] = B; pt.cols[0] = AUD; pt.ld_dst[0] = AUD_PAD;
     pt.nseg = 1;
     TRY(launch_pad_cols(pt, s));
+    MARK("pad_cols (audio 84 -> 128)");
   }
   // F1: the three input projections (fusion.py:236-237, 322) in one launch
   if (!in_chain) {
@@ -568,6 +596,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     }
     g.p[2] = X.fwd(a->text, in_f32, TXT, P_TXT_W, P_TXT_B, L.xtok + (size_t)FUS * es, 2 * FUS, B, 0, -1);     // token 1
     TRY(X.run(g));
+    MARK("F1 input projections (3 problems)");
   }
   // bf16 mode: each LayerNorm runs inside the GEMM that consumes it (gemm_ln.hip: the workgroup of a 64-row tile owns whole
   // rows of its A operand, K = the LayerNorm width) -- three launches fewer in the forward; option "ln_fused" = 0 restores
@@ -655,6 +684,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     }
     c.nseg = k;
     TRY(launch_chain(c, s));
+    MARK(in_chain ? "chain F1-F6 (input projections + audio-visual fusion)" : "chain F2-F6 (audio-visual fusion)");
   } else {
     // F2: value projection of the shared AV cross-attention on [video_proj; audio_proj] (fusion.py:244-255;
     //     L = S = 1 so q/k are dead), attention-weight dropout = one decision per (row, head)
@@ -683,6 +713,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
       TRY(X.run1(X.fwd(L.av, f32, INTER, P_AVP_W, P_AVP_B, L.xtok, 2 * FUS, B, 0, -1)));
     }
   }
+  if (!chains) MARK("F2-F6 separate launches");
   // F7: packed q|k|v in_proj of the 2-token self-attention (fusion.py:328)
   //     + F8: 2x2 softmax attention, token-pooled context.  bf16: ONE kernel, q|k|v stay in its accumulators
   if (a->prof_events[0]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[0], s));
@@ -690,11 +721,14 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     void* qkv_out = (a->training && !env_qkv_recompute()) ? L.qkv : nullptr;
     TRY(launch_tri_fused_fwd(L.xtok, L.wqkv_hm, X.V(P_TIN_B), L.obar, L.probs, qkv_out, B, X.drop_on ? 1 : 0, X.dc, s));
     if (a->prof_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[1], s));
+    MARK("tri_fused_kernel<0> (in_proj + attention)");
     TRY(launch_tri_attn_weights(L.probs, a->trimodal_attention, a->av_attention, B, X.drop_on ? 1 : 0, X.dc, s));
+    if (a->trimodal_attention || a->av_attention) MARK("attention weights");
   } else {
     TRY(X.run1(X.fwd(L.xtok, f32, FUS, P_TIN_W, P_TIN_B, L.qkv, 3 * FUS, 2 * B, 0, -1)));
     if (a->prof_events[1]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->prof_events[1], s));
     TRY(launch_tri_attn_fwd(L.qkv, L.obar, L.probs, a->trimodal_attention, a->av_attention, B, f32, X.drop_on ? 1 : 0, X.dc, s));
+    MARK("in_proj GEMM + attention (unfused)");
   }
   // F9-F17 are local to a sample (Linear / ReLU / Dropout / LayerNorm): in bf16 mode ONE launch walks the chain with the rows
   // resident in LDS (chain.hip) and writes the same workspace buffers; option "chain" = 0 restores the separate launches
@@ -736,6 +770,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
     c.stamps = reinterpret_cast<unsigned long long*>(L.slab);   // diagnostic library: cycle samples of workgroup 0 (tools/chain_stamps.py)
 #endif
     TRY(launch_chain(c, s));
+    MARK("chain F9-F17 (trimodal fusion tail + head)");
   } else {
     // F9: out_proj on the pooled context (mean over tokens commutes with the linear map; fusion.py:335)
     TRY(X.run1(X.fwd(L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, L.pool, FUS, B, 0, -1)));
@@ -770,8 +805,10 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
       }
     }
   }
+  if (!chains) MARK("F9-F17 separate launches");
   // F18: last layer (64 -> 4), NIG activations, uncertainties and -- with targets -- the loss statistics
   TRY(launch_nig_fwd(L.e2, X.W(P_EV2_W), X.V(P_EV2_B), 64, L.evid, a->nig_out, a->targets, L.stats, B, f32, bump, s));
+  MARK("nig_fwd (head's last layer + loss statistics)");
   return 0;
 }
 
@@ -839,9 +876,11 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     if (!last) return 0;
     if (dwg.nprob > 0) {
       if (X.run(dwg) != 0) return -1;
+      if (trace_mark("weight gradients (all problems, one launch)", s) != 0) return -1;
       for (int i = 0; i < dwg.nprob; ++i) Exec::add_slab_segments(rt, dwg.p[i], L.slab, G);
     }
     if (launch_reduce_partials(rt, s) != 0) return -1;
+    if (trace_mark("reduce_partials (fold)", s) != 0) return -1;
     for (int b = ev_done; b <= bucket; ++b)      // every bucket up to this one is final now
       if (a->bucket_events[b]) MMDEER_HIP(hipEventRecord((hipEvent_t)a->bucket_events[b], s));
     ev_done = bucket + 1;
@@ -859,6 +898,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   if (!nigfold)
     TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->targets ? a->global_stats : nullptr, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
                        L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
+  if (!nigfold) MARK("nig_bwd (head's last layer backward + loss gradient)");
   // B2-B10 are local to a sample like the forward's layers: in bf16 mode (chain_min <= B <= chain_max, no outside gradient on fused_features)
   // ONE launch of the layer-chain kernel walks the head's four dX products, both LayerNorm backwards and the three trimodal dX
   // products with the rows resident in LDS, and writes the same workspace buffers (the weight-gradient launch reads them)
@@ -907,6 +947,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     c.stamps = reinterpret_cast<unsigned long long*>(L.davin);   // diagnostic library: untouched until phase 2 (tools/chain_stamps.py bwd)
 #endif
     TRY(launch_chain(c, s));
+    MARK(nigfold ? "chain B1-B10 (head backward + loss gradient + head / trimodal dX)" : "chain B2-B10 (head / trimodal dX)");
   } else
   {
     // evidence_net layer 3 (128 -> 64), batched over heads: dX masked by e1
@@ -948,11 +989,16 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     TRY(X.run1(X.dx(L.dz_t3, FUS, P_TFF_W, L.dpool, FUS, B, nullptr, 0)));
     TRY(X.run1(X.dx(L.dpool, FUS, P_TOUT_W, L.dobar, FUS, B, nullptr, 0)));      // attention out_proj (pooled context)
   }
-  if (!f32 && env_fused_attn() && env_qkv_recompute())    // the forward kept q|k|v on chip: recompute the head tiles
+  if (!bchain) MARK("B2-B10 separate launches");
+  if (!f32 && env_fused_attn() && env_qkv_recompute()) {   // the forward kept q|k|v on chip: recompute the head tiles
     TRY(launch_tri_fused_bwd(L.xtok, L.wqkv_hm, X.V(P_TIN_B), L.dobar, L.probs, L.dqkv, B, X.drop_on ? 1 : 0, X.dc, s));
-  else
+    MARK("tri_fused_kernel<1> (attention backward, recompute)");
+  } else {
     TRY(launch_tri_attn_bwd(L.qkv, L.dobar, L.probs, L.dqkv, B, f32, X.drop_on ? 1 : 0, X.dc, s));
+    MARK("attention backward (unfused)");
+  }
   TRY(X.run1(X.dx(L.dqkv, 3 * FUS, P_TIN_W, L.dxtok, FUS, 2 * B, nullptr, 0)));  // in_proj
+  MARK("in_proj dX GEMM");
   // (with the AV chain below, this product is its first segment)
   if (!dchain) TRY(X.run1(X.dx(L.dxtok, 2 * FUS, P_AVP_W, L.dav, INTER, B, nullptr, 0)));     // token 0 -> audiovisual features
   {
@@ -1009,6 +1055,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     c.seg[k++] = dxs(X.WTF(P_AIN_W, (size_t)2 * INTER * INTER), INTER, INTER, INTER, L.davin, INTER, INTER);
     c.nseg = k;
     TRY(launch_chain(c, s));
+    MARK("chain B13-B17 (audio-visual dX)");
   } else {
     TRY(launch_ln_bwd(L.dav, L.y_a2, L.mean_a2, L.rstd_a2, X.V(P_AVF_G), L.dz_a2, L.part_ln_a2, B, INTER, f32, X.mask_scale, s));
     // fusion_layers dX, written "stacked" ([2B,256]: rows [0,B) = d audio_attended, rows [B,2B) = d video_attended)
@@ -1046,6 +1093,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
     else add_dw(X.dw(L.davin + (size_t)B * INTER * es, INTER, L.audio_pad, 0, AUD_PAD, P_AUD_W, P_AUD_B, G, B));    // padded copy of F0
     reduce_ln(rt, L.part_ln_a2, P_AVF_G, INTER, dchain);
   }
+  if (!dchain) MARK("B13-B17 separate launches");
   // ---- default: all weight gradients in one grouped split-K launch + one deterministic fold of every partial slab
   TRY(flush(2, true));
   return 0;
@@ -1087,9 +1135,8 @@ int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
   t.max_norm = a->max_grad_norm; t.grad_scale = a->grad_scale;
   TRY(launch_adamw_pack(t, L.wpack, f32, L.vpack, s));
   const void* const* cparams = const_cast<const void* const*>(a->params);
-  if (a->pack_transposed) TRY(pack_transposed_weights(cparams, L, f32, s));
-  if (!f32) TRY(pad_audio_weight(cparams, L, s));
-  if (!f32) TRY(pack_frag_images(L, a->pack_transposed != 0, s));
+  if (f32) { if (a->pack_transposed) TRY(pack_transposed_weights(cparams, L, f32, s)); }
+  else TRY(repack_images(L, a->pack_transposed != 0, s));
   return 0;
 }
 
@@ -1109,9 +1156,8 @@ int mmdeer_pack_weights(const void* const* params, void* weights, size_t weights
     t.is_vec[i] = kParams[i].is_matrix ? 0 : 1;
   }
   TRY(launch_pack_params(t, L.wpack, f32, L.vpack, s));
-  TRY(pack_transposed_weights(params, L, f32, s));
-  if (!f32) TRY(pad_audio_weight(params, L, s));
-  if (!f32) TRY(pack_frag_images(L, true, s));
+  if (f32) TRY(pack_transposed_weights(params, L, f32, s));
+  else TRY(repack_images(L, true, s));
   return 0;
 }
 

@@ -108,15 +108,23 @@ inline int chain_workgroups_max(int B) { return (B + 15) / 16; }     // whatever
 // 16-byte granule index = ((wt * (K / 64) + kt) * 2 + c) * 64 + lane holds W[16 wt + (lane & 15)][64 kt + 32 c + 8 (lane >> 4) ... + 8),
 // so each of a wave's two global_load_dwordx4 per stage reads one contiguous KiB (eight whole cache lines) straight into registers.
 // (Measured, tools/probes/wstream.hip: 54 B/clk per CU with every CU streaming the same 2 MB, against 39-44 through an LDS-DMA ring.)
-constexpr int FRAG_MAX = 32;
-struct FragTable {
-  int nmat;
-  const bf16_t* src[FRAG_MAX];   // [N][ld] row-major
-  bf16_t* dst[FRAG_MAX];         // N * K elements
-  int ld[FRAG_MAX], N[FRAG_MAX], K[FRAG_MAX];
-  int gstart[FRAG_MAX + 1];      // filled by the launcher: first granule of each matrix
+// launch_repack: EVERY derived bf16 image of the packed weights in one launch, from the row-major bf16 copies the optimiser (or
+// the parameter pack) has just written: the W^T copies the dX GEMMs read, the fragment-major images of W and W^T the chains stream,
+// the head-major in_proj image of tri_fused.hip, the zero-padded audio projection.  (Round 3 and the first half of round 4 used a
+// launch each: pack_transposed, pack_frag, pad_cols, pack_qkv_headmajor -- 25 us of mostly launch floor per optimiser step.)
+struct RepackJob {
+  const bf16_t* src;     // S [rows][ld_src], element (r, c) = c < cols_valid ? src[r * ld_src + c] : 0
+  bf16_t* dst;
+  int ld_src, rows, cols, cols_valid;
+  int transpose;         // 1: the image is of S^T ([cols][rows])
+  int layout;            // 0: row-major dst[r * ld_dst + dst_col + c]; 1: fragment-major (above); 2: row-major in the head-major row order
+  int ld_dst, dst_col;
+  int gstart;            // filled by the launcher: first granule of the job
+  int pad_;
 };
-int launch_pack_frag(FragTable& t, hipStream_t s);
+constexpr int REPACK_MAX = 64;
+struct RepackTable { int njobs; int pad_; RepackJob job[REPACK_MAX]; };
+int launch_repack(RepackTable& t, hipStream_t s);
 
 void chain_seg_defaults(ChainSeg& s);
 // Validates shapes / alignment, derives the kernel's tables and enqueues the chain on `stream`.

@@ -945,37 +945,70 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(120))) void cha
 }  // namespace
 
 namespace {
-struct FragKArgs { FragTable t; };
-// one thread per 16-byte granule of a fragment-major image (chain.h): granule g of matrix m = lane (g & 63) of chunk ((g >> 6) & 1)
-// of stage kt of 16-column block wt, with (g >> 7) = wt * (K / 64) + kt
-__global__ __launch_bounds__(256) void pack_frag_kernel(const FragKArgs a) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  int m = 0;
-  while (m + 1 < a.t.nmat && g >= a.t.gstart[m + 1]) ++m;
-  const int l = g - a.t.gstart[m];
-  if (l >= a.t.gstart[m + 1] - a.t.gstart[m]) return;
-  const int nkt = a.t.K[m] >> 6;
-  const int lane = l & 63, c = (l >> 6) & 1, rest = l >> 7;
-  const int kt = rest % nkt, wt = rest / nkt;
-  const int n = wt * 16 + (lane & 15), k = kt * 64 + c * 32 + (lane >> 4) * 8;
-  *reinterpret_cast<u32x4*>(a.t.dst[m] + (size_t)l * 8) = *reinterpret_cast<const u32x4*>(a.t.src[m] + (size_t)n * a.t.ld[m] + k);
+// One thread per 16-byte granule (8 bf16) of an output image.  A job's logical matrix M is S (`rows` x `cols`, element (r, c) at
+// src[r * ld_src + c], zero for c >= cols_valid) or its transpose; the granule is 8 consecutive columns of one row of M, written
+// row-major (optionally with the head-major row order of tri_fused.hip) or fragment-major (chain.h).
+__global__ __launch_bounds__(256) void repack_kernel(const RepackTable t) {
+  // jobs start at block boundaries: the job of a block is uniform (a scalar search, not one per thread)
+  int j = 0;
+  while (j + 1 < t.njobs && (int)blockIdx.x * 256 >= t.job[j + 1].gstart) ++j;
+  const RepackJob& J = t.job[j];
+  const int l = blockIdx.x * 256 + threadIdx.x - J.gstart;
+  const int R = J.transpose ? J.cols : J.rows, Cn = J.transpose ? J.rows : J.cols;
+  if (l >= R * (Cn >> 3)) return;
+  int r, c0;
+  bf16_t* dst;
+  if (J.layout == 1) {
+    const int nkt = Cn >> 6, lane = l & 63, c = (l >> 6) & 1, rest = l >> 7;
+    const int kt = rest % nkt, wt = rest / nkt;
+    r = wt * 16 + (lane & 15); c0 = kt * 64 + c * 32 + (lane >> 4) * 8;
+    dst = J.dst + (size_t)l * 8;
+  } else {
+    // row-major: consecutive threads take consecutive granules of a row -- or, for a transposed image, consecutive ROWS of one
+    // granule column, so that the eight strided 2-byte reads of a wave are runs of 128 contiguous source bytes
+    const int per = Cn >> 3;
+    int dr;
+    if (J.transpose) { dr = l % R; c0 = (l / R) * 8; }
+    else { dr = l / per; c0 = (l - dr * per) * 8; }
+    r = dr;
+    if (J.layout == 2) {       // destination row dr = 192 h + 96 wn + 32 part + dd  <-  source row 512 part + 64 h + 32 wn + dd
+      const int h = dr / 192, rem = dr - h * 192, wn = rem / 96, rem2 = rem - wn * 96, part = rem2 >> 5, dd = rem2 & 31;
+      r = part * 512 + h * 64 + wn * 32 + dd;
+    }
+    dst = J.dst + (size_t)dr * J.ld_dst + J.dst_col + c0;
+  }
+  u32x4 v;
+  if (!J.transpose && J.cols_valid == J.cols && (J.ld_src & 7) == 0) {
+    v = *reinterpret_cast<const u32x4*>(J.src + (size_t)r * J.ld_src + c0);
+  } else {
+    unsigned short e[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int rr = J.transpose ? c0 + q : r, cc = J.transpose ? r : c0 + q;
+      e[q] = cc < J.cols_valid ? J.src[(size_t)rr * J.ld_src + cc] : (unsigned short)0;
+    }
+    v = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
+              (unsigned)e[6] | ((unsigned)e[7] << 16)};
+  }
+  *reinterpret_cast<u32x4*>(dst) = v;
 }
 }  // namespace
 
-int launch_pack_frag(FragTable& t, hipStream_t s) {
-  MMDEER_CHECK(t.nmat >= 0 && t.nmat <= FRAG_MAX, "pack_frag: too many matrices");
-  if (t.nmat == 0) return 0;
+int launch_repack(RepackTable& t, hipStream_t s) {
+  MMDEER_CHECK(t.njobs >= 0 && t.njobs <= REPACK_MAX, "repack: too many jobs (%d)", t.njobs);
+  if (t.njobs == 0) return 0;
   int g = 0;
-  for (int m = 0; m < t.nmat; ++m) {
-    MMDEER_CHECK(t.src[m] && t.dst[m] && ((uintptr_t)t.src[m] % 16) == 0 && ((uintptr_t)t.dst[m] % 16) == 0 && t.ld[m] % 8 == 0,
-                 "pack_frag: matrix %d pointers / leading dimension must be 16-byte aligned", m);
-    MMDEER_CHECK(t.N[m] > 0 && t.N[m] % 16 == 0 && t.K[m] > 0 && t.K[m] % 64 == 0, "pack_frag: matrix %d is %d x %d (N % 16, K % 64)", m, t.N[m], t.K[m]);
-    t.gstart[m] = g;
-    g += t.N[m] * t.K[m] / 8;
+  for (int m = 0; m < t.njobs; ++m) {
+    RepackJob& J = t.job[m];
+    const int R = J.transpose ? J.cols : J.rows, Cn = J.transpose ? J.rows : J.cols;
+    MMDEER_CHECK(J.src && J.dst && ((uintptr_t)J.dst % 16) == 0 && J.rows > 0 && J.cols > 0 && J.cols_valid <= J.cols, "repack: job %d pointers / sizes", m);
+    MMDEER_CHECK(Cn % 8 == 0 && (J.layout != 1 || (R % 16 == 0 && Cn % 64 == 0)), "repack: job %d is %d x %d", m, R, Cn);
+    MMDEER_CHECK(J.layout == 1 || (J.ld_dst % 8 == 0 && J.dst_col % 8 == 0), "repack: job %d destination alignment", m);
+    MMDEER_CHECK(J.layout != 2 || (!J.transpose && J.rows == 1536 && J.cols == 512), "repack: the head-major order is that of the [1536][512] in_proj");
+    J.gstart = g;
+    g += (R * (Cn >> 3) + 255) / 256 * 256;        // every job starts a block
   }
-  t.gstart[t.nmat] = g;
-  FragKArgs ka{t};
-  hipLaunchKernelGGL(pack_frag_kernel, dim3((g + 255) / 256), dim3(256), 0, s, ka);
+  hipLaunchKernelGGL(repack_kernel, dim3((g + 255) / 256), dim3(256), 0, s, t);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

@@ -112,7 +112,12 @@ class FlatAdamW(torch.optim.Optimizer):
     updates the fp32 parameters, the moments and the compute-dtype copies the GEMMs read.  A ``torch.optim.Optimizer``, so the
     reference's LR schedulers drive it unchanged; default parameter groups follow the reference trainer: parameters with
     'encoder' in their name at ``encoder_lr_scale`` x lr (training.py:125-140).  Parameters the backward never reaches (the
-    calibration layer: ``grad is None`` under autograd, which torch's AdamW skips) are left untouched."""
+    calibration layer: ``grad is None`` under autograd, which torch's AdamW skips) are left untouched.
+
+    The clipping norm is taken over the WHOLE flat gradient buffer (one pass over contiguous memory): with ``params=`` naming a
+    subset (frozen encoders) it includes the excluded parameters' gradients, where ``clip_grad_norm_`` over the optimiser's own
+    parameters would not -- zero the frozen ranges of the gradient buffer if that matters.  betas / eps / weight_decay must be the
+    same in every group; ``step()`` re-checks it (a scheduler or a caller editing ``param_groups`` later is not ignored silently)."""
 
     def __init__(self, model, params: Optional[Iterable] = None, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, max_grad_norm: float = 0.0, encoder_lr_scale: float = 0.5, skip=("calibration_layer.",)):
@@ -163,6 +168,8 @@ class FlatAdamW(torch.optim.Optimizer):
             self._v = torch.zeros_like(self._m)
             self._scratch = torch.empty(256, dtype=torch.float32, device=dev)
         segs = self._segments(st)
+        if len({(tuple(g["betas"]), g["eps"], g["weight_decay"]) for g in self.param_groups}) != 1:
+            raise NotImplementedError("FlatAdamW: betas / eps / weight_decay must be the same in every group (lr may differ)")
         self._t += 1
         g0 = self.param_groups[0]
         a = _lib.AdamWFlatArgs()

@@ -219,6 +219,10 @@ class DEERTrainer:
         first = 0
         if self._resumed:          # continue a checkpointed run: next epoch, best model / patience as they were
             first, self._resumed = self.current_epoch + 1, False
+            if first >= c.num_epochs:
+                import warnings
+                warnings.warn(f"DEERTrainer.train: the loaded checkpoint finished epoch {first - 1} and num_epochs is {c.num_epochs}: "
+                              "nothing left to train (load_checkpoint(path, resume=False) starts a new run from the loaded weights)")
         else:
             self.best_ccc, self.best_val_loss, self.patience_counter = -float("inf"), float("inf"), 0
         vf, sf = max(1, int(c.val_frequency)), max(1, int(c.save_frequency))
@@ -277,8 +281,11 @@ class DEERTrainer:
                                       "best_val_loss": getattr(self, "best_val_loss", float("inf")),
                                       "patience_counter": getattr(self, "patience_counter", 0)}}, path)
 
-    def load_checkpoint(self, path: str) -> Dict:
-        """Resume from ``save_checkpoint``: parameters, optimiser moments / step, scheduler, history."""
+    def load_checkpoint(self, path: str, resume: bool = True) -> Dict:
+        """Load a ``save_checkpoint`` file: parameters, optimiser moments / step, scheduler, history.  ``resume=True`` (default)
+        makes the next ``train()`` CONTINUE the checkpointed run -- epoch + 1, best model and patience as they were; with
+        ``resume=False`` (a best-model file loaded for evaluation or fine-tuning) the next ``train()`` runs its ``num_epochs`` from
+        epoch 0 like the reference trainer after a load."""
         ck = torch.load(path, map_location=self.device, weights_only=False)
         self.model.load_state_dict(ck["model_state_dict"])
         if ck.get("optimizer_state_dict") is not None:
@@ -294,7 +301,7 @@ class DEERTrainer:
         self.patience_counter = ts.get("patience_counter", 0)
         if ck.get("epoch") is not None:
             self.current_epoch = int(ck["epoch"])
-            self._resumed = True             # train() continues with epoch + 1
+            self._resumed = bool(resume)     # train() continues with epoch + 1
         return ck
 
 
