@@ -86,6 +86,9 @@ size_t mmdeer_weights_bytes(int compute_f32);
  *   dw_tile (2)        weight-gradient launch: 2 = 128x128 tiles, K-slices of B rows (no split-K slabs for the B-row problems),
  *                      3 = 256x256 tiles + split-K slabs, 4 = 256x128 tiles; dw_kg (2): 1 = the 128x128 kernel on 32-row K stages
  *   chain_depth (4)    weight stages a wave of the 16-sample chain kernel keeps in flight (2 or 4)
+ *   chain_in (1)       0: the input projections as a pad launch + one 3-problem GEMM launch also where the first chain could run them
+ *   chain_nigf (0)     1: the NIG head as the tail of the forward head chain (bit-identical, one launch fewer, measured slower)
+ *   chain_ts (0)       16 / 32: force the samples per chain workgroup (0: 16 up to B = 4096, 32 above)
  *   xcd, nt128, nt192, glds, nt8 (1), t128 (512), tile (-1), ksteps (0), splitk_max (8)   GEMM tile / split-K selection
  * mmdeer_set_option / mmdeer_get_option return -1 for an unknown name, mmdeer_set_option also for a value outside the option's
  * range (every option has one: booleans 0..1, dw_tile 2..4, dw_kg 1..2, tile -1..4, splitk_max 1..8, chain_depth 2..4, ...; the
@@ -135,8 +138,9 @@ typedef struct mmdeer_forward_args {
   uint64_t seed, offset;
   const uint64_t* offset_dev; /* optional device counter added to `offset` when the kernels run: lets a captured HIP
                                * graph draw fresh dropout masks on every replay (NULL: offset alone) */
-  int32_t bump_offset_dev;  /* 1 (bf16 compute only): the first kernel of this call increments *offset_dev before
-                             * anything reads it, so a replayed graph needs no separate counter kernel */
+  int32_t bump_offset_dev;  /* 1 (bf16 compute only; a training step = this call + mmdeer_backward with the same flag): every kernel
+                             * of the step uses *offset_dev + 1 and the LAST launch of mmdeer_backward stores the incremented
+                             * counter, so a replayed graph draws fresh masks without a counter kernel of its own */
   const void* audio;        /* [B, 84]  */
   const void* video;        /* [B, 256] */
   const void* text;         /* [B, 768] */
@@ -201,6 +205,7 @@ typedef struct mmdeer_backward_args {
    * audio-visual remainder (bucket 2).  Lets a data-parallel caller start the all-reduce of buckets 0-1 (89 % of
    * the gradient) while part 2 runs.  Both calls take the same arguments; 1 must precede 2. */
   int32_t phase;
+  int32_t bump_offset_dev;  /* as given to the matching mmdeer_forward (phase 1 and 2 both; the counter advances at the end of 2) */
   /* Exact-global loss for data parallelism (optional): MMDEER_GLOBAL_STATS floats = the loss statistics of
    * ALL ranks' batches (every rank calls mmdeer_loss_stats after its forward and the host sums the vectors across
    * ranks, e.g. mmdeer_allreduce with average = 0).  The ECE and cross-dimension terms are non-linear in these batch

@@ -441,6 +441,22 @@ def test_head_backward_in_the_chain_prologue_matches_its_own_launch(B):
     assert float(d) < 1e-5, float(d)
 
 
+@pytest.mark.parametrize("B", [300, 1000, 4096, 5000, 8192])
+def test_nig_head_in_the_forward_chain_tail_matches_its_own_launch(B):
+    """Option chain_nigf: the forward head chain ends in the NIG head -- last layer, activations, uncertainties and the loss statistics as
+    WAVE partials (16 samples each) that the consumers combine four to a block in nig_fwd_kernel's own order.  Loss record, outputs, ECE
+    bin counts and the whole flat gradient must come out bit for bit as with the separate nig_fwd launch (ragged batches: the last
+    block's absent waves count as the zeros an inactive wave contributes; 32-sample workgroups: two row blocks per workgroup)."""
+    on, off = _chain_step(B, chain_nigf=1), _chain_step(B, chain_nigf=0)
+    assert on[0] == off[0]
+    for k in on[2]:
+        assert torch.equal(on[2][k], off[2][k]), k
+    assert torch.equal(on[1], off[1])
+    # ... also with the head's backward as a launch of its own (nig_bwd_kernel reads the wave partials) and in exact-global mode
+    on2, off2 = _chain_step(B, chain_nigf=1, chain_nig=0), _chain_step(B, chain_nigf=0, chain_nig=0)
+    assert on2[0] == off2[0] and torch.equal(on2[1], off2[1])
+
+
 @pytest.mark.parametrize("opts", [dict(dw_tile=3), dict(dw_tile=4), dict(dw_kg=1), dict(ln_fused=0, chain=0), dict(chain=0, dw_tile=3),
                                   dict(splitk_max=2), dict(ksteps=8), dict(chain_nig=0)])
 def test_weight_gradient_and_launch_plan_options_agree(opts):

@@ -56,7 +56,7 @@ class BackwardArgs(C.Structure):
         ("targets", c_void_p), ("g_mu", c_void_p), ("g_nu", c_void_p), ("g_alpha", c_void_p), ("g_beta", c_void_p),
         ("loss", LossCfg),
         ("grads", c_void_p), ("loss_out", c_void_p), ("bin_counts", c_void_p),
-        ("bucket_events", c_void_p * 3), ("phase", c_int), ("global_stats", c_void_p), ("g_fused", c_void_p), ("stream", c_void_p),
+        ("bucket_events", c_void_p * 3), ("phase", c_int), ("bump_offset_dev", c_int), ("global_stats", c_void_p), ("g_fused", c_void_p), ("stream", c_void_p),
     ]
 
 

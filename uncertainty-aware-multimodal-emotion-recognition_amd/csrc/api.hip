@@ -142,7 +142,7 @@ Layout make_layout(void* base, void* wbase, int B, int f32) {
   L.h1 = act(Bz, HID); L.h2 = act(Bz, HID); L.e1 = act(Bz, 3 * EV1); L.e2 = act(Bz, 3 * EV2);
   L.probs = f32buf(Bz * 8 * 4); L.evid = f32buf(Bz * 12);
   const size_t nblk = (size_t)nig_nblocks(B);
-  L.stats = f32buf(nblk * 3 * NIG_NSTAT);
+  L.stats = f32buf(4 * nblk * 3 * NIG_NSTAT);      // block partials of nig_fwd_kernel, or four wave partials per block (the chain's NIG tail)
   L.mean_a2 = f32buf(Bz); L.rstd_a2 = f32buf(Bz); L.mean_t3 = f32buf(Bz); L.rstd_t3 = f32buf(Bz);
   L.mean_o1 = f32buf(Bz); L.rstd_o1 = f32buf(Bz);
   L.dz2 = act(Bz, 3 * EV2); L.de1 = act(Bz, 3 * EV1); L.dh2 = act(Bz, HID); L.dh1 = act(Bz, HID);
@@ -181,7 +181,7 @@ OptEntry g_opts[OPT_COUNT] = {
     {"glds", 1, 0, 1, {1}}, {"nt8", 1, 0, 1, {1}}, {"t128", 512, 1, 1 << 30, {512}}, {"tile", -1, -1, 4, {-1}}, {"ksteps", 0, 0, 4096, {0}},
     {"ln_fused", 1, 0, 1, {1}}, {"chain", 1, 0, 1, {1}}, {"chain_bwd", 1, 0, 1, {1}}, {"chain_min", 512, 1, 1 << 30, {512}},
     {"dw_tile", 2, 2, 4, {2}}, {"dw_kg", 2, 1, 2, {2}}, {"chain_max", 8192, 1, 1 << 30, {8192}}, {"chain_nig", 1, 0, 1, {1}},
-    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 4, {4}}, {"chain_ts", 0, 0, 32, {0}}, {"chain_in", 1, 0, 1, {1}},
+    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 4, {4}}, {"chain_ts", 0, 0, 32, {0}}, {"chain_in", 1, 0, 1, {1}}, {"chain_nigf", 0, 0, 1, {0}},
 };
 }  // namespace
 
@@ -221,6 +221,11 @@ int ksteps_target(int f32) {
 // bf16 mode.  Default 1: tri_fused.hip.  "qkv_recompute" = 0 (with the fused forward): the forward also stores q|k|v and
 // the backward runs the unfused attention-backward kernel on it instead of recomputing the head tiles.
 int env_fused_attn() { return opt(OPT_FUSED_ATTN); }
+// the forward head chain ends in the NIG head (option chain_nigf): the loss statistics in the workspace are wave partials then.
+// Forward, backward and mmdeer_loss_stats of one step must agree on it: it depends on the options and the batch size only.
+bool nig_tail_plan(int B, int f32) {
+  return !f32 && opt(OPT_CHAIN) && opt(OPT_CHAIN_NIGF) && B >= opt(OPT_CHAIN_MIN) && B <= opt(OPT_CHAIN_MAX);
+}
 int env_qkv_recompute() { return opt(OPT_QKV_RECOMPUTE); }
 int forced_tile() { return opt(OPT_TILE); }
 }  // namespace
@@ -560,11 +565,11 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   Exec X;
   X.B = B; X.f32 = f32; X.es = f32 ? 4 : 2; X.L = &L; X.s = s;
   X.drop_on = a->training && a->dropout_p > 0.f;
-  // The device-side dropout step counter (HIP-graph replays) is advanced by the LAST kernel of the forward (the NIG head, which
-  // draws no mask) instead of its first: the forward's kernels add the pending 1 to the host-side offset, the backward's read the
-  // advanced counter -- every kernel of the step sees the same effective offset, and no kernel in front of the first mask has to
-  // exist just to bump it.
-  unsigned long long* const bump = (a->bump_offset_dev && a->offset_dev) ? reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(a->offset_dev)) : nullptr;
+  // The device-side dropout step counter (HIP-graph replays) is advanced by the LAST kernel of the STEP (the fold at the end of
+  // mmdeer_backward, which draws no mask): with bump_offset_dev every kernel of the forward and of the backward adds the pending 1
+  // to the host-side offset -- the same effective offset everywhere, and no kernel has to exist just to bump the counter (round 3:
+  // the pad launch in front of the first mask; the chains took that launch away).
+  const bool bump = a->bump_offset_dev && a->offset_dev;
   X.dc = make_drop(a->dropout_p, a->seed, a->offset + (bump ? 1 : 0), a->offset_dev);
   X.mask_scale = X.drop_on ? X.dc.scale : 1.f;
   const int in_f32 = a->inputs_bf16 ? 0 : 1;
@@ -574,6 +579,7 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   // first two layers of the audio-visual chain below -- the workgroup reads its samples' text, video and raw 84-wide audio rows
   // itself (padding the audio rows in LDS and leaving the padded copy for the weight-gradient launch): no pad launch, no F1 launch.
   const bool in_chain = chains && opt(OPT_CHAIN_IN) && !in_f32 && chain_samples_per_workgroup(B) == 16;
+  const bool nig_tail = nig_tail_plan(B, f32);
 
   // F0 (bf16 mode): 84-wide rows are not 16-byte aligned -- zero-pad the audio block to 128 columns so that it runs on the
   //     LDS-DMA kernels
@@ -766,11 +772,17 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
       c.seg[k++] = q;
     }
     c.nseg = k;
+    if (nig_tail) {     // F18 as the chain's tail: last head layer, NIG activations, uncertainties, loss statistics (wave partials)
+      ChainNigF& g = c.nigf;
+      g.enabled = 1;
+      g.w3 = reinterpret_cast<const bf16_t*>(X.W(P_EV2_W)); g.b3 = X.V(P_EV2_B); g.b3_stride = 64;
+      g.evid = L.evid; g.nig_out = a->nig_out; g.targets = a->targets; g.wstats = L.stats;
+    }
 #ifdef MMDEER_STAMPS
     c.stamps = reinterpret_cast<unsigned long long*>(L.slab);   // diagnostic library: cycle samples of workgroup 0 (tools/chain_stamps.py)
 #endif
     TRY(launch_chain(c, s));
-    MARK("chain F9-F17 (trimodal fusion tail + head)");
+    MARK(nig_tail ? "chain F9-F18 (trimodal fusion tail + head + NIG)" : "chain F9-F17 (trimodal fusion tail + head)");
   } else {
     // F9: out_proj on the pooled context (mean over tokens commutes with the linear map; fusion.py:335)
     TRY(X.run1(X.fwd(L.obar, f32, FUS, P_TOUT_W, P_TOUT_B, L.pool, FUS, B, 0, -1)));
@@ -807,8 +819,10 @@ int mmdeer_forward(const mmdeer_forward_args* a) {
   }
   if (!chains) MARK("F9-F17 separate launches");
   // F18: last layer (64 -> 4), NIG activations, uncertainties and -- with targets -- the loss statistics
-  TRY(launch_nig_fwd(L.e2, X.W(P_EV2_W), X.V(P_EV2_B), 64, L.evid, a->nig_out, a->targets, L.stats, B, f32, bump, s));
-  MARK("nig_fwd (head's last layer + loss statistics)");
+  if (!nig_tail) {
+    TRY(launch_nig_fwd(L.e2, X.W(P_EV2_W), X.V(P_EV2_B), 64, L.evid, a->nig_out, a->targets, L.stats, B, f32, s));
+    MARK("nig_fwd (head's last layer + loss statistics)");
+  }
   return 0;
 }
 
@@ -824,11 +838,15 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   Exec X;
   X.B = B; X.f32 = f32; X.es = f32 ? 4 : 2; X.L = &L; X.s = s;
   X.drop_on = a->training && a->dropout_p > 0.f;
-  X.dc = make_drop(a->dropout_p, a->seed, a->offset, a->offset_dev);
+  // bump_offset_dev: the matching forward ran with it -- the pending 1 is added here too, and the last launch of the pass (of phase
+  // 2 in the two-call mode) advances the counter
+  const bool bump = a->bump_offset_dev && a->offset_dev;
+  X.dc = make_drop(a->dropout_p, a->seed, a->offset + (bump ? 1 : 0), a->offset_dev);
   X.mask_scale = X.drop_on ? X.dc.scale : 1.f;
   const int in_f32 = a->inputs_bf16 ? 0 : 1;
   const size_t es = X.es;
   float* G = a->grads;
+  const int nwp = nig_tail_plan(B, f32) ? (B + 15) / 16 : 0;      // the forward left wave partials of the loss statistics
   LossCfg cfg;
   cfg.reg_w = a->loss.reg_weight; cfg.kl_w = a->loss.kl_weight; cfg.ece_w = a->loss.ece_weight;
   cfg.cross_w = a->loss.cross_weight;
@@ -879,6 +897,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
       if (trace_mark("weight gradients (all problems, one launch)", s) != 0) return -1;
       for (int i = 0; i < dwg.nprob; ++i) Exec::add_slab_segments(rt, dwg.p[i], L.slab, G);
     }
+    if (bump && (phase == 0 || phase == 2)) rt.bump = reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(a->offset_dev));
     if (launch_reduce_partials(rt, s) != 0) return -1;
     if (trace_mark("reduce_partials (fold)", s) != 0) return -1;
     for (int b = ev_done; b <= bucket; ++b)      // every bucket up to this one is final now
@@ -897,7 +916,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
   const bool nigfold = bchain && opt(OPT_CHAIN_NIG) && a->targets;
   if (!nigfold)
     TRY(launch_nig_bwd(L.e2, X.W(P_EV2_W), L.evid, a->targets, L.stats, a->targets ? a->global_stats : nullptr, a->g_mu, a->g_nu, a->g_alpha, a->g_beta, nullptr,
-                       L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, s));
+                       L.dz2, L.part_w3, L.part_b3, a->loss_out, a->bin_counts, B, f32, X.mask_scale, cfg, nwp, s));
   if (!nigfold) MARK("nig_bwd (head's last layer backward + loss gradient)");
   // B2-B10 are local to a sample like the forward's layers: in bf16 mode (chain_min <= B <= chain_max, no outside gradient on fused_features)
   // ONE launch of the layer-chain kernel walks the head's four dX products, both LayerNorm backwards and the three trimodal dX
@@ -939,7 +958,7 @@ int mmdeer_backward(const mmdeer_backward_args* a) {
       ChainNig& g = c.nig;
       g.enabled = 1;
       g.e2 = reinterpret_cast<const bf16_t*>(L.e2); g.w3 = reinterpret_cast<const bf16_t*>(X.W(P_EV2_W)); g.evid = L.evid;
-      g.targets = a->targets; g.stats = L.stats; g.gstats = a->global_stats; g.nblk = nblk;
+      g.targets = a->targets; g.stats = L.stats; g.gstats = a->global_stats; g.nblk = nblk; g.nwp = nwp;
       g.dz2 = reinterpret_cast<bf16_t*>(L.dz2); g.partial_w = L.part_w3; g.partial_b = L.part_b3;
       g.loss_out = a->loss_out; g.bin_counts = a->bin_counts; g.mask_scale = X.mask_scale; g.cfg = cfg;
     }
@@ -1402,7 +1421,7 @@ int mmdeer_loss_stats(const void* workspace, size_t workspace_bytes, int batch, 
   MMDEER_CHECK(batch > 0, "loss_stats: batch must be > 0 (got %d)", batch);
   const Layout L = make_layout(const_cast<void*>(workspace), nullptr, batch, compute_f32 ? 1 : 0);
   MMDEER_CHECK(workspace_bytes >= L.bytes, "loss_stats: workspace of %zu bytes is smaller than the %zu of this batch", workspace_bytes, L.bytes);
-  return launch_nig_stats_sum(L.stats, batch, out, (hipStream_t)stream);
+  return launch_nig_stats_sum(L.stats, batch, out, nig_tail_plan(batch, compute_f32 ? 1 : 0) ? (batch + 15) / 16 : 0, (hipStream_t)stream);
 }
 
 long long mmdeer_deer_loss_v1_scratch(long long n) { return n > 0 ? 4ll * deer_v1_nblocks(n) : 0; }

@@ -67,6 +67,7 @@ struct ChainNig {
   const float* stats;      // [nblk][3][NIG_NSTAT] block partials of the forward's loss statistics
   const float* gstats;     // optional: the global batch's statistics instead (exact-global data-parallel mode)
   int nblk;
+  int nwp;                 // > 0: `stats` holds that many wave partials (the forward chain's NIG tail), four to a block
   bf16_t* dz2;             // [B][192]
   float* partial_w;
   float* partial_b;
@@ -74,6 +75,22 @@ struct ChainNig {
   int* bin_counts;         // [3][10] or null
   float mask_scale;
   LossCfg cfg;
+};
+
+// Forward chains only: the NIG head as the chain's TAIL -- the last layer (64 -> 4 per emotion dimension) on the finished e2 panel,
+// NIG activations, the three uncertainties and, with targets, the loss statistics: what nig_fwd_kernel (nig.hip) does in a launch
+// of its own, per (sample, dimension) with the same four lanes and the same arithmetic.  The statistics leave as WAVE partials
+// [16-sample block][3][NIG_NSTAT] (a wave here = a wave of that kernel's 64-sample block); their consumers combine four to a block in
+// block_stats' order, so the loss and its gradient are bit for bit those of the separate launch.
+struct ChainNigF {
+  int enabled;
+  const bf16_t* w3;        // [3][4][64] packed last-layer weights
+  const float* b3;         // [3][64-strided][4]: head d's bias at b3 + d * b3_stride
+  int b3_stride;
+  float* evid;             // [B][3][4]
+  float* nig_out;          // [7][B][3]
+  const float* targets;    // [B][3] or null
+  float* wstats;           // [ceil(B / 16)][3][NIG_NSTAT], written iff targets
 };
 
 // Host-side description of a chain (api.hip fills it; launch_chain() validates it and derives the kernel's tables).
@@ -91,6 +108,7 @@ struct ChainArgs {
   int aux_ldv, aux_lda;
   unsigned long long* stamps;   // diagnostic builds (-DMMDEER_STAMPS) only: cycle-counter samples of workgroup 0; else null
   ChainNig nig;            // enabled: X is unused, K0 = ldx = 192, groups = 1
+  ChainNigF nigf;          // enabled: the last layer must be the 192-wide e2 panel of one row group
   ChainSeg seg[CHAIN_MAX_SEGS];
 };
 

@@ -169,6 +169,7 @@ struct ChainKArgs {
   ChainRecK rec[CHAIN_MAX_SEGS];
   ChainVecK vec[CHAIN_MAX_VECS];
   ChainNig nig;      // behind the tables: not copied to LDS, read as kernel arguments
+  ChainNigF nigf;
 };
 static_assert(__builtin_offsetof(ChainKArgs, rec) % 16 == 0, "tables must be 16-byte aligned");
 static_assert(sizeof(ChainKArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -400,7 +401,7 @@ __device__ __forceinline__ void chain_nig_head(const ChainNig& g, unsigned char*
   }
   const int stat_n = g.gstats ? (int)g.gstats[3 * NIG_NSTAT] : B;
   NSTAMP(111);
-  compute_finals(g.gstats ? g.gstats : g.stats, g.gstats ? 1 : g.nblk, stat_n, g.cfg, F, gs, ftmp);
+  compute_finals(g.gstats ? g.gstats : g.stats, g.gstats ? 1 : g.nblk, stat_n, g.cfg, F, gs, ftmp, g.gstats ? 0 : g.nwp);
   NSTAMP(112);
   if (blockIdx.x == 0 && tid == 0) write_loss(F, g.loss_out, g.bin_counts);
   if (quad_on) {
@@ -446,6 +447,71 @@ __device__ __forceinline__ void chain_nig_head(const ChainNig& g, unsigned char*
     g.partial_b[(long long)blockIdx.x * 12 + tid] = bs;
   }
   // no barrier here: the caller's prologue barrier follows, and the scratch area is next written by the first segment's epilogue
+}
+
+// The NIG head as the tail of the forward head chain (ChainNigF, chain.h): nig_fwd_kernel's arithmetic on the workgroup's MS samples
+// from the finished e2 panel.  The LAST 3 MS / 16 waves own one (16-row block, dimension) each, four lanes per (sample, dimension).
+template <int MS>
+__device__ __forceinline__ void chain_nig_tail(const ChainNigF& g, const unsigned char* pan, int row0, int B, int tid) {
+  const int wave = tid >> 6, lane = tid & 63, q = lane & 3;
+  const int qw = wave - (8 - 3 * (MS / 16));
+  if (qw < 0) return;                          // a wave-uniform branch: only the quad waves work
+  const int d = qw % 3, blk = qw / 3;
+  const int r = 16 * blk + (lane >> 2);
+  const int b = row0 + r;
+  const bool active = b < B;
+  const int bc = active ? b : B - 1;
+  float w[4][16], x[16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) load_chunk16<false>(g.w3, d * 256 + c * 64 + q * 16, w[c]);
+  {   // this lane's 16 of the row's 64 inputs of dimension d: image d of the panel, chunks 2 q and 2 q + 1
+    const unsigned char* prow = pan + d * (MS * 128) + r * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(prow + (((2 * q + h) ^ (r & 7)) * 16));
+      const unsigned dw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[8 * h + 2 * e] = __uint_as_float(dw[e] << 16); x[8 * h + 2 * e + 1] = __uint_as_float(dw[e] & 0xFFFF0000u); }
+    }
+  }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    a0 = fmaf(x[j], w[0][j], a0); a1 = fmaf(x[j], w[1][j], a1);
+    a2 = fmaf(x[j], w[2][j], a2); a3 = fmaf(x[j], w[3][j], a3);
+  }
+  a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
+  const float* bb = g.b3 + d * g.b3_stride;
+  const f32x4 ev{a0 + bb[0], a1 + bb[1], a2 + bb[2], a3 + bb[3]};
+  const Nig n = nig_act(ev);
+  const bool writer = active && q == 0;
+  if (writer) {
+    *reinterpret_cast<f32x4*>(g.evid + ((long long)b * 3 + d) * 4) = ev;
+    const float alea = n.beta / (n.alpha - 1.f);             // deer.py:96-98
+    const float epis = n.beta / (n.nu * (n.alpha - 1.f));
+    const long long o = (long long)b * 3 + d, plane = (long long)B * 3;
+    float* out = g.nig_out;
+    out[o] = n.mu; out[plane + o] = n.nu; out[2 * plane + o] = n.alpha; out[3 * plane + o] = n.beta;
+    out[4 * plane + o] = alea; out[5 * plane + o] = epis; out[6 * plane + o] = alea + epis;
+  }
+  if (g.targets) {
+    const float y = g.targets[(long long)bc * 3 + d];
+    const Terms t = loss_terms(n, y);
+    float* slab = g.wstats + ((long long)((row0 >> 4) + blk) * 3 + d) * NIG_NSTAT;
+    // the per-wave half of block_stats (nig_dev.h): the same 35 values, the same wave_sum
+    float v[NIG_NSTAT];
+    v[0] = writer ? t.logprob : 0.f; v[1] = writer ? t.reg : 0.f; v[2] = writer ? t.kla : 0.f; v[3] = writer ? t.klb : 0.f; v[4] = writer ? t.u : 0.f;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const bool in = writer && t.bin == k;
+      v[5 + k] = in ? t.conf : 0.f; v[15 + k] = in ? t.aerr : 0.f; v[25 + k] = in ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NIG_NSTAT; ++i) {
+      const float sm = wave_sum(v[i]);
+      if (lane == 0) slab[i] = sm;
+    }
+  }
 }
 
 // D: weight stages a wave keeps in flight (2 KiB each, in a[0 : 8 D)); VECF floats of bias / gamma / beta in LDS.
@@ -927,6 +993,9 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     }
     stamp(5 + 3 * si);
   }
+  // forward head chain: the NIG head on the finished e2 panel (the last layer end's barrier made it complete; its stash copy only
+  // read it).  Tracked loads in here drain the wrapped-around weight stages: nothing reads those.
+  if (a.nigf.enabled) chain_nig_tail<MS>(a.nigf, pin, row0, B, tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -1046,6 +1115,15 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   k.X = a.X; k.ldx = a.ldx; k.K0 = a.K0; k.B = a.B; k.groups = a.groups; k.group_stride = a.group_stride; k.drop = a.drop;
   k.stamps = a.stamps;
   k.nig = a.nig;
+  k.nigf = a.nigf;
+  if (a.nigf.enabled) {
+    const ChainSeg& last = a.seg[a.nseg - 1];
+    MMDEER_CHECK(!a.nig.enabled && last.end_layer && last.nout == 192 && !last.gamma && !last.lnb_gamma && last.fold_groups == 0,
+                 "chain: the NIG tail needs a plain 192-wide last layer");
+    MMDEER_CHECK(a.nigf.w3 && a.nigf.b3 && a.nigf.evid && a.nigf.nig_out && (!a.nigf.targets || a.nigf.wstats) &&
+                     ((uintptr_t)a.nigf.w3 % 16) == 0 && ((uintptr_t)a.nigf.evid % 16) == 0,
+                 "chain: NIG tail: NULL argument / alignment");
+  }
   int vec = 0, nend = 0, nvec = 0;
   int blocks_in = a.groups * ts, width_in = a.K0, layer_first_seg = 0;
   bool layer_has_group1 = false;

@@ -22,9 +22,8 @@ inline int nig_nblocks(int B) { return B > 0 ? (B + NIG_ROWS - 1) / NIG_ROWS : 1
 // evid: [B,3,4] fp32 raw evidence (saved for backward)
 // nig_out: [7][B][3] fp32 = mu, nu, alpha, beta, aleatoric, epistemic, total uncertainty
 // targets: [B,3] fp32 or null; stats: [nblk][3][NIG_NSTAT] fp32 block partials (written iff targets)
-// bump: optional device-side dropout step counter; one thread adds 1 (this is the forward's last kernel)
 int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_stride, float* evid, float* nig_out,
-                   const float* targets, float* stats, int B, int act_f32, unsigned long long* bump, hipStream_t s);
+                   const float* targets, float* stats, int B, int act_f32, hipStream_t s);
 
 // Backward of the head's last layer.  Two modes:
 //   loss mode  (targets != null): gradients of MultiTaskDEERLoss are formed in-kernel from `stats`;
@@ -37,10 +36,12 @@ int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_strid
 int launch_nig_bwd(const void* e2, const void* w3, const float* evid, const float* targets, const float* stats,
                    const float* gstats, const float* gmu, const float* gnu, const float* galpha, const float* gbeta,
                    float* devid, void* dz2, float* partial_w, float* partial_b, float* loss_out, int* bin_counts,
-                   int B, int act_f32, float mask_scale, const LossCfg& cfg, hipStream_t s);
+                   int B, int act_f32, float mask_scale, const LossCfg& cfg, int nwp, hipStream_t s);
+// nwp (here and below): 0 = `stats` holds nig_fwd_kernel's block partials; > 0 = it holds that many WAVE partials (16 samples each,
+// written by the forward chain's NIG tail, chain.hip), combined four to a block in block_stats' order: bit-identical sums.
 
 // out[d][k] = sum over the nblk block partials of stats, out[3 * NIG_NSTAT] = B
-int launch_nig_stats_sum(const float* stats, int B, float* out, hipStream_t s);
+int launch_nig_stats_sum(const float* stats, int B, float* out, int nwp, hipStream_t s);
 
 // Standalone loss on given NIG parameters (the `nig_loss` op of the C-ABI): same statistics / gradient code,
 // inputs are gamma, nu, alpha, beta [B,3]; outputs loss_out[17], bin_counts[30] and (optional) d{gamma,nu,alpha,beta}.

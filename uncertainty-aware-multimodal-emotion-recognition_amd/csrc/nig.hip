@@ -31,12 +31,8 @@ namespace {
 // ------------------------------------------------------------------ forward (+ loss statistics)
 template <bool F32>
 __global__ __launch_bounds__(256) void nig_fwd_kernel(const void* e2, const void* w3, const float* b3, int b3_stride,
-                                                      float* evid, float* nig_out, const float* targets, float* stats, int B,
-                                                      unsigned long long* bump) {
+                                                      float* evid, float* nig_out, const float* targets, float* stats, int B) {
   const int d = blockIdx.y, tid = threadIdx.x, q = tid & 3;
-  // the device-side dropout step counter: advanced here, by the last kernel of the forward (nothing in this kernel reads it; the
-  // forward's kernels added the pending 1 on the host side, the backward's read the new value)
-  if (bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *bump += 1;
   const int b = blockIdx.x * NIG_ROWS + (tid >> 2);
   const bool active = b < B;
   const int bc = active ? b : B - 1;   // inactive quads read a valid row, their results are discarded
@@ -77,7 +73,7 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
                                                       const float* stats, const float* gstats, const float* gmu,
                                                       const float* gnu, const float* galpha, const float* gbeta, float* devid, void* dz2,
                                                       float* partial_w, float* partial_b, float* loss_out,
-                                                      int* bin_counts, int B, float mask_scale, LossCfg cfg) {
+                                                      int* bin_counts, int B, float mask_scale, LossCfg cfg, int nwp) {
   __shared__ float gs[3][NIG_NSTAT];
   __shared__ float ftmp[NIG_FINALS_TMP];
   __shared__ f32x4 sdE[NIG_ROWS];
@@ -104,7 +100,7 @@ __global__ __launch_bounds__(256) void nig_bwd_kernel(const void* e2, const void
     GSTAMP(1);
     // exact-global mode: the statistics of all ranks' batches (already summed), N = the global batch size
     const int stat_n = gstats ? (int)gstats[3 * NIG_NSTAT] : B;
-    compute_finals(gstats ? gstats : stats, gstats ? 1 : nblk, stat_n, cfg, F, gs, ftmp);
+    compute_finals(gstats ? gstats : stats, gstats ? 1 : nblk, stat_n, cfg, F, gs, ftmp, gstats ? 0 : nwp);
     GSTAMP(2);
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) write_loss(F, loss_out, bin_counts);
     const Nig n = nig_act(ev);
@@ -364,29 +360,34 @@ __global__ __launch_bounds__(256) void calibration_kernel(const float* gamma, co
 }  // namespace
 
 int launch_nig_fwd(const void* e2, const void* w3, const float* b3, int b3_stride, float* evid, float* nig_out,
-                   const float* targets, float* stats, int B, int act_f32, unsigned long long* bump, hipStream_t s) {
+                   const float* targets, float* stats, int B, int act_f32, hipStream_t s) {
   if (B == 0) return 0;
   dim3 grid(nig_nblocks(B), 3);
-  if (act_f32) hipLaunchKernelGGL(nig_fwd_kernel<true>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B, bump);
-  else hipLaunchKernelGGL(nig_fwd_kernel<false>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B, bump);
+  if (act_f32) hipLaunchKernelGGL(nig_fwd_kernel<true>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B);
+  else hipLaunchKernelGGL(nig_fwd_kernel<false>, grid, dim3(256), 0, s, e2, w3, b3, b3_stride, evid, nig_out, targets, stats, B);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
 
-__global__ __launch_bounds__(128) void nig_stats_sum_kernel(const float* stats, int nblk, int B, float* out) {
+__global__ __launch_bounds__(128) void nig_stats_sum_kernel(const float* stats, int nblk, int B, float* out, int nwp) {
   const int i = threadIdx.x;
   if (i < 3 * NIG_NSTAT) {
     float acc = 0.f;
-    for (int p = 0; p < nblk; ++p) acc += stats[(long long)p * 3 * NIG_NSTAT + i];   // same order as compute_finals
+    for (int p = 0; p < nblk; ++p) {
+      if (nwp == 0) { acc += stats[(long long)p * 3 * NIG_NSTAT + i]; continue; }
+      float w[4];      // wave partials of the forward chain's NIG tail: the four of a block as block_stats combines them
+      for (int z = 0; z < 4; ++z) w[z] = 4 * p + z < nwp ? stats[(long long)(4 * p + z) * 3 * NIG_NSTAT + i] : 0.f;
+      acc += (w[0] + w[1]) + (w[2] + w[3]);
+    }
     out[i] = acc;
   } else if (i == 3 * NIG_NSTAT) {
     out[i] = (float)B;
   }
 }
 
-int launch_nig_stats_sum(const float* stats, int B, float* out, hipStream_t s) {
+int launch_nig_stats_sum(const float* stats, int B, float* out, int nwp, hipStream_t s) {
   MMDEER_CHECK(B > 0, "nig statistics need a non-empty batch");
-  hipLaunchKernelGGL(nig_stats_sum_kernel, dim3(1), dim3(128), 0, s, stats, nig_nblocks(B), B, out);
+  hipLaunchKernelGGL(nig_stats_sum_kernel, dim3(1), dim3(128), 0, s, stats, nig_nblocks(B), B, out, nwp);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }
@@ -394,15 +395,15 @@ int launch_nig_stats_sum(const float* stats, int B, float* out, hipStream_t s) {
 int launch_nig_bwd(const void* e2, const void* w3, const float* evid, const float* targets, const float* stats,
                    const float* gstats, const float* gmu, const float* gnu, const float* galpha, const float* gbeta,
                    float* devid, void* dz2, float* partial_w, float* partial_b, float* loss_out, int* bin_counts,
-                   int B, int act_f32, float mask_scale, const LossCfg& cfg, hipStream_t s) {
+                   int B, int act_f32, float mask_scale, const LossCfg& cfg, int nwp, hipStream_t s) {
   MMDEER_CHECK(B > 0, "nig backward needs a non-empty batch");
   dim3 grid(nig_nblocks(B), 3);
   if (act_f32)
     hipLaunchKernelGGL(nig_bwd_kernel<true>, grid, dim3(256), 0, s, e2, w3, evid, targets, stats, gstats, gmu, gnu, galpha, gbeta,
-                       devid, dz2, partial_w, partial_b, loss_out, bin_counts, B, mask_scale, cfg);
+                       devid, dz2, partial_w, partial_b, loss_out, bin_counts, B, mask_scale, cfg, nwp);
   else
     hipLaunchKernelGGL(nig_bwd_kernel<false>, grid, dim3(256), 0, s, e2, w3, evid, targets, stats, gstats, gmu, gnu, galpha, gbeta,
-                       devid, dz2, partial_w, partial_b, loss_out, bin_counts, B, mask_scale, cfg);
+                       devid, dz2, partial_w, partial_b, loss_out, bin_counts, B, mask_scale, cfg, nwp);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

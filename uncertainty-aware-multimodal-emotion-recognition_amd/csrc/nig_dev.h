@@ -116,8 +116,11 @@ struct Finals {
 // -- before each LDS read that might alias one: 267 such waits appeared in the chain kernel's stage loops and tile epilogues and
 // cost 25 us per step.  With the kernel's one LDS array as the only object there is no scope information and no such wait.)
 constexpr int NIG_FINALS_TMP = 3 * NIG_NSTAT + 30 + 3 + 3;
+// `nwp` > 0: `stats` holds nwp WAVE partials (16 samples each, what the forward chain's NIG tail writes: chain.hip) instead of nblk
+// block partials; the four of a block are combined as block_stats combines its four waves -- (w0 + w1) + (w2 + w3), absent waves
+// count as the zeros an inactive wave contributes -- so every sum comes out bit for bit as from nig_fwd_kernel's partials.
 __device__ __forceinline__ void compute_finals(const float* stats, int nblk, int B, const LossCfg& cfg, Finals& F,
-                                               float (*gs)[NIG_NSTAT], float* tmp) {
+                                               float (*gs)[NIG_NSTAT], float* tmp, int nwp = 0) {
   // Identical in every workgroup (blockDim.x == 256), and every wave of it waits here: the serial part is kept short.
   // Measured on workgroup (0,0) at B = 4096 (tools/nig_stamps.py): one thread walking the 3 x 10 bins took 12.4k cycles
   // and the chain of nblk dependent adds 5.9k, of 30k for the whole kernel.
@@ -132,17 +135,42 @@ __device__ __forceinline__ void compute_finals(const float* stats, int nblk, int
       const int per = (nblk + 1) >> 1, p0 = h * per, p1 = (p0 + per < nblk) ? p0 + per : nblk;
       // batches of 16 unconditional loads (index clamped, value masked): a load under a per-lane branch would be
       // waited for on the spot, and a plain accumulation loop is a chain of dependent adds
-      for (int q = p0; q < p1; q += 16) {
-        float v[16];
+      if (nwp == 0) {
+        for (int q = p0; q < p1; q += 16) {
+          float v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int p = q + u < p1 ? q + u : p1 - 1;
-          v[u] = stats[(long long)p * NV + i];
+          for (int u = 0; u < 16; ++u) {
+            const int p = q + u < p1 ? q + u : p1 - 1;
+            v[u] = stats[(long long)p * NV + i];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = q + u < p1 ? v[u] : 0.f;
+          acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+                 (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
         }
+      } else {
+        // wave partials: ALL 64 loads of a batch of 16 blocks first (clamped indices, values masked afterwards -- a branch between
+        // them made every group of four a round trip of its own: 29k cycles instead of 7k), then the four of a block, then the tree
+        for (int q = p0; q < p1; q += 16) {
+          float w[16][4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = q + u < p1 ? v[u] : 0.f;
-        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
-               (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+          for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int z = 0; z < 4; ++z) {
+              const int p = q + u < p1 ? q + u : p1 - 1, wp = 4 * p + z;
+              w[u][z] = stats[(long long)(wp < nwp ? wp : nwp - 1) * NV + i];
+            }
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int p = q + u < p1 ? q + u : p1 - 1;
+#pragma unroll
+            for (int z = 0; z < 4; ++z) w[u][z] = 4 * p + z < nwp ? w[u][z] : 0.f;
+            v[u] = q + u < p1 ? (w[u][0] + w[u][1]) + (w[u][2] + w[u][3]) : 0.f;
+          }
+          acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+                 (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        }
       }
       if (h == 1) upper[i] = acc;
     }

@@ -31,6 +31,10 @@ enum OptId {
   OPT_CHAIN_TS,         // 0: 16-sample chain workgroups up to B = 4096, 32-sample ones above; 16 / 32: that size at every batch
   OPT_CHAIN_IN,         // 1 (with chain = 1, bf16 feature blocks, B <= 4096): the three input projections and the audio padding run
                         // inside the audio-visual chain's launch instead of as pad + F1 launches
+  OPT_CHAIN_NIGF,       // 1 (with chain = 1; default 0): the NIG head (last layer, activations, loss statistics) runs as the tail of the
+                        // forward head chain instead of a launch of its own.  Bit-identical, one launch fewer -- and measured 6 us
+                        // SLOWER per step at B = 4096: the 256 wave partials cost the backward chain's prologue 8k cycles more to
+                        // fetch than the 64 block partials, the tail itself 5k
   OPT_COUNT
 };
 

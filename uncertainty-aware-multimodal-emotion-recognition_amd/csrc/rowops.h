@@ -53,6 +53,8 @@ struct ReduceTable {
   int n[REDUCE_MAX_SEGMENTS];             // multiple of 4
   long long stride[REDUCE_MAX_SEGMENTS];
   int bstart[REDUCE_MAX_SEGMENTS + 1];    // filled by the launcher: first block of each segment (256 elements per block)
+  unsigned long long* bump;               // optional: thread 0 of block 0 adds 1 (the device-side dropout step counter: this fold is
+                                          // the last launch of a training step and reads no mask)
 };
 // dst[j] = sum_p src[p*stride + j] in a fixed order (deterministic): folds LayerNorm / head partial slabs and
 // split-K weight-gradient slabs into the flat gradient buffer.

@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceTable 
   __shared__ f32x4 red[4][64];
   const auto& T = karg<ReduceTable>();
   const int b = blockIdx.x;
+  if (T.bump && b == 0 && threadIdx.x == 0) *T.bump += 1;
   int sgm = 0;
 #pragma unroll
   for (int i = 1; i < REDUCE_MAX_SEGMENTS; ++i)

@@ -333,7 +333,7 @@ class MultimodalDEER(nn.Module):
         _lib.check(lib.mmdeer_forward(C.byref(a)))
         self._st.packed_key = key
         self._st.generation += 1
-        meta = dict(B=B, training=int(training), in_bf16=int(in_bf16), offset=step, offset_dev=offset_dev, ws=ws, wb=wb,
+        meta = dict(B=B, training=int(training), in_bf16=int(in_bf16), offset=step, offset_dev=offset_dev, bump=int(bump), ws=ws, wb=wb,
                     inputs=(audio, video, text), targets=targets)
         return {"_nig": nig, "_meta": meta, "fused_features": fused, "audiovisual_features": avf,
                 "trimodal_features": trif, "av_attention": avw, "trimodal_attention": triw}
@@ -359,6 +359,7 @@ class MultimodalDEER(nn.Module):
         a.batch, a.compute_f32, a.training, a.inputs_bf16 = B, self.compute_f32, meta["training"], meta["in_bf16"]
         a.dropout_p, a.seed, a.offset = float(self.dims.dropout), self.dropout_seed, meta["offset"]
         a.offset_dev = _lib.ptr(meta.get("offset_dev"))
+        a.bump_offset_dev = int(meta.get("bump", 0))      # the forward ran with the pending increment: the backward's last launch stores it
         audio, video, text = meta["inputs"]
         a.audio, a.video, a.text = audio.data_ptr(), video.data_ptr(), text.data_ptr()
         a.workspace, a.workspace_bytes = meta["ws"].data_ptr(), meta["ws"].numel()
@@ -574,7 +575,7 @@ class MultimodalDEER(nn.Module):
         self._graph_counter = torch.full((), int(self._step), dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        in_kernel = not self.compute_f32     # bf16: the first kernel of the forward bumps the counter itself
+        in_kernel = not self.compute_f32     # bf16: the step's kernels add the pending 1 themselves and its last launch stores the counter
         # With a collective in the capture (or a process group alive at all) the process has other threads that talk to the runtime (the communicator's watchdog
         # polls the events of earlier eager collectives): in the default "global" mode such a call from another thread, landing
         # while this one captures, invalidates the capture.  Only this thread's calls matter here.
