@@ -99,7 +99,7 @@ def recorded_profile(batch, dtype):
             # the two kernels that dominate the step by time, against the MFMA peak (flops from the layer shapes)
             w_sq = 3 * 64 * 128 + 384 * 256 + 256 * 256 + 256 * 512 + 3 * 512 * 512 + 2 * 1536 * 512 + 512 * 256 + 512 * 768 + \
                 256 * 512 + 2 * 2 * 256 * 256 + 256 * 256 + 256 * 128      # sum of N x K over the weight-gradient problems, 2B-row ones twice
-            chain_w = {"F2-F6": 2 * 2 * 256 * 256 + 256 * 512 + 512 * 256,
+            chain_w = {"F1-F6": 256 * 256 + 256 * 128 + 512 * 768 + 2 * 2 * 256 * 256 + 256 * 512 + 512 * 256,
                        "F9-F17": 3 * 512 * 512 + 256 * 512 + 256 * 256 + 384 * 256 + 3 * 64 * 128,
                        "B2-B10": 3 * 64 * 128 + 384 * 256 + 256 * 256 + 256 * 512 + 3 * 512 * 512,
                        "B13-B17": 512 * 256 + 256 * 512 + 2 * 2 * 256 * 256}
@@ -113,7 +113,7 @@ def recorded_profile(batch, dtype):
                     rec["mfma_tflops"][kname] = {"avg_us": round(avg[kname] * 1e6, 2), "tflops": round(fl / avg[kname] / 1e12, 1),
                                                  "frac_of_mfma_peak": round(fl / avg[kname] / BF16_MFMA_PEAK, 4),
                                                  "note": ("all weight gradients of the step in one launch" if kname.startswith("gemm_tt")
-                                                          else "average over the four layer-chain launches (F2-F6, F9-F17, B2-B10, B13-B17)")}
+                                                          else "average over the four layer-chain launches (F1-F6 incl. the input projections, F9-F17, B2-B10, B13-B17)")}
             for name, nbytes in hbm.items():
                 if name in avg:
                     rec["hbm_gbps"][name] = {"gbps": round(nbytes / avg[name] / 1e9, 1), "frac_of_8TBps": round(nbytes / avg[name] / 8e12, 3),

@@ -14,6 +14,8 @@ timeout -k 10 300 python bench.py --batch 7 --no-cpu-baseline > $OUT/bench_b7_bf
 timeout -k 10 200 python tools/fwd_only.py > $OUT/fwd_only.txt 2> $OUT/fwd_only.err; echo "fwd only rc=$?"
 ( cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $ROOT/$OUT/rocprof.log 2>&1; echo "rocprof rc=$?" )
 python tools/step_trace.py $OUT/prof/*/*_kernel_trace.csv 3 > $OUT/step_trace.txt 2>&1; echo "step trace rc=$?"
+( cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof8192 -- python3 $ROOT/bench.py --batch 8192 --no-cpu-baseline > $ROOT/$OUT/rocprof8192.log 2>&1; echo "rocprof B=8192 rc=$?" )
+python tools/step_trace.py $OUT/prof8192/*/*_kernel_trace.csv 3 > $OUT/step_trace_b8192.txt 2>&1; cp $OUT/prof8192/*/*_kernel_stats.csv $OUT/kernel_stats_b8192.csv 2>/dev/null; rm -rf $OUT/prof8192
 bash tools/gpu_pmc_fused.sh > $OUT/pmc.log 2>&1; echo "pmc rc=$?"
 cp gpurun_out/pmc_fused_summary.txt gpurun_out/pmc_traffic.json $OUT/ 2>/dev/null
 bash tools/gpu_pmc_step.sh > $OUT/pmc_step.log 2>&1; echo "pmc step rc=$?"

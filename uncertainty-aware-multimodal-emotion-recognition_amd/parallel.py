@@ -142,7 +142,23 @@ class BucketedAllReduce:
             raise ValueError("the bf16 payload needs the GPU (RCCL) path")
         self.payload = payload
         if backend == "rccl" and self.cuda and (self.world > 1 or self.force):
-            self._rccl = RcclCommunicator.from_torch_distributed(group)
+            # Collective set-up: if ANY rank cannot create the C-ABI communicator (librccl not loadable, ncclCommInitRank failing),
+            # every rank falls back to torch.distributed's own collectives together -- the first real multi-GPU run must not die here.
+            err = None
+            try:
+                self._rccl = RcclCommunicator.from_torch_distributed(group)
+            except Exception as e:      # noqa: BLE001
+                err = e
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok) == 0:
+                if self._rccl is not None:
+                    self._rccl.close()
+                    self._rccl = None
+                import sys
+                print(f"[mmdeer] C-ABI communicator unavailable on some rank ({type(err).__name__ if err else 'peer'}: {err}); "
+                      "gradient exchange through torch.distributed", file=sys.stderr)
+                self.backend = "torch"
         # exact-global loss (optional): ranks exchange the loss statistics between forward and backward
         # (sum_small), each rank's gradient then is its SHARE of the global-batch gradient and the exchange is a SUM
         self.exact_global = False
