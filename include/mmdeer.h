@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMDEER_ABI_VERSION 14
+#define MMDEER_ABI_VERSION 15
 
 /* ---- fixed geometry of the path (reference fusion.py:47-50, deer.py:201-202, configs/config.yaml:13-20).
  * RESTRICTION: mmdeer_forward / mmdeer_backward / mmdeer_adamw_step (the Stack C entry points) are compiled for exactly this
@@ -85,13 +85,13 @@ size_t mmdeer_weights_bytes(int compute_f32);
  *   chain_nig (1)      0: the head's last-layer backward + loss gradient as a launch of their own also when the backward chain runs
  *   dw_tile (2)        weight-gradient launch: 2 = 128x128 tiles, K-slices of B rows (no split-K slabs for the B-row problems),
  *                      3 = 256x256 tiles + split-K slabs, 4 = 256x128 tiles; dw_kg (2): 1 = the 128x128 kernel on 32-row K stages
- *   chain_depth (4)    weight stages a wave of the 16-sample chain kernel keeps in flight (2 or 4)
+ *   chain_depth (4)    weight stages a wave of the 16-sample chain kernel keeps in flight (2, 4 or 8)
  *   chain_in (1)       0: the input projections as a pad launch + one 3-problem GEMM launch also where the first chain could run them
  *   chain_nigf (0)     1: the NIG head as the tail of the forward head chain (bit-identical, one launch fewer, measured slower)
  *   chain_ts (0)       16 / 32: force the samples per chain workgroup (0: 16 up to B = 4096, 32 above)
  *   xcd, nt128, nt192, glds, nt8 (1), t128 (512), tile (-1), ksteps (0), splitk_max (8)   GEMM tile / split-K selection
  * mmdeer_set_option / mmdeer_get_option return -1 for an unknown name, mmdeer_set_option also for a value outside the option's
- * range (every option has one: booleans 0..1, dw_tile 2..4, dw_kg 1..2, tile -1..4, splitk_max 1..8, chain_depth 2..4, ...; the
+ * range (every option has one: booleans 0..1, dw_tile 2..4, dw_kg 1..2, tile -1..4, splitk_max 1..8, chain_depth 2..8, ...; the
  * message names it); mmdeer_option_name(i) enumerates (NULL past the end). */
 int mmdeer_set_option(const char* name, int value);
 int mmdeer_get_option(const char* name, int* value);
@@ -505,6 +505,8 @@ typedef struct mmdeer_stackb_attn_train_args {
   void* r;                  /* act [B][256]: weight_network hidden after ReLU and dropout */
   float* weights4;          /* fp32 [B][4]: softmax weights (audio, video, text, 0) */
   float* unc4;              /* fp32 [B][4]: modality uncertainties (audio, video, text, 0) */
+  void* unc8;               /* optional, written by the BACKWARD: act [B][8] = (unc4, 0, 0, 0, 0) -- the uncertainties as a k-contiguous
+                               operand of the weight-gradient GEMM of weight_network.0's uncertainty columns */
   /* backward: gradients in (d_av: rows of stride ld_av, audio | video; d_text: stride ld_text) and out */
   const void* d_av; const void* d_text;
   void* d_self; void* d_cross;    /* act [B][768] */
@@ -514,6 +516,7 @@ typedef struct mmdeer_stackb_attn_train_args {
   void* d_z8;                     /* act [3B][8]: column 0 = gradient at the estimator's pre-sigmoid output, the rest zeros */
   void* d_h2;                     /* act [3B][64] */
   int32_t ld_w1_unc, ld_av, ld_text, B, act_f32;
+  int32_t ld_dcross;              /* row stride of d_cross read as [3B][256] rows (0: dense, 256) -- lets it be the right half of a [3B][512] matrix */
   int32_t training, drop_site;    /* weight_network.2 dropout: keep mask = hash(seed, offset, drop_site, row, col) */
   float dropout_p;
   uint64_t seed, offset;
@@ -614,6 +617,72 @@ typedef struct mmdeer_stackb_forward_args {
 } mmdeer_stackb_forward_args;
 size_t mmdeer_stackb_workspace_bytes(int batch, int compute_f32, int audio_ld);
 int mmdeer_stackb_forward(const mmdeer_stackb_forward_args* a);
+
+/* ---- row-local layer chains as an operator (csrc/chain.hip) -------------------------------------------------------------
+ * A run of Linear (+ReLU +Dropout) (+LayerNorm | LayerNorm backward) layers that are local to a sample -- Stack B's residual
+ * encoders, attention value / output projections, fusion stages and evidence heads (reference complete_project.py:60-118,
+ * 120-184, 307-418) and their backward passes -- as ONE launch: a workgroup keeps 16 (or 32) samples' rows in LDS and walks the
+ * layers, only the weights stream.  bf16 activations and weights, fp32 accumulation and vectors; results are those of the same
+ * layers run one by one through mmdeer_gemm / mmdeer_layernorm_fwd / _bwd / mmdeer_add_masked, bit for bit.
+ *
+ * Weights are read from FRAGMENT-MAJOR images (mmdeer_repack, layout 1) of the [N][K] matrix a segment multiplies by (forward:
+ * the nn.Linear weight; dX = dY W: its transpose [K_lin][N_lin], i.e. N = in_features, K = out_features).
+ * A layer is one or more segments writing disjoint column ranges of one output panel; the last carries end_layer = 1.
+ * Limits: <= MMDEER_CHAIN_MAX_SEGS segments, 8 layers, 16 bias / gamma / beta vectors of 4864 floats in total; N % 64 == 0,
+ * K in {64, 128, 256, 384, 512, 768 (16-sample workgroups, one row block only)}, N % 128 == 0 or K % 128 == 0, <= 4 column tiles
+ * (of 128, or 64 when N % 128 != 0) per segment; panel width <= 768 columns (16-sample workgroups) or 512 (32-sample). */
+#define MMDEER_CHAIN_MAX_SEGS 12
+typedef struct mmdeer_chain_seg {
+  const void* W;            /* fragment-major image of the segment's [N][K] bf16 matrix */
+  const float* bias;        /* [N] or NULL */
+  int32_t N, K;
+  int32_t kin_off, nout_off;/* first input / output panel column (multiples of 64) */
+  int32_t relu;
+  int32_t drop_site, drop_shift, dcol_off;   /* drop_site < 0: no dropout; the mask is hash(seed, offset, site, row, (dcol_off + n) >> shift) */
+  const void* mask_y;       /* backward: out *= (Y[row][mask_col0 + n] > 0) * mask_scale (ReLU + dropout of the forward layer below), or NULL */
+  int32_t ld_mask, mask_col0;
+  float mask_scale;
+  int32_t res_add, res_dup; /* backward of a residual block (256-wide layers): add columns 256 + n of the input panel; write the result
+                               at columns 256 + n of the output panel as well */
+  int32_t end_layer;
+  /* end_layer only: */
+  int32_t nout;             /* width of the finished panel */
+  void* stash; int32_t ld_stash;             /* the finished (pre-LayerNorm) rows -> stash[row][ld_stash], or NULL */
+  void* stash2; int32_t stash_split;         /* columns >= stash_split go to stash2[row][ld_stash] instead (0: none) */
+  const float* gamma; const float* beta;     /* LayerNorm of the finished panel in place (nout 256 or 512), or NULL */
+  void* xln; float* mean; float* rstd;       /* its outputs: rows [row][nout] (with the residual when set), statistics [row] */
+  int32_t residual;         /* LayerNorm rows + the layer's input panel (x + LayerNorm(...)) */
+  const float* lnb_gamma;   /* non-NULL instead of gamma: LayerNorm BACKWARD of the finished panel (= d out of the LayerNorm) */
+  const void* lnb_y; const float* lnb_mean; const float* lnb_rstd;   /* the forward's pre-LayerNorm rows [row][nout], statistics */
+  void* lnb_dz;             /* result rows [row][nout] */
+  float* lnb_partial;       /* [mmdeer_chain_workgroups][2][nout] column sums of d * xhat and d (gamma / beta gradients; fold over workgroups) */
+  float lnb_mask_scale;     /* > 0: the (y > 0) * scale mask of the Linear-ReLU-Dropout in front of the LayerNorm */
+} mmdeer_chain_seg;
+typedef struct mmdeer_chain_args {
+  const void* X;            /* input rows [rows][ldx] bf16 */
+  int32_t ldx, K0;          /* leading dimension, width (multiple of 64) */
+  int32_t rows;             /* every row is a sample of its own */
+  int32_t samples_per_workgroup;   /* 0: the library's choice (16 up to 4096 rows, 32 above); 16 or 32 */
+  int32_t nseg;
+  float dropout_p;          /* ONE probability for every dropout site of the chain */
+  uint64_t seed, offset;
+  const uint64_t* offset_dev;
+  mmdeer_chain_seg seg[MMDEER_CHAIN_MAX_SEGS];
+  void* debug;              /* diagnostic builds (-DMMDEER_STAMPS) only: uint64[512] buffer for in-kernel cycle stamps; NULL otherwise */
+  void* stream;
+} mmdeer_chain_args;
+int mmdeer_chain(const mmdeer_chain_args* a);
+int mmdeer_chain_workgroups(int rows, int samples_per_workgroup);
+
+/* Derived bf16 images of bf16 matrices, any number of jobs in as few launches as possible (64 jobs each).  Job j restates the
+ * matrix S = src[j] ([rows][cols], row stride ld_src, columns >= cols_valid read as zero) or, with transpose, S^T, in layout 0
+ * (row-major at dst[j] with row stride ld_dst, starting at column dst_col) or layout 1 (fragment-major, what mmdeer_chain streams:
+ * rows of the image % 16 == 0, columns % 64 == 0). */
+typedef struct mmdeer_repack_job {
+  const void* src; void* dst;
+  int32_t ld_src, rows, cols, cols_valid, transpose, layout, ld_dst, dst_col;
+} mmdeer_repack_job;
+int mmdeer_repack(const mmdeer_repack_job* jobs, int n, void* stream);
 
 /* ---- gradient exchange: the data-parallel step has ONE exchange, of the flat gradient buffer: one
  * all-reduce, or reduce-scatter + all-gather (every rank reduces 1/N of the buffer from all peers at once and then fetches

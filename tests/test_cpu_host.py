@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/mmdeer.h but not exported"
     bound = {n for n, _, _ in _lib.SYMBOLS}
     assert bound == set(declared), (bound ^ set(declared))
-    assert lib.mmdeer_abi_version() == 14
+    assert lib.mmdeer_abi_version() == 15
     assert b"gfx950" in lib.mmdeer_version()
 
 

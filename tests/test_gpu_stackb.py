@@ -383,6 +383,7 @@ def test_fused_train_step_equals_the_autograd_path(compute, B):
     from mmdeer.optim import FlatAdamW
     m1, _ = _train_model(compute)
     m2 = copy.deepcopy(m1)
+    m2.train_plan = "ops"          # the launch-by-launch plan: the sequence autograd runs (the layer-chain plan has its own test below)
     b = synth.make_batch(B, seed=33)
     xs, y = _batch_dev(b)
     m1.train(); m2.train()
@@ -426,6 +427,78 @@ def test_fused_train_step_equals_the_autograd_path(compute, B):
     l2b = m2.train_step_fused(*xs, y)
     assert float(l1b["total_loss"]) == pytest.approx(float(l2b["total_loss"]), rel=1e-5 if compute == "fp32" else 2e-3)
     assert float(l2b["total_loss"]) != float(l2["total_loss"])
+
+
+@pytest.mark.parametrize("B", [100, 515, 1024])
+def test_fused_train_step_layer_chains_match_the_launch_by_launch_plan(B):
+    """the bf16 fused step runs its sample-local layer runs (residual encoders, attention value / output
+    projections, estimator, fusion stages, evidence heads -- complete_project.py:60-118, 120-184, 307-418 -- and their dX runs) as
+    launches of the layer-chain kernel (mmdeer_chain).  Same tape, same arithmetic per layer; the one difference is the summation
+    order inside LayerNorm's variance (1 fp32 ulp in rstd), which now and then flips a bf16 rounding that the following bf16
+    layers amplify -- so: equal loss to 2e-4, every stored activation equal except for a few bf16 ulps on a small fraction of the
+    elements, gradients equal in direction and norm."""
+    import copy
+    m1, _ = _train_model("bf16")
+    m2 = copy.deepcopy(m1)
+    m1.train_plan, m2.train_plan = "ops", "auto"
+    b = synth.make_batch(B, seed=35)
+    xs, y = _batch_dev(b)
+    m1.train(); m2.train()
+    m1._train_step = m2._train_step = 23
+    l1 = m1.train_step_fused(*xs, y)
+    l2 = m2.train_step_fused(*xs, y)
+    torch.cuda.synchronize()
+    T1, T2 = l1["_keep"][0], l2["_keep"][0]
+    assert not T1["chain"] and T2["chain"]
+    assert float(l2["total_loss"]) == pytest.approx(float(l1["total_loss"]), rel=2e-4)
+    assert int((l1["ece_bin_counts"] - l2["ece_bin_counts"]).abs().sum()) <= 2
+    for key in ("E", "VV", "S", "X", "H1", "H2", "AV", "T", "R2", "fused", "H0", "H3"):
+        a, c = T1[key].float(), T2[key].float()
+        assert torch.isfinite(c).all(), key
+        scale = float(a.abs().max())
+        assert float((a - c).abs().max()) <= 0.02 * scale, (key, float((a - c).abs().max()), scale)          # a few bf16 ulps
+        assert float((a - c).norm() / a.norm()) < 3e-3, (key, float((a - c).norm() / a.norm()))       # ... on a small fraction of the elements
+    for t1, t2 in zip(T1["enc"], T2["enc"]):
+        for a, c in zip(t1["h"] + t1["y"], t2["h"] + t2["y"]):
+            assert float((a.float() - c.float()).abs().max()) <= 0.02 * float(a.float().abs().max())
+            assert float((a.float() - c.float()).norm() / a.float().norm()) < 3e-3
+        for (ma, ra), (mc, rc) in zip(t1["st"], t2["st"]):
+            assert torch.allclose(ma, mc, rtol=1e-3, atol=1e-3) and torch.allclose(ra, rc, rtol=1e-3, atol=1e-3)
+    seen = 0
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        g1, g2 = p1.grad.double().flatten(), p2.grad.double().flatten()
+        assert torch.isfinite(g2).all(), n
+        if float(g1.norm()) == 0.0:
+            assert float(g2.norm()) == 0.0, n
+            continue
+        cos, ratio = float((g1 @ g2) / (g1.norm() * g2.norm())), float(g2.norm() / g1.norm())
+        assert cos > 0.998 and 0.95 < ratio < 1.05, (n, cos, ratio)
+        seen += 1
+    assert seen >= 100
+
+
+def test_layer_chain_operator_refuses_what_it_does_not_instantiate():
+    """mmdeer_chain validates its tables on the host: unsupported widths, panels that do not fit, a residual on a layer that changes
+    the geometry all fail with a message instead of launching."""
+    import ctypes as C
+    from mmdeer import _lib
+    lib = _lib.load()
+    x = torch.zeros(32, 256, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(256 * 256, dtype=torch.bfloat16, device="cuda")
+    a = _lib.ChainArgs()
+    a.X, a.ldx, a.K0, a.rows, a.nseg, a.stream = x.data_ptr(), 256, 256, 32, 1, _lib.current_stream()
+    s = a.seg[0]
+    s.W, s.N, s.K, s.end_layer, s.nout, s.drop_site = w.data_ptr(), 256, 256, 1, 256, -1
+    assert lib.mmdeer_chain(C.byref(a)) == 0
+    s.K = 320                                              # not an instantiated depth
+    assert lib.mmdeer_chain(C.byref(a)) != 0 and b"chain" in lib.mmdeer_last_error()
+    s.K, s.N, s.nout = 256, 96, 96                         # N % 64
+    assert lib.mmdeer_chain(C.byref(a)) != 0
+    s.N, s.nout, s.res_add = 256, 256, 1                   # a bypass copy nobody wrote
+    assert lib.mmdeer_chain(C.byref(a)) != 0
+    s.res_add, a.samples_per_workgroup = 0, 24
+    assert lib.mmdeer_chain(C.byref(a)) != 0
+    torch.cuda.synchronize()
 
 
 def test_fused_train_step_graph_replay_trains_and_matches_eager():

@@ -1,5 +1,5 @@
 """Static check of csrc/chain.hip's weight ring (run after every change of the kernel; tests/test_cpu_host.py runs it):
-the ring lives in the top VGPRs of each wave, v[224:255] (16-sample kernel) / v[240:255] (32-sample kernel), which the register
+the ring lives in the top VGPRs of each wave, v[224:255] (16-sample kernel; v[192:255] in its 8-deep form) / v[240:255] (32-sample kernel), which the register
 allocator must never touch -- every instruction that names one of them has to come from the kernel's own inline asm, and the
 kernels must not use accumulation registers (an AGPR split would move the ring)."""
 import os
@@ -10,7 +10,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "uncertainty-aware-multimodal-emotion-recognition_amd", "csrc", "chain.hip")
-LIMITS = {"chain_kernel_s16": 224, "chain_kernel_s32": 240, "chain_kernel_s16_d2": 240}
+LIMITS = {"chain_kernel_s16": 224, "chain_kernel_s32": 240, "chain_kernel_s16_d2": 240, "chain_kernel_s16_d8": 192}
 
 
 def device_asm() -> str:
@@ -27,7 +27,7 @@ def check(asm: str):
     kernel, in_asm = None, False
     reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
     for ln, line in enumerate(asm.splitlines(), 1):
-        m = re.match(r"^(_ZN\S*?\d+(chain_kernel_s\d+(?:_d2)?)E\S*):", line)
+        m = re.match(r"^(_ZN\S*?\d+(chain_kernel_s\d+(?:_d\d)?)E\S*):", line)
         if m:
             kernel, in_asm = m.group(2), False
             seen[kernel] = 0

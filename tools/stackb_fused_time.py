@@ -14,6 +14,7 @@ from mmdeer.optim import FlatAdamW  # noqa: E402
 dev = torch.device("cuda:0")
 for B, dtype in ((4096, "bf16"), (256, "bf16"), (4096, "fp32")):
     m = stackb.CompleteDEERModel(stackb.ModelConfig(), compute_dtype=dtype).to(dev).train()
+    m.train_plan = os.environ.get("SB_PLAN", "auto")       # "ops": the launch-by-launch sequence instead of the layer chains
     b = synth.make_batch(B, seed=1)
     a, v, t, y = (torch.from_numpy(b[k]).to(dev) for k in ("audio", "video", "text", "targets"))
     opt = FlatAdamW(m, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0)

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """One steady-state train step from a rocprofv3 kernel trace: every launch in order with its duration, the gap to the
-previous kernel's end, grid and LDS.  usage: step_trace.py <kernel_trace.csv> [which-step-from-the-end]"""
+previous kernel's end, grid and LDS.  usage: step_trace.py <kernel_trace.csv> [which-step-from-the-end] [name of the step's last kernel]"""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last = [i for i, r in enumerate(rows) if "reduce_partials" in r["Kernel_Name"]]      # the step's final launch
+marker = sys.argv[3] if len(sys.argv) > 3 else "reduce_partials"
+last = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]      # the step's final launch
 s, e = last[-back - 1] + 1, last[-back] + 1
 prev, tot = None, 0.0
 for r in rows[s:e]:

@@ -117,10 +117,10 @@ class StackBAttnTrainArgs(C.Structure):
     _fields_ = [
         ("h2", c_void_p), ("pre", c_void_p), ("self_out", c_void_p), ("cross_out", c_void_p),
         ("est_w3", c_void_p), ("est_b3", c_void_p), ("wn_w1_unc", c_void_p), ("wn_w2", c_void_p), ("wn_b2", c_void_p),
-        ("out_av", c_void_p), ("out_text", c_void_p), ("r", c_void_p), ("weights4", c_void_p), ("unc4", c_void_p),
+        ("out_av", c_void_p), ("out_text", c_void_p), ("r", c_void_p), ("weights4", c_void_p), ("unc4", c_void_p), ("unc8", c_void_p),
         ("d_av", c_void_p), ("d_text", c_void_p), ("d_self", c_void_p), ("d_cross", c_void_p), ("d_pre", c_void_p),
         ("d_logits8", c_void_p), ("d_z8", c_void_p), ("d_h2", c_void_p),
-        ("ld_w1_unc", c_int), ("ld_av", c_int), ("ld_text", c_int), ("B", c_int), ("act_f32", c_int),
+        ("ld_w1_unc", c_int), ("ld_av", c_int), ("ld_text", c_int), ("B", c_int), ("act_f32", c_int), ("ld_dcross", c_int),
         ("training", c_int), ("drop_site", c_int), ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64),
         ("offset_dev", c_void_p), ("stream", c_void_p),
     ]
@@ -153,6 +153,38 @@ class StackBForwardArgs(C.Structure):
     ]
 
 
+class ChainSeg(C.Structure):
+    """mmdeer_chain_seg (include/mmdeer.h)."""
+    _fields_ = [
+        ("W", c_void_p), ("bias", c_void_p), ("N", c_int), ("K", c_int), ("kin_off", c_int), ("nout_off", c_int), ("relu", c_int),
+        ("drop_site", c_int), ("drop_shift", c_int), ("dcol_off", c_int),
+        ("mask_y", c_void_p), ("ld_mask", c_int), ("mask_col0", c_int), ("mask_scale", c_float),
+        ("res_add", c_int), ("res_dup", c_int), ("end_layer", c_int), ("nout", c_int),
+        ("stash", c_void_p), ("ld_stash", c_int), ("stash2", c_void_p), ("stash_split", c_int),
+        ("gamma", c_void_p), ("beta", c_void_p), ("xln", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("residual", c_int),
+        ("lnb_gamma", c_void_p), ("lnb_y", c_void_p), ("lnb_mean", c_void_p), ("lnb_rstd", c_void_p), ("lnb_dz", c_void_p),
+        ("lnb_partial", c_void_p), ("lnb_mask_scale", c_float),
+    ]
+
+
+CHAIN_MAX_SEGS = 12
+
+
+class ChainArgs(C.Structure):
+    """mmdeer_chain_args (include/mmdeer.h)."""
+    _fields_ = [
+        ("X", c_void_p), ("ldx", c_int), ("K0", c_int), ("rows", c_int), ("samples_per_workgroup", c_int), ("nseg", c_int),
+        ("dropout_p", c_float), ("seed", c_u64), ("offset", c_u64), ("offset_dev", c_void_p),
+        ("seg", ChainSeg * CHAIN_MAX_SEGS), ("debug", c_void_p), ("stream", c_void_p),
+    ]
+
+
+class RepackJob(C.Structure):
+    """mmdeer_repack_job (include/mmdeer.h)."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("ld_src", c_int), ("rows", c_int), ("cols", c_int), ("cols_valid", c_int),
+                ("transpose", c_int), ("layout", c_int), ("ld_dst", c_int), ("dst_col", c_int)]
+
+
 # every symbol include/mmdeer.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mmdeer_version", C.c_char_p, []),
@@ -172,6 +204,9 @@ SYMBOLS = [
     ("mmdeer_bucket_begin", c_ll, [c_int]),
     ("mmdeer_bucket_end", c_ll, [c_int]),
     ("mmdeer_gemm", c_int, [C.POINTER(GemmArgs)]),
+    ("mmdeer_chain", c_int, [C.POINTER(ChainArgs)]),
+    ("mmdeer_chain_workgroups", c_int, [c_int, c_int]),
+    ("mmdeer_repack", c_int, [C.POINTER(RepackJob), c_int, c_void_p]),
     ("mmdeer_gemm_batch_slab_elems", c_ll, [C.POINTER(GemmArgs), c_int]),
     ("mmdeer_gemm_batch", c_int, [C.POINTER(GemmArgs), c_int, c_void_p, c_ll, c_void_p]),
     ("mmdeer_adamw_flat", c_int, [C.POINTER(AdamWFlatArgs)]),
@@ -267,7 +302,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here == ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if lib.mmdeer_abi_version() != 14:   # MMDEER_ABI_VERSION of include/mmdeer.h
+        if lib.mmdeer_abi_version() != 15:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
         # The library itself reads no environment variable (include/mmdeer.h).  For the A/B tools the host forwards
         # MMDEER_<OPTION> (e.g. MMDEER_FUSED_ATTN=0) to mmdeer_set_option once, here.

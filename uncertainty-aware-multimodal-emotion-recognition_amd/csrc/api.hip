@@ -181,7 +181,7 @@ OptEntry g_opts[OPT_COUNT] = {
     {"glds", 1, 0, 1, {1}}, {"nt8", 1, 0, 1, {1}}, {"t128", 512, 1, 1 << 30, {512}}, {"tile", -1, -1, 4, {-1}}, {"ksteps", 0, 0, 4096, {0}},
     {"ln_fused", 1, 0, 1, {1}}, {"chain", 1, 0, 1, {1}}, {"chain_bwd", 1, 0, 1, {1}}, {"chain_min", 512, 1, 1 << 30, {512}},
     {"dw_tile", 2, 2, 4, {2}}, {"dw_kg", 2, 1, 2, {2}}, {"chain_max", 8192, 1, 1 << 30, {8192}}, {"chain_nig", 1, 0, 1, {1}},
-    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 4, {4}}, {"chain_ts", 0, 0, 32, {0}}, {"chain_in", 1, 0, 1, {1}}, {"chain_nigf", 0, 0, 1, {0}},
+    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 8, {4}}, {"chain_ts", 0, 0, 32, {0}}, {"chain_in", 1, 0, 1, {1}}, {"chain_nigf", 0, 0, 1, {0}},
 };
 }  // namespace
 
@@ -1479,6 +1479,63 @@ int mmdeer_dropout_mask(int site, int rows, int cols, float dropout_p, uint64_t 
   MMDEER_CHECK(out != nullptr, "dropout_mask: out is NULL");
   const DropCtx dc = make_drop(dropout_p, seed, offset);
   return launch_dropout_mask(dc, site, rows, cols, out, (hipStream_t)stream);
+}
+
+// The layer-chain kernel as an operator (include/mmdeer.h: mmdeer_chain): every row of the input is a sample.
+int mmdeer_chain(const mmdeer_chain_args* a) {
+  MMDEER_CHECK(a && a->nseg >= 1 && a->nseg <= MMDEER_CHAIN_MAX_SEGS, "mmdeer_chain: 1..%d segments", MMDEER_CHAIN_MAX_SEGS);
+  MMDEER_CHECK(a->rows >= 0, "mmdeer_chain: rows");
+  if (a->rows == 0) return 0;
+  MMDEER_CHECK(a->samples_per_workgroup == 0 || a->samples_per_workgroup == 16 || a->samples_per_workgroup == 32, "mmdeer_chain: samples_per_workgroup must be 0, 16 or 32");
+  ChainArgs c{};
+  c.X = reinterpret_cast<const bf16_t*>(a->X); c.ldx = a->ldx; c.K0 = a->K0; c.B = a->rows; c.groups = 1; c.group_stride = 0;
+  c.ts = a->samples_per_workgroup;
+  c.drop = make_drop(a->dropout_p, a->seed, a->offset, a->offset_dev);
+  c.nseg = a->nseg;
+  c.stamps = reinterpret_cast<unsigned long long*>(a->debug);
+  for (int i = 0; i < a->nseg; ++i) {
+    const mmdeer_chain_seg& s = a->seg[i];
+    ChainSeg& q = c.seg[i];
+    chain_seg_defaults(q);
+    q.W = reinterpret_cast<const bf16_t*>(s.W); q.bias = s.bias; q.N = s.N; q.K = s.K; q.ldw = s.K;
+    q.kin_off = s.kin_off; q.nout_off = s.nout_off; q.relu = s.relu;
+    q.drop_site = a->dropout_p > 0.f ? s.drop_site : -1; q.drop_shift = s.drop_shift; q.dcol_off = s.dcol_off;
+    q.mask_y = reinterpret_cast<const bf16_t*>(s.mask_y); q.ld_mask = s.ld_mask; q.mask_col0 = s.mask_col0; q.mask_scale = s.mask_scale;
+    q.res_add = s.res_add; q.res_dup = s.res_dup;
+    q.end_layer = s.end_layer;
+    if (s.end_layer) {
+      q.nout = s.nout; q.stash = reinterpret_cast<bf16_t*>(s.stash); q.ld_stash = s.ld_stash;
+      q.stash2 = reinterpret_cast<bf16_t*>(s.stash2); q.stash_split = s.stash_split;
+      q.gamma = s.gamma; q.beta = s.beta; q.xln = reinterpret_cast<bf16_t*>(s.xln); q.mean = s.mean; q.rstd = s.rstd; q.residual = s.residual;
+      q.lnb_gamma = s.lnb_gamma; q.lnb_y = reinterpret_cast<const bf16_t*>(s.lnb_y); q.lnb_mean = s.lnb_mean; q.lnb_rstd = s.lnb_rstd;
+      q.lnb_dz = reinterpret_cast<bf16_t*>(s.lnb_dz); q.lnb_partial = s.lnb_partial; q.lnb_mask_scale = s.lnb_mask_scale;
+    }
+  }
+  return launch_chain(c, (hipStream_t)a->stream);
+}
+
+int mmdeer_chain_workgroups(int rows, int samples_per_workgroup) {
+  ChainArgs c{};
+  c.B = rows; c.ts = samples_per_workgroup;
+  const int m = chain_samples_per_workgroup(c);
+  return (rows + m - 1) / m;
+}
+
+int mmdeer_repack(const mmdeer_repack_job* jobs, int n, void* stream) {
+  MMDEER_CHECK(n >= 0 && (n == 0 || jobs), "mmdeer_repack: jobs");
+  for (int base = 0; base < n; base += REPACK_MAX) {
+    RepackTable t{};
+    for (int j = base; j < n && j < base + REPACK_MAX; ++j) {
+      const mmdeer_repack_job& s = jobs[j];
+      RepackJob& J = t.job[t.njobs++];
+      J.src = reinterpret_cast<const bf16_t*>(s.src); J.dst = reinterpret_cast<bf16_t*>(s.dst);
+      J.ld_src = s.ld_src; J.rows = s.rows; J.cols = s.cols; J.cols_valid = s.cols_valid; J.transpose = s.transpose;
+      MMDEER_CHECK(s.layout == 0 || s.layout == 1, "mmdeer_repack: job %d layout", j);
+      J.layout = s.layout; J.ld_dst = s.ld_dst; J.dst_col = s.dst_col;
+    }
+    TRY(launch_repack(t, (hipStream_t)stream));
+  }
+  return 0;
 }
 
 int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream) {

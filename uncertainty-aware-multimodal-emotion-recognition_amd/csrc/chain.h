@@ -52,6 +52,13 @@ struct ChainSeg {
   bf16_t* lnb_dz;          // result rows [row][nout] (also the next layer's input panel)
   float* lnb_partial;      // [workgroup][2][nout] column sums of d * xhat and d (folded by reduce_partials)
   float lnb_mask_scale;    // > 0: the (y > 0) * scale mask of the Linear-ReLU-Dropout in front of the LayerNorm
+  // residual blocks (Stack B's encoders, reference complete_project.py:60-75: x + LayerNorm(Dropout(ReLU(Linear x)))):
+  int residual;            // end_layer with gamma: the finished LayerNorm rows get the layer's INPUT panel added (same width, same rows)
+  int res_add, res_dup;    // backward: res_add -- the epilogue adds columns [256 + n) of the input panel (the gradient that bypasses the
+                           // block); res_dup -- the result is also written at columns 256 + n of the output panel (the bypass copy for the
+                           // layer below; the LayerNorm backward at the layer end rewrites only columns [0, 256)).  256-wide layers.
+  bf16_t* stash2;          // end_layer, plain stash: columns >= stash_split go to stash2[row][ld_stash] (columns - stash_split) instead
+  int stash_split;         // multiple of 8; 0: everything to `stash`
 };
 
 // Backward chains only: the chain's input rows are not read but COMPUTED in the prologue -- the backward of the head's last layer
@@ -98,6 +105,7 @@ struct ChainArgs {
   const bf16_t* X;         // chain input [rows][ldx]
   int ldx, K0;             // leading dimension, width (<= 512, multiple of 64)
   int B;                   // samples
+  int ts;                  // 0: 16-sample workgroups up to B = 4096 and 32-sample ones above (chain_samples_per_workgroup); 16 / 32 force one
   int groups;              // 1, or 2: the input holds rows [0,B) and [group_stride, group_stride + B) of every sample block
   long long group_stride;  // rows between the groups
   int nseg;
@@ -119,6 +127,7 @@ inline int chain_samples_per_workgroup(int B) {
   return forced == 16 || forced == 32 ? forced : (B > 4096 ? 32 : 16);
 }
 inline int chain_workgroups(int B) { const int m = chain_samples_per_workgroup(B); return (B + m - 1) / m; }
+inline int chain_samples_per_workgroup(const struct ChainArgs& a);
 inline int chain_workgroups_max(int B) { return (B + 15) / 16; }     // whatever the option says: what per-workgroup buffers are sized for
 
 // Fragment-major weight images: what the chain kernel streams.  For a matrix W [N][K] (bf16, N % 16 == 0, K % 64 == 0) the 2 KiB
@@ -147,5 +156,6 @@ int launch_repack(RepackTable& t, hipStream_t s);
 void chain_seg_defaults(ChainSeg& s);
 // Validates shapes / alignment, derives the kernel's tables and enqueues the chain on `stream`.
 int launch_chain(const ChainArgs& a, hipStream_t stream);
+inline int chain_samples_per_workgroup(const ChainArgs& a) { return a.ts == 16 || a.ts == 32 ? a.ts : chain_samples_per_workgroup(a.B); }
 
 }  // namespace mmdeer

@@ -81,7 +81,7 @@ __device__ __forceinline__ void dma16(const void* src, void* dst) {
 // Slot S = v[248 - 8 S : 255 - 8 S]: two dwordx4 per lane = the two 32-wide k-chunks of the stage.
 template <int S>
 __device__ __forceinline__ void wr_issue(const void* p) {
-  static_assert(S >= 0 && S < 4, "ring slots 0..3");
+  static_assert(S >= 0 && S < 8, "ring slots 0..7");
   if constexpr (S == 0)
     asm volatile("global_load_dwordx4 v[248:251], %0, off\n\tglobal_load_dwordx4 v[252:255], %0, off offset:1024" ::"v"(p)
                  : "memory", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
@@ -91,9 +91,21 @@ __device__ __forceinline__ void wr_issue(const void* p) {
   else if constexpr (S == 2)
     asm volatile("global_load_dwordx4 v[232:235], %0, off\n\tglobal_load_dwordx4 v[236:239], %0, off offset:1024" ::"v"(p)
                  : "memory", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239");
-  else
+  else if constexpr (S == 3)
     asm volatile("global_load_dwordx4 v[224:227], %0, off\n\tglobal_load_dwordx4 v[228:231], %0, off offset:1024" ::"v"(p)
                  : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231");
+  else if constexpr (S == 4)
+    asm volatile("global_load_dwordx4 v[216:219], %0, off\n\tglobal_load_dwordx4 v[220:223], %0, off offset:1024" ::"v"(p)
+                 : "memory", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223");
+  else if constexpr (S == 5)
+    asm volatile("global_load_dwordx4 v[208:211], %0, off\n\tglobal_load_dwordx4 v[212:215], %0, off offset:1024" ::"v"(p)
+                 : "memory", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215");
+  else if constexpr (S == 6)
+    asm volatile("global_load_dwordx4 v[200:203], %0, off\n\tglobal_load_dwordx4 v[204:207], %0, off offset:1024" ::"v"(p)
+                 : "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207");
+  else
+    asm volatile("global_load_dwordx4 v[192:195], %0, off\n\tglobal_load_dwordx4 v[196:199], %0, off offset:1024" ::"v"(p)
+                 : "memory", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199");
 }
 // wait until at most N younger vector-memory operations are outstanding, then copy slot S into compiler-visible registers (s_nop: the
 // MFMAs that follow read what these VALU moves wrote, and the compiler's hazard recogniser does not look into the statement)
@@ -109,7 +121,11 @@ __device__ __forceinline__ void wr_take(u32x4& f0, u32x4& f1) {
   if constexpr (S == 0) CH_TAKE(248, 249, 250, 251, 252, 253, 254, 255);
   else if constexpr (S == 1) CH_TAKE(240, 241, 242, 243, 244, 245, 246, 247);
   else if constexpr (S == 2) CH_TAKE(232, 233, 234, 235, 236, 237, 238, 239);
-  else CH_TAKE(224, 225, 226, 227, 228, 229, 230, 231);
+  else if constexpr (S == 3) CH_TAKE(224, 225, 226, 227, 228, 229, 230, 231);
+  else if constexpr (S == 4) CH_TAKE(216, 217, 218, 219, 220, 221, 222, 223);
+  else if constexpr (S == 5) CH_TAKE(208, 209, 210, 211, 212, 213, 214, 215);
+  else if constexpr (S == 6) CH_TAKE(200, 201, 202, 203, 204, 205, 206, 207);
+  else CH_TAKE(192, 193, 194, 195, 196, 197, 198, 199);
 #undef CH_TAKE
   f0 = u32x4{r0, r1, r2, r3};
   f1 = u32x4{r4, r5, r6, r7};
@@ -143,8 +159,10 @@ struct ChainEndK {           // what happens to a finished panel; 80 bytes
   bf16_t* stash; bf16_t* xln; float* out32; float* mean; float* rstd;   // has_ln == 2 (LayerNorm backward): xln = dz, out32 = partial
   int ld_stash, nout, gb_off, has_ln;
   const bf16_t* lnb_y;       // LayerNorm backward: the forward's pre-LayerNorm rows
-  float lnb_mask_scale; int pad;
-  int pad2[2];
+  float lnb_mask_scale;
+  int res_split;             // bit 0: LayerNorm forward adds the layer's INPUT panel (x + LayerNorm(...): residual blocks); bits 4..: the
+                             // plain stash copy sends columns >= (res_split >> 4) to stash2 (0: everything to stash)
+  bf16_t* stash2;
 };
 struct ChainVecK {           // one bias / gamma / beta vector to stage into LDS; 16 bytes
   const float* src;
@@ -193,7 +211,7 @@ __device__ __forceinline__ float half_sum(float v, int lane) {
 // the 16-byte chunks l, l + 32 of its row.
 template <int NKT>
 __device__ __forceinline__ void chain_ln(unsigned char* pan, int img, int r, bool valid, long long grow, int lane, const float* vec,
-                                         const ChainLnOut& o_) {
+                                         const ChainLnOut& o_, const unsigned char* res) {
 #pragma clang fp contract(off)   // the same arithmetic, operation by operation, as the LayerNorm block of gemm_ln.hip
   constexpr int KD = NKT * 64, NC = NKT / 4;   // chunks per lane
   constexpr float inv_k = 1.0f / (float)KD;
@@ -240,7 +258,19 @@ __device__ __forceinline__ void chain_ln(unsigned char* pan, int img, int r, boo
     o[2] = (x[8 * j + 2] - mu) * rs * ga.z + ba.z; o[3] = (x[8 * j + 3] - mu) * rs * ga.w + ba.w;
     o[4] = (x[8 * j + 4] - mu) * rs * gb2.x + bb.x; o[5] = (x[8 * j + 5] - mu) * rs * gb2.y + bb.y;
     o[6] = (x[8 * j + 6] - mu) * rs * gb2.z + bb.z; o[7] = (x[8 * j + 7] - mu) * rs * gb2.w + bb.w;
-    const u32x4 packed{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+    u32x4 packed{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+    if (res) {
+      // residual block (reference complete_project.py:73, x + LayerNorm(...)): the layer's input panel has the geometry of this one;
+      // the sum is formed from the bf16-rounded LayerNorm output, as the separate launches do (layernorm_fwd, then add_masked)
+      const u32x4 h = *reinterpret_cast<const u32x4*>(res + (cell[j] - pan));
+      const unsigned pw[4] = {packed.x, packed.y, packed.z, packed.w}, hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = __uint_as_float(pw[e] << 16) + __uint_as_float(hw[e] << 16);
+        o[2 * e + 1] = __uint_as_float(pw[e] & 0xFFFF0000u) + __uint_as_float(hw[e] & 0xFFFF0000u);
+      }
+      packed = u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+    }
     *reinterpret_cast<u32x4*>(cell[j]) = packed;
     if (valid) {
       const long long col = grow * KD + c * 8;
@@ -520,6 +550,10 @@ __device__ __forceinline__ void chain_nig_tail(const ChainNigF& g, const unsigne
 template <int D, int VECF, int TS>
 __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   constexpr int MS = 16 * TS, LOG_MS = TS == 1 ? 4 : 5, FLY = 2 * D;   // FLY: weight loads of one wave in flight
+  // Tiles take a multiple of G stages.  D = 8: the ring is TWO granules of four slots -- a 256-wide layer (eight stages) is requested
+  // completely while the layer before it ends, where a four-deep ring restarted the stream after every layer end (stamps of Stack B's
+  // 256-wide encoder layers: 4.5k cycles for eight stages against 2.6k at the streaming rate) -- and a tile starts in slot 0 or 4.
+  constexpr int G = D == 8 ? 4 : D;
   // a panel: MS rows x 512 columns (or 2 MS x 256) of bf16; 16-sample workgroups: x 768, the width of the text block the input
   // chain starts from
   constexpr int PAN = TS == 1 ? MS * 1536 : MS * 1024;
@@ -640,7 +674,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     const u32x4 q0 = rec[0], q1 = rec[1];
     p_W = reinterpret_cast<const unsigned char*>(sp(q0.x, q0.y));
     p_nkt = sc(q0.w); p_ntiles = sc(q1.x); p_kb = sc(q1.y);
-    p_nv = (p_nkt + D - 1) / D * D;
+    p_nv = (p_nkt + G - 1) / G * G;
     p_nt = 0;
     p_tile();
   };
@@ -672,7 +706,11 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   p_load();
   issue(std::integral_constant<int, 0>{});
   issue(std::integral_constant<int, 1>{});
-  if constexpr (D == 4) { issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{}); }
+  if constexpr (D >= 4) { issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{}); }
+  if constexpr (D == 8) {
+    issue(std::integral_constant<int, 4>{}); issue(std::integral_constant<int, 5>{});
+    issue(std::integral_constant<int, 6>{}); issue(std::integral_constant<int, 7>{});
+  }
   // backward head chain: the input rows are computed while the vectors and the ring's first stages are in flight (its loads and
   // stores are younger than those: the counted waits below can only become stricter by them)
   if (nig_in) {
@@ -692,11 +730,14 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
 
   // One segment.  The activation fragments of its 16 (or 32) rows stay in REGISTERS for all its column tiles.
   // MB row blocks; KB: 64-column tiles (four column blocks), else 128 columns; NKT real stages per tile.
-  auto seg_body = [&](auto mbc, auto kbc, auto nktc, const SegCtl& sg) __attribute__((always_inline)) {
+  // H0 (D = 8 only): the granule of the ring the segment's first tile starts in; the return value is the granule the NEXT tile starts in.
+  auto seg_body = [&](auto mbc, auto kbc, auto nktc, auto h0c, const SegCtl& sg) __attribute__((always_inline)) -> int {
     constexpr int MB = decltype(mbc)::value;
     constexpr bool KB = decltype(kbc)::value;
     constexpr int NKT = decltype(nktc)::value;
-    constexpr int NV = (NKT + D - 1) / D * D;     // stages incl. padding: the tile ends in the ring slot it started in
+    constexpr int H0 = decltype(h0c)::value;
+    constexpr int NV = (NKT + G - 1) / G * G;     // stages incl. padding: a tile takes whole granules of the ring
+    constexpr bool FLIP = D == 8 && ((NV / G) & 1) != 0;      // a tile of an odd number of granules: the next one starts in the other half
     const bool active = !KB || wave < 4;          // 64-column tiles: four column blocks
     const int img_in = sg.in_aux ? MS * 128 : rows_in * 128, img_out = sg.rows_out * 128;
     // 16-sample workgroups: the fragments of ALL k stay in registers for the whole segment (64-96 VGPRs).  32-sample workgroups have
@@ -720,9 +761,14 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
         fr[kt & 1][1][i] = *reinterpret_cast<const u32x4*>(sa + kt * img_in + i * 2048 + swz1);
       }
     };
-    const int site = sg.site, shift = sg.shift, relu = sg.relu, fold = sg.fold, N = sg.N;
+    const int site = sg.site, shift = sg.shift, relu = sg.relu, fold = sg.fold & 15, N = sg.N;
+    // backward of a residual block: bit 4 -- add columns [256 + col) of the INPUT panel (the gradient that bypasses the block);
+    // bit 5 -- write the result a second time at columns 256 + col of the output panel (the next layer's bypass copy: the LayerNorm
+    // backward at the layer end rewrites columns [0, 256) in place)
+    const bool res_add = (sg.fold & 16) != 0, res_dup = (sg.fold & 32) != 0;
     const unsigned dkey = site >= 0 ? chain_drop_key(dseed, doff, site) : 0u;
-    for (int nti = 0; nti < sg.ntiles; ++nti) {
+    auto tile = [&](auto hc, int nti) __attribute__((always_inline)) {
+      constexpr int HS = decltype(hc)::value * G;             // ring slot of the tile's first stage
       const int nt = phys_tile(nti, sg.ntiles);
       f32x4 acc[MB];
 #pragma unroll
@@ -743,7 +789,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
       }
       auto stage = [&](auto ktc) __attribute__((always_inline)) {
         constexpr int kt = decltype(ktc)::value;
-        constexpr int S = kt % D;
+        constexpr int S = (HS + kt) % D;
         // this wave's stage has landed when at most FLY - 2 younger loads are outstanding; no barrier: a wave reads only what it
         // loaded itself
         if constexpr (kt < NKT) {
@@ -789,9 +835,9 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
         const f32x4 bias4 = sg.has_bias ? *reinterpret_cast<const f32x4*>(vec + sg.vec_off + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned dcol = (unsigned)(sg.dcol_off + n0);
         const int colb = sg.nout_off + n0;
-        if (mask_y) {      // the mask loads are older than this tile's 2 NV >= FLY weight loads, FLY of which are still in flight
+        if (mask_y) {      // the mask loads are older than the 2 NV weight loads this tile issued (FLY of which are still in flight when 2 NV >= FLY)
 #pragma unroll
-          for (int i = 0; i < MB; ++i) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(mk[i]) : "n"(FLY) : "memory");
+          for (int i = 0; i < MB; ++i) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(mk[i]) : "n"(2 * NV < FLY ? 2 * NV : FLY) : "memory");
         }
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
@@ -820,16 +866,36 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
           if (fold == 1) { col += (r >> LOG_MS) * N; orow = r & (MS - 1); }
           else if (fold == 2) { const int half = N >> 1, z = col >= half; col -= z * half; orow = r + z * MS; }
           else if (fold == 3) orow = r + MS;        // the segment's rows are row group 1 of the output panel
-          unsigned char* cell = pout + (col >> 6) * img_out + orow * 128 + ((((col & 63) >> 3) ^ (orow & 7)) * 16) + (col & 4) * 2;
-          *reinterpret_cast<u32x2*>(cell) = u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+          const int cell_off = (col >> 6) * img_out + orow * 128 + ((((col & 63) >> 3) ^ (orow & 7)) * 16) + (col & 4) * 2;
+          if (res_add) {
+            // the product is rounded to bf16 first, as the separate launches do (the dX GEMM stores bf16, add_masked adds)
+            const u32x2 h = *reinterpret_cast<const u32x2*>(pin + cell_off + 4 * img_out);      // same geometry: img_in == img_out
+            const unsigned p0 = pack_bf2(v.x, v.y), p1 = pack_bf2(v.z, v.w);
+            v.x = __uint_as_float(p0 << 16) + __uint_as_float(h.x << 16); v.y = __uint_as_float(p0 & 0xFFFF0000u) + __uint_as_float(h.x & 0xFFFF0000u);
+            v.z = __uint_as_float(p1 << 16) + __uint_as_float(h.y << 16); v.w = __uint_as_float(p1 & 0xFFFF0000u) + __uint_as_float(h.y & 0xFFFF0000u);
+          }
+          const u32x2 pk{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+          *reinterpret_cast<u32x2*>(pout + cell_off) = pk;
+          if (res_dup) *reinterpret_cast<u32x2*>(pout + cell_off + 4 * img_out) = pk;
         }
       }
+    };
+    if constexpr (!FLIP) {
+      for (int nti = 0; nti < sg.ntiles; ++nti) tile(std::integral_constant<int, H0>{}, nti);
+      return H0;
+    } else {
+      for (int nti = 0; nti < sg.ntiles; nti += 2) {
+        tile(std::integral_constant<int, H0>{}, nti);
+        if (nti + 1 < sg.ntiles) tile(std::integral_constant<int, 1 - H0>{}, nti + 1);
+      }
+      return (sg.ntiles & 1) ? 1 - H0 : H0;
     }
   };
 
   // The table record of a segment (its end part included) is requested while the segment BEFORE it winds down -- in front of the
   // layer end's barrier, where half the waves wait for the other half anyway -- and only converted to scalars here: read at the top
   // of the loop and again behind the barrier, the three dependent LDS round trips and their waits were ~1500 cycles per layer.
+  int half = 0;        // D = 8: the granule of the ring the next tile starts in
   u32x4 R[11];
   auto fetch_rec = [&](int si_) __attribute__((always_inline)) {
     const u32x4* rec = reinterpret_cast<const u32x4*>(tab + si_ * SEG_BYTES);
@@ -859,6 +925,8 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     const int gb_off = sc(e3.x), has_ln = endi >= 0 ? sc(e3.y) : 0;
     const bf16_t* const end_lnb_y = reinterpret_cast<const bf16_t*>(sp(e3.z, e3.w));
     const float lms = __uint_as_float((unsigned)sc(e4.x));
+    const int res_split = endi >= 0 ? sc(e4.y) : 0;
+    bf16_t* const stash2 = reinterpret_cast<bf16_t*>(sp(e4.z, e4.w));
     // a layer that ends in a LayerNorm backward: this lane's chunks of the forward's rows and the row statistics.
     // 16-sample workgroups request them NOW, before the segment's weight stages (>= D of them: FLY younger loads), and wait with
     // vmcnt(FLY) at the layer end; 32-sample workgroups have no registers to hold them across the segment (the compiler would spill
@@ -883,7 +951,8 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     };
     if (TS == 1 && has_ln == 2) lnb_fetch();
     stamp(3 + 3 * si);
-#define CH_SEG(MBv, KBv, NKTv) seg_body(std::integral_constant<int, MBv>{}, std::integral_constant<bool, KBv>{}, std::integral_constant<int, NKTv>{}, sg)
+#define CH_SEG1(MBv, KBv, NKTv, Hv) seg_body(std::integral_constant<int, MBv>{}, std::integral_constant<bool, KBv>{}, std::integral_constant<int, NKTv>{}, std::integral_constant<int, Hv>{}, sg)
+#define CH_SEG(MBv, KBv, NKTv) do { if constexpr (D == 8) { if (half) half = CH_SEG1(MBv, KBv, NKTv, 1); else half = CH_SEG1(MBv, KBv, NKTv, 0); } else CH_SEG1(MBv, KBv, NKTv, 0); } while (0)
     if (!kb) {
       if (mb == TS) {
         if (nkt == 8) CH_SEG(TS, false, 8); else if (nkt == 6) CH_SEG(TS, false, 6); else if (nkt == 4) CH_SEG(TS, false, 4);
@@ -897,6 +966,7 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
       else CH_SEG(2 * TS, true, 2);
     }
 #undef CH_SEG
+#undef CH_SEG1
     stamp(4 + 3 * si);
     fetch_rec(si + 1 < nseg ? si + 1 : 0);       // the next segment's record: lands while this layer ends
     if (endi >= 0) {
@@ -908,7 +978,11 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
       if (has_ln == 2) {
         stamp(100);
         if constexpr (TS == 1) {
-          asm volatile("s_waitcnt vmcnt(%4)" : "+v"(lnb[0].y[0]), "+v"(lnb[0].y[1]), "+v"(lnb[0].mu), "+v"(lnb[0].rs) : "n"(FLY) : "memory");
+          // the segment issued 2 x (its stages) loads behind the prefetch: FLY of them are in flight, or all 2 G of a one-granule segment
+          if (2 * sg.ntiles * ((nkt + G - 1) / G * G) >= FLY)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(lnb[0].y[0]), "+v"(lnb[0].y[1]), "+v"(lnb[0].mu), "+v"(lnb[0].rs) : "n"(FLY) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(lnb[0].y[0]), "+v"(lnb[0].y[1]), "+v"(lnb[0].mu), "+v"(lnb[0].rs) : "n"(2 * G) : "memory");
         } else {
           lnb_fetch();
 #pragma unroll
@@ -954,30 +1028,40 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
         }
         stamp(103);
       } else if (has_ln) {
+        const unsigned char* const ln_res = (res_split & 1) ? pin : nullptr;
         ChainLnOut o;
         o.stash = stash; o.xln = end_xln; o.out32 = end_out32;
         o.mean = end_mean; o.rstd = end_rstd;
         o.ld_stash = ld_stash; o.gb_off = gb_off;
         for (int r = 2 * wave + (lane >> 5); r < rows_out; r += 16) {
-          if (nout == 512) chain_ln<8>(pout, img_out, r, valid_of(r), grow_of(r), lane, vec, o);
-          else chain_ln<4>(pout, img_out, r, valid_of(r), grow_of(r), lane, vec, o);
+          if (nout == 512) chain_ln<8>(pout, img_out, r, valid_of(r), grow_of(r), lane, vec, o, ln_res);
+          else chain_ln<4>(pout, img_out, r, valid_of(r), grow_of(r), lane, vec, o, ln_res);
         }
       } else if (stash) {
         // a wave copies rows wave, wave + 8, ...: every LDS read first, then the stores (row by row the two dependent LDS round trips
         // were most of the copy's 1250 cycles)
         const int nch = nout >> 3;
+        const int split_ch = (res_split >> 4) ? (res_split >> 7) : nch;      // columns >= res_split >> 4 go to stash2
         constexpr int NR = 4 * TS;                        // rows per wave: at most 2 groups x MS / 8; a row is <= 64 chunks: one per lane
+        // panels wider than 512 columns (16-sample workgroups, one row group: 16 rows) have more than 64 chunks per row: the upper
+        // half of the slots then takes chunks 64.. of the wave's two rows instead of rows 16..31
+        const bool wide = TS == 1 && nch > 64;
         u32x4 raw[NR];
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
-          const int r = wave + 8 * q;
-          if (r < rows_out && lane < nch) raw[q] = *reinterpret_cast<const u32x4*>(pout + (lane >> 3) * img_out + r * 128 + (((lane & 7) ^ (r & 7)) * 16));
+          const int r = wide && q >= NR / 2 ? wave + 8 * (q - NR / 2) : wave + 8 * q;
+          const int c = wide && q >= NR / 2 ? lane + 64 : lane;
+          if (r < rows_out && c < nch) raw[q] = *reinterpret_cast<const u32x4*>(pout + (c >> 3) * img_out + r * 128 + (((c & 7) ^ (r & 7)) * 16));
         }
         stamp(132 + 4 * si);
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
-          const int r = wave + 8 * q;
-          if (r < rows_out && lane < nch && valid_of(r)) store_wt16(stash + grow_of(r) * ld_stash + lane * 8, raw[q]);
+          const int r = wide && q >= NR / 2 ? wave + 8 * (q - NR / 2) : wave + 8 * q;
+          const int c = wide && q >= NR / 2 ? lane + 64 : lane;
+          if (r < rows_out && c < nch && valid_of(r)) {
+            if (c < split_ch) store_wt16(stash + grow_of(r) * ld_stash + c * 8, raw[q]);
+            else store_wt16(stash2 + grow_of(r) * ld_stash + (c - split_ch) * 8, raw[q]);
+          }
         }
       }
       // A LayerNorm (forward or backward) rewrote the panel in place: everyone must see it before the next layer reads it.  A plain
@@ -1003,6 +1087,9 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
 // 16 samples per workgroup, four stages in flight (v[224:255]); 32 samples per workgroup, two stages (v[240:255]).
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(112))) void chain_kernel_s16(const ChainKArgs a) {
   chain_body<4, CHAIN_VEC_FLOATS, 1>(a);
+}
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void chain_kernel_s16_d8(const ChainKArgs a) {     // option chain_depth = 8
+  chain_body<8, CHAIN_VEC_FLOATS, 1>(a);
 }
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(120))) void chain_kernel_s32(const ChainKArgs a) {
   chain_body<2, CHAIN_VEC_FLOATS, 2>(a);
@@ -1101,7 +1188,9 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   }
   MMDEER_CHECK(a.B > 0, "chain: empty batch");
   MMDEER_CHECK(a.groups == 1 || a.groups == 2, "chain: groups must be 1 or 2");
-  const int ts = chain_samples_per_workgroup(a.B) / 16;       // 16-sample blocks per workgroup
+  const int msamp = chain_samples_per_workgroup(a);
+  const int ts = msamp / 16;                                  // 16-sample blocks per workgroup
+  const int nwg = (a.B + msamp - 1) / msamp;
   const int pan_cols = ts == 1 ? 768 : 512;                   // panel width of one row group (chain_body: PAN)
   MMDEER_CHECK(a.K0 % 64 == 0 && a.K0 * a.groups <= pan_cols, "chain: input width %d x %d groups does not fit the panel", a.K0, a.groups);
   if (a.aux_video) {
@@ -1126,7 +1215,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
   }
   int vec = 0, nend = 0, nvec = 0;
   int blocks_in = a.groups * ts, width_in = a.K0, layer_first_seg = 0;
-  bool layer_has_group1 = false;
+  bool layer_has_group1 = false, width_in_dup = false;     // width_in_dup: the input panel carries a bypass copy at columns [256, 512)
   auto add_vec = [&](const float* src, int n) { ChainVecK& v = k.vec[nvec++]; v.src = src; v.off = vec; v.n4 = n / 4; vec += n; return v.off; };
   for (int i = 0; i < a.nseg; ++i) {
     const ChainSeg& s = a.seg[i];
@@ -1153,6 +1242,11 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     td.W = s.W; td.in_aux = s.in_aux ? 1 : 0; td.nkt = nkt; td.ntiles = ntl; td.kindb = kb; td.end = -1;
     td.N = s.N; td.vec_off = vec_off; td.dcol_off = s.dcol_off; td.nout_off = s.nout_off;
     td.site = s.drop_site; td.shift = s.drop_shift; td.relu = s.relu; td.fold = s.row_group == 1 ? 3 : s.fold_groups;
+    if (s.res_add || s.res_dup) {
+      MMDEER_CHECK(td.fold == 0 && s.N == 256 && s.nout_off == 0 && blocks_in == ts && !s.in_aux, "chain: segment %d: residual epilogue on a 256-wide single-group layer only", i);
+      MMDEER_CHECK(!s.res_add || width_in_dup, "chain: segment %d adds a bypass copy the layer above did not write", i);
+      td.fold |= (s.res_add ? 16 : 0) | (s.res_dup ? 32 : 0);
+    }
     td.mblocks = mblocks; td.kin_off = s.kin_off;
     td.has_bias = s.bias != nullptr;
     td.mask_y = s.mask_y; td.ld_mask = s.ld_mask; td.mask_col0 = s.mask_col0; td.mask_scale = s.mask_scale;
@@ -1182,21 +1276,29 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
                          ((uintptr_t)s.xln % 16) == 0 && (!s.out32 || ((uintptr_t)s.out32 % 16) == 0),
                      "chain: LayerNorm of segment %d: pointers / alignment", i);
         e.has_ln = 1; e.xln = s.xln; e.out32 = s.out32; e.mean = s.mean; e.rstd = s.rstd;
+        MMDEER_CHECK(!s.residual || (blocks_out == blocks_in && s.nout == width_in), "chain: residual LayerNorm of segment %d: the layer must keep the panel's geometry", i);
+        e.res_split = s.residual ? 1 : 0;
         e.gb_off = add_vec(s.gamma, s.nout);
         add_vec(s.beta, s.nout);
+      }
+      else if (s.stash && s.stash_split) {
+        MMDEER_CHECK(s.stash2 && ((uintptr_t)s.stash2 % 16) == 0 && s.stash_split % 8 == 0 && s.stash_split > 0 && s.stash_split < s.nout,
+                     "chain: segment %d stash split", i);
+        e.res_split = s.stash_split << 4; e.stash2 = s.stash2;
       }
       td.end = nend++;
       for (int t = layer_first_seg; t <= i; ++t) k.rec[t].seg.rows_out = blocks_out * 16;   // every segment of the layer needs the output geometry
       layer_first_seg = i + 1;
-      blocks_in = blocks_out; width_in = s.nout;
+      blocks_in = blocks_out; width_in = s.nout; width_in_dup = s.res_dup != 0;
     }
   }
   MMDEER_CHECK(a.seg[a.nseg - 1].end_layer, "chain: the last segment must end its layer");
   MMDEER_CHECK(vec <= CHAIN_VEC_FLOATS, "chain: %d bias / gamma / beta floats exceed the LDS area (%d)", vec, CHAIN_VEC_FLOATS);
   k.nseg = a.nseg; k.nvec = nvec;
-  if (ts == 1 && opt(OPT_CHAIN_DEPTH) == 2) hipLaunchKernelGGL(chain_kernel_s16_d2, dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
-  else if (ts == 1) hipLaunchKernelGGL(chain_kernel_s16, dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
-  else hipLaunchKernelGGL(chain_kernel_s32, dim3(chain_workgroups(a.B)), dim3(512), 0, stream, k);
+  if (ts == 1 && opt(OPT_CHAIN_DEPTH) == 2) hipLaunchKernelGGL(chain_kernel_s16_d2, dim3(nwg), dim3(512), 0, stream, k);
+  else if (ts == 1 && opt(OPT_CHAIN_DEPTH) == 8) hipLaunchKernelGGL(chain_kernel_s16_d8, dim3(nwg), dim3(512), 0, stream, k);
+  else if (ts == 1) hipLaunchKernelGGL(chain_kernel_s16, dim3(nwg), dim3(512), 0, stream, k);
+  else hipLaunchKernelGGL(chain_kernel_s32, dim3(nwg), dim3(512), 0, stream, k);
   MMDEER_HIP(hipGetLastError());
   return 0;
 }

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_mix_train_fwd_kernel(const mmdeer_st
 }
 
 // backward of the above, one wave per sample.  Per-sample results only:
-//   d_self / d_cross [B][768] (modality m in columns 256 m ..), d_pre [B][256] (gradient at weight_network.0's output,
+//   d_self [B][768] / d_cross [3B][ld_dcross] (modality m of sample b in columns 256 m .. / in row 3 b + m), d_pre [B][256] (gradient at weight_network.0's output,
 //   ReLU / dropout mask applied), d_logits8 [B][8] (columns 0..2) and d_z8 [3B][8] (column 0: gradient at the
 //   estimator's last pre-sigmoid value) -- zero-padded to 8 columns = one 16-byte bf16 row, the narrowest operand the
 //   GEMM's vector loads take --, d_h2 [3B][64] (ReLU mask of the estimator's second layer applied).
@@ -110,8 +110,9 @@ __global__ __launch_bounds__(256) void attn_mix_bwd_kernel(const mmdeer_stackb_a
     dw[m] = wave_sum((g.x * s.x + g.y * s.y) + (g.z * s.z + g.w * s.w));
     du[m] = -wave_sum((g.x * c.x + g.y * c.y) + (g.z * c.z + g.w * c.w));
     tst4<F32>(a.d_self, (long long)b * 768 + m * 256 + col, g * w[m]);
-    tst4<F32>(a.d_cross, (long long)b * 768 + m * 256 + col, g * (1.f - u[m]));
+    tst4<F32>(a.d_cross, (long long)(3 * b + m) * (a.ld_dcross ? a.ld_dcross : 256) + col, g * (1.f - u[m]));
   }
+  if (a.unc8 && lane < 2) tst4<F32>(a.unc8, 8ll * b + 4 * lane, lane == 0 ? f32x4{u[0], u[1], u[2], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f});
   // softmax over the three modalities
   const float dot = dw[0] * w[0] + dw[1] * w[1] + dw[2] * w[2];
   float dl[3];
@@ -225,6 +226,7 @@ int check_attn(const mmdeer_stackb_attn_train_args* p, bool bwd) {
                "stackb_attn_mix_train: bad leading dimension (w1 %d, av %d, text %d)", p->ld_w1_unc, p->ld_av, p->ld_text);
   if (!bwd) MMDEER_CHECK(p->pre && p->out_av && p->out_text, "stackb_attn_mix_train_fwd: NULL pointer");
   else MMDEER_CHECK(p->d_av && p->d_text && p->d_self && p->d_cross && p->d_pre && p->d_logits8 && p->d_z8 && p->d_h2, "stackb_attn_mix_bwd: NULL pointer");
+  MMDEER_CHECK(p->ld_dcross == 0 || (p->ld_dcross >= 256 && p->ld_dcross % 4 == 0), "stackb_attn_mix: ld_dcross %d", p->ld_dcross);
   return 0;
 }
 

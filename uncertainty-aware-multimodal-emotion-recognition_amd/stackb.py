@@ -411,6 +411,10 @@ class CompleteDEERModel(nn.Module):
         st = {"dev": dev, "offs": offs, "n": cur, "p": flat_p, "g": flat_g, "packed": packed, "by_id": by_id, "gview": gview,
               "ptrs": [p.data_ptr() for _, p in named], "versions": None, "names": [n for n, _ in named],
               "packed_t": packed_t, "extra_t": extra, "ttab": tt}
+        st["frag"] = None
+        if not f32:
+            from . import stackb_train
+            st["frag"] = stackb_train.build_frag_images(self, st)
         self._flat_state = st
         self._packed = None
         return st
@@ -432,6 +436,8 @@ class CompleteDEERModel(nn.Module):
         t = st["ttab"]
         _lib.check(_lib.load().mmdeer_pack_transposed_batch(t["n"], t["src"], t["rows"], t["cols"], st["packed_t"].data_ptr(), t["off"], t["ld"],
                                                             t["col"], int(st["packed"] is st["p"]), _lib.current_stream()))
+        if st.get("frag") is not None:       # bf16: the fragment-major images the layer chains stream (stackb_train.py), from the copies above
+            st["frag"].refresh()
 
     def train_step_fused(self, audio, video, text, targets) -> Dict[str, torch.Tensor]:
         """forward (dropout live) + ``MultiTaskDEERLoss`` + backward as library launches only: the same operator sequence as
@@ -450,7 +456,20 @@ class CompleteDEERModel(nn.Module):
         # bf16 compute: the feature blocks are rounded to bf16 once here (the GEMM loaders would round them on the fly anyway)
         # so that the input-projection weight gradients run on the LDS-DMA kernel with the rest of their group
         xdt = torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
-        xs = [x.detach().to(xdt).contiguous() for x in xs]
+        lean = st.get("frag") is not None and getattr(self, "train_plan", "auto") != "ops"
+        xs = [x.detach() if (lean and x.shape[1] % 64) else x.detach().to(xdt).contiguous() for x in xs]
+        if lean:
+            # layer-chain plan: rows of a width the chain's DMA cannot take (the 84-wide audio block) live in a persistent buffer
+            # zero-padded to a multiple of 64 columns -- one converting copy per step, and the input projection's weight gradient
+            # reads 16-byte aligned rows
+            for i, x in enumerate(xs):
+                K0 = (x.shape[1] + 63) // 64 * 64
+                if K0 != x.shape[1]:
+                    pad = st.get(("xpad", i))
+                    if pad is None or pad.shape[0] != B:
+                        pad = st[("xpad", i)] = torch.zeros(B, K0, dtype=xdt, device=dev)
+                    pad[:, :x.shape[1]].copy_((audio, video, text)[i].detach())
+                    xs[i] = pad[:, :x.shape[1]]
         if getattr(self, "_in_graph_step", False):
             drop = (self.config.dropout, int(self.config.dropout_seed), 0, self._drop_counter)
         else:
