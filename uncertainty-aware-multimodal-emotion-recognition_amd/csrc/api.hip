@@ -1232,9 +1232,13 @@ int batch_splitk(int K, int f32, int boost) {
   return sk < 1 ? 1 : sk;
 }
 int batch_boost(const mmdeer_gemm_args* a, int n, int f32) {
+  // tiles of the kernel that will run: 128 x 128 for the bf16 weight-gradient DMA kernel (option dw_tile = 2, the default), else 256 x 256
+  // (the estimate counted 256 x 256 tiles after the kernel had moved to 128 x 128: groups of 256 x 256 matrices were split four times
+  // too fine -- 590-640 workgroups and 38 MB of slabs per group of Stack B's step)
+  const int t = (!f32 && opt(OPT_DW_TILE) == 2) ? 128 : 256;
   long long wgs = 0;
   for (int i = 0; i < n; ++i)
-    wgs += (long long)((a[i].M + 255) / 256) * ((a[i].N + 255) / 256) * batch_splitk(a[i].K, f32, 1);
+    wgs += (long long)((a[i].M + t - 1) / t) * ((a[i].N + t - 1) / t) * batch_splitk(a[i].K, f32, 1);
   int boost = 1;
   while (boost < 4 && wgs * boost * 2 <= 256) boost *= 2;
   return boost;
