@@ -211,6 +211,46 @@ def test_fused_adamw_matches_torch_adamw_with_clipping():
     assert torch.allclose(out1["mu_all"], out2["mu_all"], rtol=1e-4, atol=1e-5)
 
 
+def test_fused_adamw_writes_every_weight_image_itself():
+    """in bf16 mode the optimiser step's update kernel writes every derived weight image (row-major packed copy,
+    fragment-major W / W^T, row-major W^T, head-major in_proj, padded audio projection) tile by tile -- byte for byte what the
+    element-wise update followed by the repack launch (option adam_fused = 0) leaves in the weights buffer, with the same
+    parameters and moments."""
+    import copy
+
+    from mmdeer import _lib
+    from mmdeer.model import ModelConfig, MultimodalDEER
+    from mmdeer.optim import FusedAdamW
+
+    m1 = MultimodalDEER(ModelConfig(compute_dtype="bf16", seed=4)).to("cuda:0").train()
+    m2 = copy.deepcopy(m1)
+    b = synth.make_batch(640, seed=6)
+    a, v, t, y = (torch.from_numpy(b[k]).to("cuda:0") for k in ("audio", "video", "text", "targets"))
+    o1 = FusedAdamW(m1, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    o2 = FusedAdamW(m2, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    for m in (m1, m2):                    # alignment gaps of the buffer are never written: give them the same bytes
+        m._weights(torch.device("cuda:0")).zero_()
+        m._st.packed_key = None           # ... and pack again at the first step
+    for step in range(2):
+        m1._step = m2._step = 20 + step
+        l1 = m1.train_step(a, v, t, y)
+        l2 = m2.train_step(a, v, t, y)
+        assert float(l1["total_loss"]) == float(l2["total_loss"])
+        with _lib.options(adam_fused=1):
+            o1.step()
+        with _lib.options(adam_fused=0):
+            o2.step()
+        torch.cuda.synchronize()
+        for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert torch.equal(p1, p2), (step, n)
+        w1, w2 = m1._weights(torch.device("cuda:0")), m2._weights(torch.device("cuda:0"))
+        lib = _lib.load()
+        for name in (b"wpack", b"wtpack", b"vpack", b"wa_pad", b"wqkv_hm", b"wfpack", b"wtfpack"):
+            lo = lib.mmdeer_weights_offset(0, name)
+            assert lo >= 0
+        assert torch.equal(w1, w2), (step, int((w1 != w2).sum()))
+
+
 @pytest.mark.parametrize("n", [96, 100])
 def test_trainer_graph_mode_matches_eager_mode(tmp_path, n):
     """DEERTrainer with use_graph=True (captured train_step + FusedAdamW) follows the same trajectory as the eager

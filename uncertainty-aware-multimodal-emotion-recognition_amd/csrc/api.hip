@@ -181,7 +181,7 @@ OptEntry g_opts[OPT_COUNT] = {
     {"glds", 1, 0, 1, {1}}, {"nt8", 1, 0, 1, {1}}, {"t128", 512, 1, 1 << 30, {512}}, {"tile", -1, -1, 4, {-1}}, {"ksteps", 0, 0, 4096, {0}},
     {"ln_fused", 1, 0, 1, {1}}, {"chain", 1, 0, 1, {1}}, {"chain_bwd", 1, 0, 1, {1}}, {"chain_min", 512, 1, 1 << 30, {512}},
     {"dw_tile", 2, 2, 4, {2}}, {"dw_kg", 2, 1, 2, {2}}, {"chain_max", 8192, 1, 1 << 30, {8192}}, {"chain_nig", 1, 0, 1, {1}},
-    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 8, {4}}, {"chain_ts", 0, 0, 32, {0}}, {"chain_in", 1, 0, 1, {1}}, {"chain_nigf", 0, 0, 1, {0}},
+    {"splitk_max", 8, 1, 8, {8}}, {"chain_depth", 4, 2, 8, {4}}, {"chain_ts", 0, 0, 32, {0}}, {"chain_in", 1, 0, 1, {1}}, {"chain_nigf", 0, 0, 1, {0}}, {"adam_fused", 1, 0, 1, {1}},
 };
 }  // namespace
 
@@ -1152,6 +1152,63 @@ int mmdeer_adamw_step(const mmdeer_adamw_args* a) {
   t.bias_corr1 = 1.f - powf(a->beta1, (float)a->step);
   t.bias_corr2 = 1.f - powf(a->beta2, (float)a->step);
   t.max_norm = a->max_grad_norm; t.grad_scale = a->grad_scale;
+  if (!f32 && opt(OPT_ADAM_FUSED)) {
+    // bf16 mode: the update writes every derived weight image itself (optim.h: AdamImaged) -- the table below restates repack_images
+    // per matrix; what is left for the element-wise part are the vectors and the three 4 x 64 last head layers
+    AdamImagedTable im{};
+    im.base = reinterpret_cast<bf16_t*>(a->weights);
+    const bool wt_on = a->pack_transposed != 0;
+    auto rel = [&](const char* base, long long elem) { return (int)((reinterpret_cast<const bf16_t*>(base) - im.base) + elem); };
+    auto add = [&](int pid, int row0, int rows) -> AdamImaged& {
+      AdamImaged& M = im.m[im.n++];
+      const int cols = kParams[pid].cols;
+      M.param = t.param[pid] + (long long)row0 * cols; M.off = kParams[pid].off + (long long)row0 * cols;
+      M.rows = rows; M.cols = cols; M.cols_pad = (cols + 63) / 64 * 64; M.lr = a->lr[pid];
+      M.frag = M.fragT = M.wt = M.rowpad = M.hm = -1;
+      return M;
+    };
+    auto o = [&](int pid) { return (long long)kParams[pid].off; };
+    // whole matrices [N][K] with the usual set: frag(W) (forward chains), W^T row-major + frag(W^T) (backward)
+    auto plain = [&](int pid, bool frag, bool fragT, bool wt) {
+      const int N = kParams[pid].rows, K = kParams[pid].cols;
+      AdamImaged& M = add(pid, 0, N);
+      if (frag) { M.frag = rel(L.wfpack, o(pid)); M.frag_nkt = K / 64; M.frag_row0 = 0; }
+      if (fragT && wt_on) { M.fragT = rel(L.wtfpack, o(pid)); M.fragT_nkt = N / 64; M.fragT_col0 = 0; }
+      if (wt && wt_on) { M.wt = rel(L.wtpack, o(pid)); M.wt_ld = N; M.wt_col0 = 0; }
+    };
+    { AdamImaged& M = add(P_AUD_W, 0, INTER);      // [256][84]: zero-padded row-major copy + its fragment-major image (K = 128)
+      M.rowpad = rel(L.wa_pad, 0); M.rowpad_ld = AUD_PAD; M.frag = rel(L.wa_frag, 0); M.frag_nkt = AUD_PAD / 64; M.frag_row0 = 0; }
+    plain(P_VID_W, true, false, false);
+    { AdamImaged& M = add(P_AIN_W, 0, 2 * INTER);  // query / key rows of the AV in_proj: only the W^T copy
+      if (wt_on) { M.wt = rel(L.wtpack, o(P_AIN_W)); M.wt_ld = 3 * INTER; M.wt_col0 = 0; } }
+    { AdamImaged& M = add(P_AIN_W, 2 * INTER, INTER);   // its value rows: the matrix the chains multiply by
+      const long long sub = (long long)2 * INTER * INTER;
+      M.frag = rel(L.wfpack, o(P_AIN_W) + sub); M.frag_nkt = INTER / 64; M.frag_row0 = 0;
+      if (wt_on) { M.fragT = rel(L.wtfpack, o(P_AIN_W) + sub); M.fragT_nkt = INTER / 64; M.fragT_col0 = 0;
+                   M.wt = rel(L.wtpack, o(P_AIN_W)); M.wt_ld = 3 * INTER; M.wt_col0 = 2 * INTER; } }
+    plain(P_AOUT_W, true, true, true); plain(P_AVF_W, true, true, true); plain(P_AVP_W, true, true, true);
+    plain(P_TXT_W, true, false, false);
+    { AdamImaged& M = add(P_TIN_W, 0, 3 * FUS);    // trimodal in_proj: head-major rows (tri_fused.hip) + W^T (the in_proj dX GEMM)
+      M.hm = rel(L.wqkv_hm, 0); M.hm_row0 = 0;
+      if (wt_on) { M.wt = rel(L.wtpack, o(P_TIN_W)); M.wt_ld = 3 * FUS; M.wt_col0 = 0; } }
+    plain(P_TOUT_W, true, true, true); plain(P_TFF_W, true, true, true); plain(P_OP_W, true, true, true);
+    plain(P_FP0_W, true, true, true); plain(P_FP1_W, true, true, true);
+    for (int z = 0; z < 3; ++z) {                  // first head layers: rows [128 z, 128 z + 128) of the stacked [384][256] matrix
+      AdamImaged& M = add(P_EV0_W + z, 0, EV1);
+      M.frag = rel(L.wfpack, o(P_EV0_W)); M.frag_nkt = HID / 64; M.frag_row0 = z * EV1;
+      if (wt_on) { M.fragT = rel(L.wtfpack, o(P_EV0_W)); M.fragT_nkt = 3 * EV1 / 64; M.fragT_col0 = z * EV1;
+                   M.wt = rel(L.wtpack, o(P_EV0_W)); M.wt_ld = 3 * EV1; M.wt_col0 = z * EV1; }
+    }
+    for (int z = 0; z < 3; ++z) plain(P_EV1_W + z, true, true, true);      // second head layers [64][128], each on its own
+    AdamTable te = t;
+    te.nseg = 0;
+    for (int i = 0; i < MMDEER_NUM_PARAMS; ++i) {
+      if (kParams[i].is_matrix && i < P_EV2_W) continue;
+      const int k = te.nseg++;
+      te.param[k] = t.param[i]; te.off[k] = t.off[i]; te.n[k] = t.n[i]; te.is_vec[k] = t.is_vec[i]; te.lr[k] = t.lr[i];
+    }
+    return launch_adamw_pack_images(te, im, reinterpret_cast<bf16_t*>(L.wpack), L.vpack, s);
+  }
   TRY(launch_adamw_pack(t, L.wpack, f32, L.vpack, s));
   const void* const* cparams = const_cast<const void* const*>(a->params);
   if (f32) { if (a->pack_transposed) TRY(pack_transposed_weights(cparams, L, f32, s)); }

@@ -35,6 +35,8 @@ enum OptId {
                         // forward head chain instead of a launch of its own.  Bit-identical, one launch fewer -- and measured 6 us
                         // SLOWER per step at B = 4096: the 256 wave partials cost the backward chain's prologue 8k cycles more to
                         // fetch than the 64 block partials, the tail itself 5k
+  OPT_ADAM_FUSED,       // 1 (bf16 mode): mmdeer_adamw_step writes every derived weight image from the update itself, tile by tile (optim.h);
+                        // 0: element-wise update + one repack launch
   OPT_COUNT
 };
 
