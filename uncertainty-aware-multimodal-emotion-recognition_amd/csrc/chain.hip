@@ -596,6 +596,15 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   auto grow_of = [&](int r) -> long long { return (long long)(r >> LOG_MS) * gstride + row0 + (r & (MS - 1)); };
   auto valid_of = [&](int r) -> bool { return row0 + (r & (MS - 1)) < B; };
 
+  // ---- the tables: requested FIRST and only written to LDS behind the counted wait at the end of the prologue (an untracked load, one
+  // 16-byte piece per thread) -- the prologue used to be three serial cold fetches (tables -> barrier -> vectors / first weight stages ->
+  // barrier -> first record); what the requests below need of the tables they read from the kernel-argument segment with scalar loads
+  const auto& KA = *(const __attribute__((address_space(4))) ChainKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  u32x4 tabv{0u, 0u, 0u, 0u};
+  if (tid < TAB_BYTES / 16) {
+    const unsigned char* src = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ChainKArgs, rec) + 16 * tid;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tabv) : "v"(src) : "memory");
+  }
   // ---- input panel
   int rows_in = a.groups * MS;
   const bool nig_in = a.nig.enabled != 0;      // the input rows are computed below (the head's last-layer backward), not read
@@ -619,29 +628,10 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
       const long long gr = valid_of(r) ? grow_of(r) : 0;
       dma16(a.aux_video + gr * a.aux_ldv + image * 64 + kchunk, lds + AUX + image * (MS * 128) + g8 * 1024);
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = tid + 512 * q, r = e >> 6, dw = e & 63;
-      unsigned v = 0u;
-      if (dw * 2 < a.aux_lda && valid_of(r)) v = *reinterpret_cast<const unsigned*>(a.aux_audio + grow_of(r) * a.aux_lda + 2 * dw);
-      const int chunk = dw >> 2;
-      *reinterpret_cast<unsigned*>(lds + AUX + (4 + (chunk >> 3)) * (MS * 128) + r * 128 + (((chunk & 7) ^ (r & 7)) * 16) + (dw & 3) * 4) = v;
-    }
   }
-  // ---- the tables into LDS: one parallel vector load
-  {
-    const unsigned char* src = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ChainKArgs, rec);
-    if (tid < TAB_BYTES / 16) *reinterpret_cast<u32x4*>(lds + TAB + 16 * tid) = *reinterpret_cast<const u32x4*>(src + 16 * tid);
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
   stamp(1);
-  if (has_aux && tid < 256) {       // the padded audio rows of this workgroup -> [B][128] (what pad_cols wrote as a launch of its own)
-    const int r = tid >> 4, c = tid & 15;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(lds + AUX + (4 + (c >> 3)) * (MS * 128) + r * 128 + (((c & 7) ^ (r & 7)) * 16));
-    if (valid_of(r)) store_wt16(a.aux_audio_pad + grow_of(r) * 128 + c * 8, v);
-  }
   const unsigned char* const tab = lds + TAB;
+  bool tab_ready = false;          // the tables are in LDS (from the end of the prologue on)
   auto sc = [](unsigned v) -> int { return __builtin_amdgcn_readfirstlane((int)v); };
   auto sp = [](unsigned lo, unsigned hi) -> unsigned long long {
     return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
@@ -670,10 +660,16 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     p_cur = p_W + ((long long)wt * p_nkt) * 2048 + lane * 16;
   };
   auto p_load = [&]() __attribute__((always_inline)) {
-    const u32x4* rec = reinterpret_cast<const u32x4*>(tab + p_si * SEG_BYTES);
-    const u32x4 q0 = rec[0], q1 = rec[1];
-    p_W = reinterpret_cast<const unsigned char*>(sp(q0.x, q0.y));
-    p_nkt = sc(q0.w); p_ntiles = sc(q1.x); p_kb = sc(q1.y);
+    if (tab_ready) {
+      const u32x4* rec = reinterpret_cast<const u32x4*>(tab + p_si * SEG_BYTES);
+      const u32x4 q0 = rec[0], q1 = rec[1];
+      p_W = reinterpret_cast<const unsigned char*>(sp(q0.x, q0.y));
+      p_nkt = sc(q0.w); p_ntiles = sc(q1.x); p_kb = sc(q1.y);
+    } else {          // prologue: scalar loads from the kernel arguments (a round trip of its own, but only the first record -- or two, when the
+      const auto& sk = KA.rec[p_si].seg;       // first segment is a single tile of one granule -- is read this way)
+      p_W = reinterpret_cast<const unsigned char*>(sk.W);
+      p_nkt = sk.nkt; p_ntiles = sk.ntiles; p_kb = sk.kindb;
+    }
     p_nv = (p_nkt + G - 1) / G * G;
     p_nt = 0;
     p_tile();
@@ -694,10 +690,9 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
   // ---- every bias / gamma / beta of the chain into LDS by DMA (vector e is wave e % 8's job); BEFORE the ring's first
   //      stages, so that the wait below can leave those in flight
   for (int e = wave; e < nvec; e += 8) {
-    const u32x4 q = *reinterpret_cast<const u32x4*>(tab + VEC0 + e * 16);
-    const float* src = reinterpret_cast<const float*>(sp(q.x, q.y));
-    unsigned char* dst = lds + VEC + sc(q.z) * 4;
-    const int n4 = sc(q.w);
+    const float* src = KA.vec[e].src;
+    unsigned char* dst = lds + VEC + KA.vec[e].off * 4;
+    const int n4 = KA.vec[e].n4;
     for (int j = 0; j * 64 < n4; ++j) {
       if (src) { if (j * 64 + lane < n4) dma16(src + 4 * (j * 64 + lane), dst + j * 1024); }
       else if (j * 64 + lane < n4) *reinterpret_cast<f32x4*>(dst + j * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -711,15 +706,33 @@ __device__ __forceinline__ void chain_body(const ChainKArgs& a) {
     issue(std::integral_constant<int, 4>{}); issue(std::integral_constant<int, 5>{});
     issue(std::integral_constant<int, 6>{}); issue(std::integral_constant<int, 7>{});
   }
+  if (has_aux) {       // the raw audio rows (tracked dword loads: the compiler waits for everything requested so far before it stores them to LDS)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + 512 * q, r = e >> 6, dw = e & 63;
+      unsigned v = 0u;
+      if (dw * 2 < a.aux_lda && valid_of(r)) v = *reinterpret_cast<const unsigned*>(a.aux_audio + grow_of(r) * a.aux_lda + 2 * dw);
+      const int chunk = dw >> 2;
+      *reinterpret_cast<unsigned*>(lds + AUX + (4 + (chunk >> 3)) * (MS * 128) + r * 128 + (((chunk & 7) ^ (r & 7)) * 16) + (dw & 3) * 4) = v;
+    }
+  }
   // backward head chain: the input rows are computed while the vectors and the ring's first stages are in flight (its loads and
   // stores are younger than those: the counted waits below can only become stricter by them)
   if (nig_in) {
     chain_nig_head<MS>(a.nig, lds, reinterpret_cast<float*>(lds + PAN), row0, B, tid, a.stamps);
     stamp(115);
   }
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FLY) : "memory");   // the vectors (and anything older) have landed; the ring's
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tabv) : "n"(FLY) : "memory");   // the tables, the input rows, the vectors (anything older than the ring's first stages) have landed
+  if (tid < TAB_BYTES / 16) *reinterpret_cast<u32x4*>(lds + TAB + 16 * tid) = tabv;
+  tab_ready = true;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // the ring's
   __builtin_amdgcn_s_barrier();                                           // first stages are waited for stage by stage in the loop
   stamp(2);
+  if (has_aux && tid < 256) {       // the padded audio rows of this workgroup -> [B][128] (what pad_cols wrote as a launch of its own)
+    const int r = tid >> 4, c = tid & 15;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(lds + AUX + (4 + (c >> 3)) * (MS * 128) + r * 128 + (((c & 7) ^ (r & 7)) * 16));
+    if (valid_of(r)) store_wt16(a.aux_audio_pad + grow_of(r) * 128 + c * 8, v);
+  }
 
   // ---- the chain
   unsigned char* pin = lds;
