@@ -1282,16 +1282,40 @@ namespace {
 // group is 16 matrices of 256 x 256 = 16 tiles; at the default 4 slices that is 64 workgroups, each a chain of 32 K-steps)
 constexpr int BATCH_SPLITK_MAX = 16;
 int batch_splitk(int K, int f32, int boost) {
-  const int nk = gemm_ktiles(K, f32), kst = ksteps_target(f32);
-  int sk = ((nk + kst - 1) / kst) * boost;
+  const int nk = gemm_ktiles(K, f32);
+  int sk;
+  if (boost < 0) sk = (nk + (-boost) - 1) / (-boost);      // boost = -L: slices of at most L K-tiles (batch_boost's search below)
+  else { const int kst = ksteps_target(f32); sk = ((nk + kst - 1) / kst) * boost; }
   if (sk > BATCH_SPLITK_MAX) sk = BATCH_SPLITK_MAX;
   if (sk > nk / 2) sk = nk / 2;          // at least two K-tiles per slice
   return sk < 1 ? 1 : sk;
 }
+// The split of one group of problems.  bf16 weight-gradient DMA kernel (128 x 128 tiles, the default): the slice length L (in 64-row
+// K-tiles) that minimises a cost model of the group -- rounds of 256 workgroups x (the longest slice at 0.62 us per K-tile per workgroup +
+// a fixed 4 us) + the fold of the slabs (two passes over 64 KiB per slice tile at ~3 TB/s, + 4 us if anything is folded) -- returned as
+// -L.  (Round 4 before this: a fixed 16 K-tiles per slice, times a boost that counted 256 x 256 tiles: Stack B's first group of 16
+// matrices ran as 592 workgroups in three rounds + a 17 us fold, 68 us, where 148 unsplit workgroups take one round of ~43 us.)
+// Other kernels: slices of ksteps_target K-tiles, times `boost` when the group would leave most of the chip idle.
 int batch_boost(const mmdeer_gemm_args* a, int n, int f32) {
-  // tiles of the kernel that will run: 128 x 128 for the bf16 weight-gradient DMA kernel (option dw_tile = 2, the default), else 256 x 256
-  // (the estimate counted 256 x 256 tiles after the kernel had moved to 128 x 128: groups of 256 x 256 matrices were split four times
-  // too fine -- 590-640 workgroups and 38 MB of slabs per group of Stack B's step)
+  if (!f32 && opt(OPT_DW_TILE) == 2 && opt(OPT_KSTEPS) == 0) {
+    int bestL = 16;
+    double best = 1e30;
+    for (int L = 8; L <= 256; L += (L < 32 ? 8 : L < 64 ? 16 : 32)) {
+      long long wgs = 0, slab_tiles = 0;
+      int longest = 0;
+      for (int i = 0; i < n; ++i) {
+        const long long tiles = (long long)((a[i].M + 127) / 128) * ((a[i].N + 127) / 128);
+        const int nk = gemm_ktiles(a[i].K, f32), sk = batch_splitk(a[i].K, f32, -L), len = (nk + sk - 1) / sk;
+        wgs += tiles * sk;
+        if (sk > 1) slab_tiles += tiles * sk;
+        if (len > longest) longest = len;
+      }
+      const double cost = (double)((wgs + 255) / 256) * (longest * 0.62 + 4.0) + (slab_tiles ? slab_tiles * 0.044 + 4.0 : 0.0);
+      if (cost < best - 1e-9) { best = cost; bestL = L; }
+    }
+    return -bestL;
+  }
+  // tiles of the kernel that will run (256 x 256 unless the 128 x 128 kernel was chosen by option with a fixed slice length)
   const int t = (!f32 && opt(OPT_DW_TILE) == 2) ? 128 : 256;
   long long wgs = 0;
   for (int i = 0; i < n; ++i)
