@@ -24,10 +24,15 @@ timeout -k 10 200 python tools/tf_stamps.py > $OUT/tf_stamps.txt 2>&1; echo "sta
 timeout -k 10 200 python tools/chain_stamps.py 4096 > $OUT/chain_stamps.txt 2>&1; echo "chain stamps rc=$?"
 timeout -k 10 200 python tools/chain_stamps.py 4096 bwd > $OUT/chain_stamps_bwd.txt 2>&1; echo "chain stamps (backward head chain) rc=$?"
 timeout -k 10 120 tools/probes/calibrate > $OUT/calibration.txt 2>&1; echo "calibration rc=$?"
-timeout -k 10 300 python tools/stackb_fused_time.py > $OUT/stackb_train.txt 2>&1; echo "stack B training rc=$?"
 # data-parallel rehearsal on the one GPU (1-rank group, the collectives really run; bench.py starts its rank on a free port)
 MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=0 timeout -k 10 300 python bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_single.json 2> $OUT/bench_dp1_single.err; echo "dp single rc=$?"
 MMDEER_FORCE_COMM=1 MMDEER_DP_OVERLAP=1 timeout -k 10 300 python bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_overlap.json 2> $OUT/bench_dp1_overlap.err; echo "dp overlap rc=$?"
 MMDEER_FORCE_COMM=1 timeout -k 10 300 python bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp1_auto.json 2> $OUT/bench_dp1_auto.err; echo "dp auto rc=$?"
 MMDEER_CHAIN=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_nochain.json 2> $OUT/bench_b4096_nochain.err; echo "bench without chains rc=$?"
+MMDEER_CHAIN_DEPTH=8 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_depth8.json 2> $OUT/bench_b4096_depth8.err; echo "bench with the 8-deep ring rc=$?"
+MMDEER_ADAM_FUSED=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_adam_unfused.json 2> $OUT/bench_b4096_adam_unfused.err; echo "bench with update + repack rc=$?"
+# Stack B training step: chains against launch by launch, one steady-state step of the kernel trace, stamps of one encoder chain
+bash tools/gpu_stackb_step.sh > $OUT/stackb_step.log 2>&1; echo "stack B step rc=$?"
+cp gpurun_out/sb/step_trace.txt $OUT/stackb_step_trace.txt; cp gpurun_out/sb/time_chain.txt $OUT/stackb_train.txt; cp gpurun_out/sb/time_ops.txt $OUT/stackb_train_ops.txt; cp gpurun_out/sb/kernel_stats.csv $OUT/stackb_kernel_stats.csv
+timeout -k 10 200 python tools/sb_chain_stamps.py 4096 1 > $OUT/stackb_chain_stamps.txt 2>&1; echo "stack B chain stamps rc=$?"
 ls -la $OUT

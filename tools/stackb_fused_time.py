@@ -17,6 +17,8 @@ for B, dtype in ((4096, "bf16"), (256, "bf16"), (4096, "fp32")):
     m.train_plan = os.environ.get("SB_PLAN", "auto")       # "ops": the launch-by-launch sequence instead of the layer chains
     b = synth.make_batch(B, seed=1)
     a, v, t, y = (torch.from_numpy(b[k]).to(dev) for k in ("audio", "video", "text", "targets"))
+    if dtype == "bf16":          # bf16 feature blocks resident in HBM, as bench.py's Stack C line
+        a, v, t = a.bfloat16(), v.bfloat16(), t.bfloat16()
     opt = FlatAdamW(m, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0)
     for _ in range(3):
         ld = m.train_step_fused(a, v, t, y)

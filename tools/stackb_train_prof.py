@@ -13,6 +13,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 m = stackb.CompleteDEERModel(stackb.ModelConfig(), compute_dtype="bf16").to(dev).train()
 b = synth.make_batch(B, seed=1)
 a, v, t, y = (torch.from_numpy(b[k]).to(dev) for k in ("audio", "video", "text", "targets"))
+a, v, t = a.bfloat16(), v.bfloat16(), t.bfloat16()      # bf16 feature blocks resident in HBM
 if len(sys.argv) > 2 and sys.argv[2] == "fused":
     from mmdeer.optim import FlatAdamW
     opt = FlatAdamW(m, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0)

@@ -499,7 +499,10 @@ class CompleteDEERModel(nn.Module):
         counter).  ``replay(a, v, t, y)`` copies new data into the static inputs and returns the (static) loss dict; the
         optimiser step (``optim.FlatAdamW.step``: two launches) follows eagerly, as for Stack C."""
         dev = audio.device
-        static = [x.detach().float().contiguous().clone() for x in (audio, video, text, targets)]
+        # feature blocks handed over in the compute dtype stay in it (bf16 blocks resident in HBM: no conversion launch inside the graph)
+        keep = torch.bfloat16 if self.compute_dtype == "bf16" else None
+        static = [x.detach().contiguous().clone() if x.dtype == keep else x.detach().float().contiguous().clone() for x in (audio, video, text)]
+        static.append(targets.detach().float().contiguous().clone())
         self._drop_counter = torch.full((1,), int(self._train_step) - 1, dtype=torch.int64, device=dev)
         counter = self._drop_counter
         was = self.training

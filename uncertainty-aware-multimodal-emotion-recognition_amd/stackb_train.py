@@ -78,10 +78,12 @@ def build_frag_images(model, st) -> Optional[FragImages]:
     wn0 = att.weight_network[0].weight
     F.area("wn1", ENC, 3 * ENC)
     F.place("wn1", W(wn0), ENC, 3 * ENC, ld_src=wn0.shape[1])
+    F.area("wh6bd", 24, 3 * HID // 2)          # the three last head layers block-diagonally: d H3 of all heads in one dX launch
     for d, nm in enumerate(("valence", "arousal", "dominance")):
         w6 = model.prediction_heads[nm].evidence_network[6].weight
         F.area(f"wh6p.{d}", 8, HID // 2)
         F.place(f"wh6p.{d}", W(w6), 4, HID // 2)
+        F.place("wh6bd", W(w6), 4, HID // 2, row0=8 * d, col0=d * (HID // 2))
     F.finish()
     return F
 
@@ -395,7 +397,10 @@ def backward(model, T: Dict, g4: torch.Tensor, flat=None) -> Dict[str, torch.Ten
     for d, nm in enumerate(names):
         pre = f"prediction_heads.{nm}.evidence_network"
         h3, dh3, ev_d = H3[:, d * 128:(d + 1) * 128], dH3[:, d * 128:(d + 1) * 128], dev_[:, 8 * d:8 * d + 8]
-        ex.dx(ev_d, 24, P["wh6p"][d], dh3, 3 * HID // 2, B, mask=h3, ldm=3 * HID // 2, mask_scale=sc)
+        if Fg is None:
+            ex.dx(ev_d, 24, P["wh6p"][d], dh3, 3 * HID // 2, B, mask=h3, ldm=3 * HID // 2, mask_scale=sc)
+        elif d == 0:        # chain plan: one launch for the three heads (the block-diagonal image of their last layers)
+            ex.dx(dev_, 24, Fg.mat("wh6bd"), dH3, 3 * HID // 2, B, mask=H3, ldm=3 * HID // 2, mask_scale=sc)
         w8, b8 = z32(8, 128), z32(8)
         ex.dw(ev_d, 24, h3, 3 * HID // 2, w8, b8, B, 8, 128)
         put(pre + ".6.weight", w8[:4]); put(pre + ".6.bias", b8[:4])
