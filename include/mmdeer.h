@@ -706,6 +706,12 @@ int mmdeer_comm_world(const mmdeer_comm* comm);
 int mmdeer_reduce_scatter(const void* send, void* recv, long long recv_count, int dtype_f32, int average, mmdeer_comm* comm, void* stream);
 int mmdeer_allgather(const void* send, void* recv, long long send_count, int dtype_f32, mmdeer_comm* comm, void* stream);
 
+/* sizeof() of an argument struct of this header by its name without the mmdeer_ prefix ("gemm_args", "chain_args", "chain_seg",
+ * "repack_job", "forward_args", "backward_args", "adamw_args", "adamw_flat_args", "stackb_attn_train_args", "stackb_attn_args",
+ * "stackb_forward_args", "stackb_weights", "softmax_mix_args"); -1 for an unknown name.  A binding in another language checks its
+ * own layout against it at load time (mmdeer/_lib.py does). */
+long long mmdeer_sizeof(const char* struct_name);
+
 /* fp32 <-> bf16 conversion of a contiguous device buffer (n % 4 == 0) */
 int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream);
 

@@ -37,6 +37,51 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.mmdeer_version()
 
 
+def test_ctypes_struct_layouts_match_the_library():
+    """Every argument struct of include/mmdeer.h is mirrored in mmdeer/_lib.py: the sizes the compiler gave them (mmdeer_sizeof) are
+    the sizes ctypes computes -- a field added on one side only fails here (and at load time) instead of shifting pointers."""
+    import ctypes as C
+    lib = _lib.load()
+    assert len(_lib.STRUCTS) >= 13
+    for name, cls in _lib.STRUCTS.items():
+        assert lib.mmdeer_sizeof(name.encode()) == C.sizeof(cls), name
+    assert lib.mmdeer_sizeof(b"no_such_struct") == -1
+
+
+def test_layer_chain_operator_validates_its_table_on_the_host():
+    """mmdeer_chain checks the whole segment table before it launches anything (no GPU is touched here: every case below is refused,
+    or empty): unsupported widths, panels that do not fit, residual / stash options where they do not apply."""
+    import ctypes as C
+    lib = _lib.load()
+    A = 1 << 20                                     # a plausible, aligned address: never dereferenced by the host checks
+    a = _lib.ChainArgs()
+    a.X, a.ldx, a.K0, a.rows, a.nseg = A, 256, 256, 0, 1
+    assert lib.mmdeer_chain(C.byref(a)) == 0        # an empty batch is nothing to do
+    a.rows, a.nseg = 64, 0
+    assert lib.mmdeer_chain(C.byref(a)) != 0 and b"segments" in lib.mmdeer_last_error()
+    a.nseg = 1
+    s = a.seg[0]
+    s.W, s.N, s.K, s.end_layer, s.nout, s.drop_site = A, 256, 320, 1, 256, -1
+    assert lib.mmdeer_chain(C.byref(a)) != 0        # K = 320 reads past the 256-wide input panel
+    s.K, s.N, s.nout = 256, 96, 96
+    assert lib.mmdeer_chain(C.byref(a)) != 0        # N % 64
+    s.N, s.nout, s.W = 256, 256, A + 2
+    assert lib.mmdeer_chain(C.byref(a)) != 0        # misaligned weight image
+    s.W, s.res_add = A, 1
+    assert lib.mmdeer_chain(C.byref(a)) != 0 and b"bypass" in lib.mmdeer_last_error()
+    s.res_add, s.stash, s.ld_stash, s.stash_split = 0, A, 256, 128
+    assert lib.mmdeer_chain(C.byref(a)) != 0        # a split without the second tensor
+    s.stash_split, a.samples_per_workgroup = 0, 24
+    assert lib.mmdeer_chain(C.byref(a)) != 0 and b"samples_per_workgroup" in lib.mmdeer_last_error()
+    a.samples_per_workgroup, a.K0 = 32, 768
+    assert lib.mmdeer_chain(C.byref(a)) != 0        # a 768-wide input needs the 16-sample workgroups
+    assert lib.mmdeer_chain_workgroups(4096, 0) == 256 and lib.mmdeer_chain_workgroups(4097, 0) == 129 and lib.mmdeer_chain_workgroups(100, 16) == 7
+    j = (_lib.RepackJob * 1)()
+    j[0].src, j[0].dst, j[0].ld_src, j[0].rows, j[0].cols, j[0].cols_valid, j[0].layout = A, A, 100, 100, 100, 100, 1
+    assert lib.mmdeer_repack(j, 1, None) != 0       # a fragment-major image needs rows % 16 == 0 and columns % 64 == 0
+    assert lib.mmdeer_repack(j, 0, None) == 0
+
+
 def test_parameter_table_matches_python_spec():
     lib = _lib.load()
     offs, total = param_offsets()

@@ -185,6 +185,12 @@ class RepackJob(C.Structure):
                 ("transpose", c_int), ("layout", c_int), ("ld_dst", c_int), ("dst_col", c_int)]
 
 
+# ctypes mirror of every argument struct, by the name mmdeer_sizeof() knows it under
+STRUCTS = {"gemm_args": GemmArgs, "chain_args": ChainArgs, "chain_seg": ChainSeg, "repack_job": RepackJob, "forward_args": ForwardArgs,
+           "backward_args": BackwardArgs, "adamw_args": AdamWArgs, "adamw_flat_args": AdamWFlatArgs, "stackb_attn_train_args": StackBAttnTrainArgs,
+           "stackb_attn_args": StackBAttnArgs, "stackb_forward_args": StackBForwardArgs, "stackb_weights": StackBWeights,
+           "softmax_mix_args": SoftmaxMixArgs}
+
 # every symbol include/mmdeer.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mmdeer_version", C.c_char_p, []),
@@ -204,6 +210,7 @@ SYMBOLS = [
     ("mmdeer_bucket_begin", c_ll, [c_int]),
     ("mmdeer_bucket_end", c_ll, [c_int]),
     ("mmdeer_gemm", c_int, [C.POINTER(GemmArgs)]),
+    ("mmdeer_sizeof", c_ll, [c_char_p]),
     ("mmdeer_chain", c_int, [C.POINTER(ChainArgs)]),
     ("mmdeer_chain_workgroups", c_int, [c_int, c_int]),
     ("mmdeer_repack", c_int, [C.POINTER(RepackJob), c_int, c_void_p]),
@@ -304,6 +311,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn.argtypes = args
         if lib.mmdeer_abi_version() != 15:   # MMDEER_ABI_VERSION of include/mmdeer.h
             raise RuntimeError("libmmdeer_hip.so ABI version mismatch")
+        for cname, cls in STRUCTS.items():      # the ctypes mirrors against the library's own sizeof (a field added on one side only)
+            if lib.mmdeer_sizeof(cname.encode()) != C.sizeof(cls):
+                raise RuntimeError(f"mmdeer: ctypes layout of mmdeer_{cname} ({C.sizeof(cls)} bytes) differs from the library's "
+                                   f"({lib.mmdeer_sizeof(cname.encode())})")
         # The library itself reads no environment variable (include/mmdeer.h).  For the A/B tools the host forwards
         # MMDEER_<OPTION> (e.g. MMDEER_FUSED_ATTN=0) to mmdeer_set_option once, here.
         i = 0

@@ -1623,6 +1623,15 @@ int mmdeer_repack(const mmdeer_repack_job* jobs, int n, void* stream) {
   return 0;
 }
 
+long long mmdeer_sizeof(const char* n) {
+  if (!n) return -1;
+#define SZ(name) if (strcmp(n, #name) == 0) return (long long)sizeof(mmdeer_##name);
+  SZ(gemm_args) SZ(chain_args) SZ(chain_seg) SZ(repack_job) SZ(forward_args) SZ(backward_args) SZ(adamw_args) SZ(adamw_flat_args)
+  SZ(stackb_attn_train_args) SZ(stackb_attn_args) SZ(stackb_forward_args) SZ(stackb_weights) SZ(softmax_mix_args)
+#undef SZ
+  return -1;
+}
+
 int mmdeer_convert(const void* src, int src_f32, void* dst, int dst_f32, long long n, void* stream) {
   return launch_convert(src, src_f32, dst, dst_f32, n, (hipStream_t)stream);
 }
