@@ -477,6 +477,47 @@ def test_fused_train_step_layer_chains_match_the_launch_by_launch_plan(B):
     assert seen >= 100
 
 
+@pytest.mark.parametrize("rows,ts", [(37, 0), (300, 32)])
+def test_layer_chain_operator_against_torch(rows, ts):
+    """mmdeer_chain on its own, against plain PyTorch fp32 on the same bf16-rounded operands: a Linear-ReLU-LayerNorm stem, a residual
+    block x + LayerNorm(ReLU(Linear x)) and an output Linear whose 512 columns are stashed into two tensors -- ragged row counts,
+    both workgroup sizes.  bf16 storage between the layers: 2e-2 of each tensor's largest element."""
+    from mmdeer.chainops import Chain, FragImages
+    from mmdeer.opseq import Exec
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    x = rnd(rows, 256).bfloat16()
+    W0, W1, W2 = (rnd(256, 256, sc=0.08).bfloat16(), rnd(256, 256, sc=0.08).bfloat16(), rnd(512, 256, sc=0.08).bfloat16())
+    b0, b1, b2 = rnd(256, sc=0.1), rnd(256, sc=0.1), rnd(512, sc=0.1)
+    g0, be0, g1, be1 = 1 + rnd(256, sc=0.1), rnd(256, sc=0.1), 1 + rnd(256, sc=0.1), rnd(256, sc=0.1)
+    F = FragImages(dev)
+    F.add("w0", W0, 256, 256); F.add("w1", W1, 256, 256); F.add("w2", W2, 512, 256)
+    F.finish(); F.refresh()
+    new = lambda *s, d=torch.bfloat16: torch.zeros(*s, dtype=d, device=dev)
+    y0, h0, y1, h1, oa, ob = new(rows, 256), new(rows, 256), new(rows, 256), new(rows, 256), new(rows, 256), new(rows, 256)
+    m0, r0, m1, r1 = (new(rows, d=torch.float32) for _ in range(4))
+    ex = Exec("bf16", None)
+    ch = Chain(ex, x, 256, 256, rows, ts=ts)
+    ch.seg(F("w0"), 256, 256, bias=b0, relu=1).end(256, stash=y0, ld_stash=256, ln=(g0, be0, h0, m0, r0))
+    ch.seg(F("w1"), 256, 256, bias=b1, relu=1).end(256, stash=y1, ld_stash=256, ln=(g1, be1, h1, m1, r1), residual=1)
+    ch.seg(F("w2"), 512, 256, bias=b2).end(512, stash=oa, ld_stash=256, stash2=ob, split=256)
+    assert ch.workgroups() == (rows + (ts or 16) - 1) // (ts or 16)
+    ch.launch()
+    torch.cuda.synchronize()
+    f = lambda t: t.float()
+    bf = lambda t: t.bfloat16().float()
+    ry0 = bf(torch.relu(f(x) @ f(W0).T + b0))
+    rh0 = bf(torch.nn.functional.layer_norm(ry0, (256,), g0, be0, 1e-5))
+    ry1 = bf(torch.relu(rh0 @ f(W1).T + b1))
+    rh1 = bf(bf(torch.nn.functional.layer_norm(ry1, (256,), g1, be1, 1e-5)) + rh0)
+    ro = rh1 @ f(W2).T + b2
+    for name, got, ref in (("y0", y0, ry0), ("h0", h0, rh0), ("y1", y1, ry1), ("h1", h1, rh1), ("out[:256]", oa, ro[:, :256]), ("out[256:]", ob, ro[:, 256:])):
+        scale = float(ref.abs().max())
+        assert float((f(got) - ref).abs().max()) <= 2e-2 * scale, (name, float((f(got) - ref).abs().max()), scale)
+    assert torch.allclose(m0, ry0.mean(1), atol=1e-4) and torch.allclose(r0, 1 / torch.sqrt(ry0.var(1, unbiased=False) + 1e-5), rtol=1e-4)
+
+
 def test_layer_chain_operator_refuses_what_it_does_not_instantiate():
     """mmdeer_chain validates its tables on the host: unsupported widths, panels that do not fit, a residual on a layer that changes
     the geometry all fail with a message instead of launching."""
