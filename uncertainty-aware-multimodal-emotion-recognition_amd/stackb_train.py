@@ -382,9 +382,17 @@ def backward(model, T: Dict, g4: torch.Tensor, flat=None) -> Dict[str, torch.Ten
         G[name] = z32(n)
         return G[name]
 
-    def put(name, src):            # a gradient that is a slice of a wider scratch matrix
+    def put(name, src, pad_from=None):            # a gradient that is a slice of a wider scratch matrix
+        # pad_from (flat mode): `src` is the head of that zero-tailed scratch vector (the rows behind it are exact zeros: the products of the
+        # zero columns the row kernels pad their 8-column outputs with) and has fewer than 4 elements -- four are copied, so that the copy
+        # rides in the one batched fold launch; the extra zeros land in the parameter's alignment gap of the flat buffer (64-element slots)
         if flat is not None:
-            late.append((fview(name), src))
+            n = src.numel()
+            if pad_from is not None and n % 4:
+                off = flat["offs"][name]
+                late.append((flat["g"][off:off + (n + 3) // 4 * 4], pad_from.reshape(-1)[:(n + 3) // 4 * 4]))
+            else:
+                late.append((fview(name), src))
         else:
             G[name] = src
 
@@ -494,7 +502,7 @@ def backward(model, T: Dict, g4: torch.Tensor, flat=None) -> Dict[str, torch.Ten
     att = "attention_module"
     t4w, t4b = z32(8, ENC), z32(8)
     ex.dw(dlog8, 8, T["r"], ENC, t4w, t4b, B, 8, ENC)                                      # weight_network.3 (3 x 256)
-    put(att + ".weight_network.3.weight", t4w[:3]); put(att + ".weight_network.3.bias", t4b[:3])
+    put(att + ".weight_network.3.weight", t4w[:3]); put(att + ".weight_network.3.bias", t4b[:3], pad_from=t4b)
     if flat is not None:
         gwn, gbn = fview(att + ".weight_network.0.weight"), fview(att + ".weight_network.0.bias")
     else:
@@ -522,7 +530,7 @@ def backward(model, T: Dict, g4: torch.Tensor, flat=None) -> Dict[str, torch.Ten
     est = att + ".uncertainty_estimator.estimator"
     t4w2, t4b2 = z32(8, ENC // 4), z32(8)
     ex.dw(dz8e, 8, T["H2"], ENC // 4, t4w2, t4b2, 3 * B, 8, ENC // 4)
-    put(est + ".5.weight", t4w2[:1]); put(est + ".5.bias", t4b2[:1])
+    put(est + ".5.weight", t4w2[:1]); put(est + ".5.bias", t4b2[:1], pad_from=t4b2)
     E3 = T["E"].view(3 * B, ENC)
     if Fg is not None:         # the estimator's two dX products on the 3 B rows: one launch
         dH1, dE_est = new(3 * B, ENC // 2), new(3 * B, ENC)
