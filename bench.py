@@ -244,6 +244,77 @@ def bench_stackb(args, dev, world, rank):
     print(json.dumps(out))
 
 
+def bench_stackb_train(args, dev, world, rank):
+    """--workload stackb_train: samples/sec of the Stack B (complete_project.CompleteDEERModel) training step -- forward with dropout +
+    MultiTaskDEERLoss + backward as ONE HIP graph (the sample-local layer runs as launches of the layer-chain kernel in bf16), and
+    beside it the same step with the eager FlatAdamW optimiser step, the launch-by-launch plan of the same model on the same box
+    (--dtype bf16 only) and the launch count of the graph.  Every rank trains its own replica on its own shard (no collective here:
+    the data-parallel exchange of this workload is the trainer's, not the bench's)."""
+    import copy
+
+    from mmdeer import stackb, synth
+    from mmdeer.optim import FlatAdamW
+    B, K, W = args.batch, args.steps, args.warmup
+    model = stackb.CompleteDEERModel(compute_dtype=args.dtype).to(dev).train()
+    twin = copy.deepcopy(model) if args.dtype == "bf16" else None
+    data = synth.make_batch(B, seed=42, row_offset=rank * B)
+    a, v, t, y = (torch.from_numpy(data[k]).to(dev) for k in ("audio", "video", "text", "targets"))
+    if args.dtype == "bf16":
+        a, v, t = a.bfloat16(), v.bfloat16(), t.bfloat16()        # bf16 feature blocks resident in HBM, as the north-star line
+
+    def timed(m, with_opt):
+        opt = FlatAdamW(m, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0)
+        rep = m.capture_train_step_fused(a, v, t, y)
+        for _ in range(max(W, 3)):
+            rep(); opt.step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ld = rep()
+            if with_opt:
+                opt.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt), float(ld["total_loss"]), rep
+
+    dt, loss, rep = timed(model, False)
+    dt_opt, _, _ = timed(model, True)
+    extra = {}
+    if twin is not None:
+        twin.train_plan = "ops"
+        dt_ops, _, _ = timed(twin, False)
+        extra["launch_by_launch_ms_per_step"] = round(dt_ops / K * 1e3, 4)
+    if rank != 0:
+        return
+    cfg = model.config
+    macs = ((cfg.audio_dim + cfg.video_dim + cfg.text_dim) * 256 + 3 * (cfg.encoder_layers + 1) * 256 * 256
+            + 3 * (256 * 512 + 2 * 256 * 256 + 256 * 128 + 128 * 64) + 768 * 256
+            + 512 * 512 * 2 + 768 * 512 * 2 + 512 * 512 + 512 * 768 + 3 * (256 * 128 + 128 * 4))
+    flops = 3 * 2.0 * macs * B
+    peak = BF16_MFMA_PEAK if args.dtype == "bf16" else F32_MFMA_PEAK
+    st = getattr(model, "_flat_state", {}) or {}
+    out = {"metric": "samples/sec (Stack B CompleteDEERModel training step: fwd + MultiTaskDEERLoss + bwd)", "value": round(world * B * K / dt, 1),
+           "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"complete_project.CompleteDEERModel (reference run_multimodal_deer.py:231-247) training step, dropout {cfg.dropout}, "
+                                  f"B={B} per GPU, Xavier-initialised weights; optimiser step excluded from `value` and reported beside it",
+                      "launch": "hip-graph replay", "parallelism": f"replicas x{world}",
+                      "plan": "layer chains (mmdeer_chain)" if st.get("frag") is not None else "launch by launch"},
+           "train_step_with_optimizer_ms": round(dt_opt / K * 1e3, 4), "final_loss": round(loss, 6),
+           "roofline": {"bound": "mfma", "achieved": round(flops * K / dt / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                        "frac": round(flops * K / dt / peak, 4), "traffic": None,
+                        "note": "whole step, algorithmic GEMM flops (3 x forward) / wall time; a step of small layers: bound by the layer ends of its "
+                                "chains and by fixed launch cost, not by MFMA (DESIGN.md section 4, Stack B training)"}}
+    out.update(extra)
+    print(json.dumps(out))
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` (N > 1, or the 1-rank rehearsal MMDEER_FORCE_COMM=1, not under a launcher): start N rank
     processes -- one per GPU -- as CHILD processes of this one, which has not touched the GPU, and return their exit code.  The
@@ -326,8 +397,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-comm", default="bf16", choices=["bf16", "fp32"],
                     help="payload of the data-parallel gradient all-reduce (N > 1): bf16 halves the bytes over xGMI")
-    ap.add_argument("--workload", default="train_step", choices=["train_step", "stackb_infer"],
-                    help="train_step: the north-star line (default); stackb_infer: SURVEY 8f-1, CompleteDEERModel eval forward")
+    ap.add_argument("--workload", default="train_step", choices=["train_step", "stackb_infer", "stackb_train"],
+                    help="train_step: the north-star line (default); stackb_infer / stackb_train: SURVEY 8f-1, CompleteDEERModel eval forward / training step")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     ap.add_argument("--no-autotune", action="store_true",
                     help="keep the library's default launch plan instead of timing the plans on this GPU first (MultimodalDEER.autotune_launch_plan)")
@@ -361,8 +432,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    if args.workload == "stackb_infer":
-        bench_stackb(args, dev, world, rank)
+    if args.workload in ("stackb_infer", "stackb_train"):
+        (bench_stackb if args.workload == "stackb_infer" else bench_stackb_train)(args, dev, world, rank)
         if dist.is_initialized():
             dist.destroy_process_group()
         return

@@ -17,7 +17,7 @@ src, dst = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profil
 sha = bench.kernel_sources_sha()
 for name in ("bench_b4096_bf16.json", "bench_b8192_bf16.json", "bench_b1024_fp32.json", "bench_b7_bf16.json", "step_trace.txt",
              "pmc_fused_summary.txt", "pmc_step_summary.txt", "tf_stamps.txt", "chain_stamps.txt", "chain_stamps_bwd.txt", "fwd_only.txt", "calibration.txt",
-             "stackb_train.txt", "stackb_train_ops.txt", "stackb_step_trace.txt", "stackb_kernel_stats.csv", "stackb_chain_stamps.txt", "bench_b4096_depth8.json", "bench_b4096_adam_unfused.json", "step_trace_b8192.txt", "kernel_stats_b8192.csv", "bench_dp1_single.json", "bench_dp1_overlap.json", "bench_dp1_auto.json", "bench_b4096_nochain.json"):
+             "stackb_train.txt", "stackb_train_ops.txt", "stackb_step_trace.txt", "stackb_kernel_stats.csv", "stackb_chain_stamps.txt", "bench_stackb_train.json", "bench_b4096_depth8.json", "bench_b4096_adam_unfused.json", "step_trace_b8192.txt", "kernel_stats_b8192.csv", "bench_dp1_single.json", "bench_dp1_overlap.json", "bench_dp1_auto.json", "bench_b4096_nochain.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))

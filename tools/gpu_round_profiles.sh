@@ -31,6 +31,7 @@ MMDEER_FORCE_COMM=1 timeout -k 10 300 python bench.py --gpus 1 --no-cpu-baseline
 MMDEER_CHAIN=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_nochain.json 2> $OUT/bench_b4096_nochain.err; echo "bench without chains rc=$?"
 MMDEER_CHAIN_DEPTH=8 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_depth8.json 2> $OUT/bench_b4096_depth8.err; echo "bench with the 8-deep ring rc=$?"
 MMDEER_ADAM_FUSED=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $OUT/bench_b4096_adam_unfused.json 2> $OUT/bench_b4096_adam_unfused.err; echo "bench with update + repack rc=$?"
+timeout -k 10 300 python bench.py --workload stackb_train > $OUT/bench_stackb_train.json 2> $OUT/bench_stackb_train.err; echo "bench Stack B training rc=$?"
 # Stack B training step: chains against launch by launch, one steady-state step of the kernel trace, stamps of one encoder chain
 bash tools/gpu_stackb_step.sh > $OUT/stackb_step.log 2>&1; echo "stack B step rc=$?"
 cp gpurun_out/sb/step_trace.txt $OUT/stackb_step_trace.txt; cp gpurun_out/sb/time_chain.txt $OUT/stackb_train.txt; cp gpurun_out/sb/time_ops.txt $OUT/stackb_train_ops.txt; cp gpurun_out/sb/kernel_stats.csv $OUT/stackb_kernel_stats.csv
