@@ -89,6 +89,7 @@ size_t mmdeer_weights_bytes(int compute_f32);
  *   chain_in (1)       0: the input projections as a pad launch + one 3-problem GEMM launch also where the first chain could run them
  *   chain_nigf (0)     1: the NIG head as the tail of the forward head chain (bit-identical, one launch fewer, measured slower)
  *   chain_ts (0)       16 / 32: force the samples per chain workgroup (0: 16 up to B = 4096, 32 above)
+ *   adam_fused (1)     bf16 mode: mmdeer_adamw_step's update writes every derived weight image itself (0: element-wise update + repack launch)
  *   xcd, nt128, nt192, glds, nt8 (1), t128 (512), tile (-1), ksteps (0), splitk_max (8)   GEMM tile / split-K selection
  * mmdeer_set_option / mmdeer_get_option return -1 for an unknown name, mmdeer_set_option also for a value outside the option's
  * range (every option has one: booleans 0..1, dw_tile 2..4, dw_kg 1..2, tile -1..4, splitk_max 1..8, chain_depth 2..8, ...; the

@@ -1,58 +1,55 @@
 // Row-local layer chains in ONE launch.
 //
 // Every layer of the path between the attention blocks and the NIG head is local to a sample: Linear, ReLU, Dropout and
-// LayerNorm act on one row (reference fusion.py:98-103, 216-221, 301-306; deer.py:215-221, 49-55).  As separate launches
-// each of them is a 5-7 us GEMM of 2-4 GFLOP whose time is the fixed cost of a dependent launch plus one fill / drain of
-// the chip (the small GEMMs are bound by LDS-DMA issue, not by MFMA), and each writes its rows to HBM only for
-// the next launch to read them back.  Here a workgroup owns 16 samples and walks the whole chain: the input rows are
-// DMA-copied into an LDS panel once, every layer multiplies the resident panel by its weight matrix -- streamed through a
-// ring of six 16-KiB LDS slots by `global_load_lds`, five stages ahead, ACROSS tile and layer boundaries, so the weight
-// stream never drains -- and writes bias / ReLU / dropout'ed bf16 rows into the second panel, which is then the input of
-// the next layer.  A finished panel is also copied to the workspace buffer the separate launches wrote (the backward pass
-// and the teacher-forced tests read the same buffers), and a LayerNorm runs on it in place.
+// LayerNorm act on one row (reference fusion.py:98-103, 216-221, 301-306; deer.py:215-221, 49-55; Stack B: complete_project.py:60-118,
+// 120-184, 307-418).  As separate launches each of them is a 5-7 us GEMM of 2-4 GFLOP whose time is the fixed cost of a dependent
+// launch plus one fill / drain of the chip, and each writes its rows to HBM only for the next launch to read them back.  Here a
+// workgroup owns 16 samples (32 above B = 4096) and walks the whole chain: the input rows are DMA-copied into an LDS panel once, every
+// layer multiplies the resident panel by its weight matrix -- streamed straight into REGISTERS from a fragment-major image (chain.h),
+// four stages of 2 KiB per wave in flight ACROSS tile and layer boundaries -- and writes bias / ReLU / dropout'ed bf16 rows into the
+// second panel, which is then the input of the next layer.  A finished panel is also copied to the workspace buffer the separate
+// launches wrote (the backward pass and the teacher-forced tests read the same buffers), and a LayerNorm runs on it in place.
 //
-// Layout.  A panel holds `rows` x 64-column images, image = rows x 128 B, 16-byte chunk c of row r at chunk slot
-// c ^ (r & 7) (the bank-conflict-free layout of gemm_glds.hip).  A weight stage is 16 KiB = sixteen 1-KiB DMA pieces,
-// two per wave: 128 output columns x 64 k (N % 128 == 0) or 64 output columns x 128 k (the three 128 -> 64 heads).
-// MFMA roles: A = weights, B = activations, so a lane ends up with four consecutive output columns of one sample row --
-// one 8-byte LDS write into the next panel.  A wave's activation fragments (all K of the 16 or 32 rows) are read from the
-// panel once per segment and stay in registers.  Accumulation order over k is that of the stand-alone GEMM kernels: the
-// chain reproduces their outputs bit for bit (tests/test_gpu_model.py).
+// Layout.  A panel holds `rows` x 64-column images, image = rows x 128 B, 16-byte chunk c of row r at chunk slot c ^ (r & 7) (the
+// bank-conflict-free layout of gemm_glds.hip).  A weight stage of a workgroup is 16 KiB = 2 KiB per wave: 128 output columns x 64 k
+// (N % 128 == 0) or 64 output columns x 128 k in four column blocks (the three 128 -> 64 heads: waves 4-7 load what waves 0-3 load and
+// ignore it, so that every wave counts the same loads).  MFMA roles: A = weights, B = activations, so a lane ends up with four
+// consecutive output columns of one sample row -- one 8-byte LDS write into the next panel.  16-sample workgroups keep a segment's
+// activation fragments (all K of the 16 rows) in registers; 32-sample workgroups read them one stage ahead from the panel.
+// Accumulation order over k is that of the stand-alone GEMM kernels: the chain reproduces their outputs bit for bit.
 //
-// Synchronisation of the stage loop: in a 128-column stage every wave DMA-copies exactly the 16 weight rows it multiplies itself, so its
-// own counted vmcnt wait is all the ordering those LDS rows need and the loop has NO barrier (with one per stage the step was 5.5 us
-// slower at B = 4096, 10 us at 8192); only the 64-column stages of the evidence heads, whose pieces are shared out over all waves,
-// and their neighbours keep barriers.  vmcnt bookkeeping: every wave issues exactly two DMA instructions per stage and the stream runs NST - 1 stages ahead, so
-// "stage j has landed" is a counted `s_waitcnt vmcnt(2 (NST - 2))`; global stores issued in between (stash copies, LayerNorm outputs)
-// only make the count conservative (loads and stores retire in order on gfx9).  Past the last stage the stream wraps around
-// to the first segment, so the count is the same at every stage of the chain and the tail needs no special case.  All bias /
-// gamma / beta vectors and the segment tables are staged into LDS once at kernel start: a tracked global load in the steady
-// state would make the compiler drain the ring with vmcnt(0).
+// Synchronisation of the stage loop: a wave loads exactly the 16 weight rows it multiplies itself, into registers only it reads, so its
+// own counted vmcnt wait is all the ordering the stream needs and the loop has NO barrier.  vmcnt bookkeeping: every wave issues exactly
+// two loads per stage and the stream runs D stages ahead, so "stage j has landed" is a counted `s_waitcnt vmcnt(2 (D - 1))`; global
+// stores issued in between (stash copies, LayerNorm outputs) only make the count conservative (loads and stores retire in order on
+// gfx9).  Every tile takes a multiple of the ring's granule in stages (behind its K / 64 real ones the last real stage is loaded again
+// and ignored), so the ring slot of every stage is known at compile time; past the last stage the stream wraps around to the first
+// segment, so the count is the same at every stage of the chain and the tail needs no special case.  All bias / gamma / beta vectors
+// and the segment tables are staged into LDS once at kernel start -- in ONE round trip: tables, input rows, vectors and the ring's
+// first stages are requested together, what those requests need of the tables comes from the kernel arguments by scalar loads.
 //
-// What bounds it (cycle stamps of workgroup 0, tools/chain_stamps.py; B = 4096, 256 workgroups): the weight stream into the
-// CU.  Every workgroup streams ALL weights of the chain (2.2 MB for F9..F17) for its 16 rows, and a 16-KiB stage lands every
-// 350-450 cycles = 36-45 B/clk per CU -- the rate the L2 -> LDS DMA path of a CU delivered in every kernel of this library
-// (tri_fused.hip: ~40 B/clk; the calibration probe's best case is 57).  It is not latency (a seventh ring slot, 96 KiB in
-// flight instead of 80, was 4-5 us per step slower) and not 32 CUs of an XCD asking one L2 for the same lines at the same
-// moment (staggering the workgroups in time by up to 8 x 512 cycles cost exactly the stagger).  Fewer bytes per row would
-// need more rows per workgroup, and two 32-row panels leave no room for the ring.
-// Measured dead ends: (1) re-reading the activation fragments from LDS at every stage made the loop LDS-bandwidth-bound
-// (48 KiB of LDS traffic per stage, 475 cycles); (2) two stages per barrier leave only four stages in flight: slower than
-// one stage per barrier with five; (3) reading the segment tables from the kernarg segment with scalar loads cost ~1000
-// cycles per record; (4) weights straight from global memory into registers in the MFMA layout (no ring, no barrier in the
-// stage loop, 128 KiB in flight) ran at 22 B/clk/CU -- a 16-lane x 64-byte request pattern instead of the DMA's full lines --
-// and was 30 us slower per step; (5) running a tile's epilogue inside the first stage of the next tile, behind that stage's DMA
-// issue, so that the ring never waits for the epilogue: 2 us per step slower.  One workgroup per 16 rows also means the launch only pays while the chip holds all
-// workgroups at once: api.hip uses 16-sample workgroups for B <= 4096, 32-sample workgroups (TS = 2) up to 8192 and the separate
-// launches above (and below ~2000 rows, where most CUs would have no workgroup).
+// What bounds it (cycle stamps of workgroup 0, tools/chain_stamps.py, tools/sb_chain_stamps.py; B = 4096, 256 workgroups): for wide
+// layers the weight stream into the CU -- every workgroup streams ALL weights of the chain (2.2 MB for F9..F17) for its 16 rows at
+// ~320 cycles per 16-KiB stage = 51 B/clk per CU (tools/probes/wstream.hip: 54 with plain register loads from a fragment-major image,
+// 39-44 through an LDS-DMA ring) --; for 256-wide layers the layer ends: decode of the next table record ~1.0k cycles, barrier skew
+// between the two waves of a SIMD ~1.5k, LayerNorm ~1.9k, and the restart of the 4-deep ring behind every layer end (eight stages in
+// 4.5k cycles instead of 2.6k).  One workgroup per 16 rows also means the launch only pays while the chip holds all workgroups at
+// once: api.hip uses 16-sample workgroups for B <= 4096, 32-sample workgroups up to 8192 and the separate launches above.
+// Measured dead ends (rounds 3-4): the LDS-DMA weight ring (36-45 B/clk) and a seventh slot of it; re-reading the activation fragments
+// from LDS at every stage while the weights also went through LDS; two stages per barrier; the segment tables from the kernel
+// arguments by dependent scalar loads record after record (~1000 cycles each); weights into registers from the ROW-MAJOR copy
+// (16 lanes x 64 bytes per request: 22 B/clk); a tile's epilogue inside the first stage of the next tile; deferring the stash /
+// LayerNorm stores into the next layer's first tile; an 8-deep ring (chain_depth = 8: parity-green, slower -- 137 spilled VGPRs at
+// 192 compiler-visible registers); both LayerNorm-backward fold passes behind one barrier pair (no change); the dropout step counter
+// as an untracked load and the first record from scalar loads (+3 us per step).
 //
-// Backward chains (dX = dY W through the packed W^T copies) use the same kernel: a segment's epilogue can multiply by the
-// (Y > 0) * scale mask of the forward layer below (four mask values per lane, requested by an untracked asm load before the
-// tile's stages and waited for by count), and a layer can end in a LayerNorm BACKWARD of the finished panel (chain_ln_bwd:
-// the forward's rows and statistics requested before the segment's stages; gamma / beta partial sums per workgroup in a
-// fixed order).  An LDS atomic in that reduction made the compiler insert vmcnt(0) -- it cannot tell the atomic from the
-// LDS-DMA targets -- which drained the ring and waited for every write-through store: 13k cycles per LayerNorm; plain
-// ordered LDS operations of one wave do the same sum.
+// Backward chains (dX = dY W through fragment-major images of W^T) use the same kernel: a segment's epilogue can multiply by the
+// (Y > 0) * scale mask of the forward layer below (four mask values per lane, requested by an untracked asm load before the tile's
+// stages and waited for by count), add the bypass gradient of a residual block and write its result twice (res_add / res_dup), and a
+// layer can end in a LayerNorm BACKWARD of the finished panel (chain_ln_bwd: the forward's rows and statistics requested before the
+// segment's stages; gamma / beta partial sums per workgroup in a fixed order).  An LDS atomic in that reduction made the compiler
+// insert vmcnt(0) -- it cannot tell the atomic from a pending load -- which drained the ring and waited for every write-through store:
+// 13k cycles per LayerNorm; plain ordered LDS operations of one wave do the same sum.
 #include <type_traits>
 #include "gemm_kernel.inc"
 #include "chain.h"

@@ -27,7 +27,8 @@ enum OptId {
   OPT_CHAIN_MAX,        // largest batch that takes the chains
   OPT_CHAIN_NIG,        // 1 (with the backward chain, loss mode): the head's last-layer backward + loss gradient run in the chain's prologue
   OPT_SPLITK_MAX,       // largest number of split-K slices of a weight-gradient problem (slabs: 4 B per parameter per slice)
-  OPT_CHAIN_DEPTH,      // weight stages a wave of the 16-sample layer-chain kernel keeps in flight: 4 (default) or 2
+  OPT_CHAIN_DEPTH,      // weight stages a wave of the 16-sample layer-chain kernel keeps in flight: 4 (default), 2, or 8 (two granules of four
+                        // slots: parity-green, measured slower -- register spills at 192 compiler-visible registers)
   OPT_CHAIN_TS,         // 0: 16-sample chain workgroups up to B = 4096, 32-sample ones above; 16 / 32: that size at every batch
   OPT_CHAIN_IN,         // 1 (with chain = 1, bf16 feature blocks, B <= 4096): the three input projections and the audio padding run
                         // inside the audio-visual chain's launch instead of as pad + F1 launches
