@@ -429,14 +429,17 @@ def test_fused_train_step_equals_the_autograd_path(compute, B):
     assert float(l2b["total_loss"]) != float(l2["total_loss"])
 
 
-@pytest.mark.parametrize("B", [100, 515, 1024])
+@pytest.mark.parametrize("B", [100, 515, 1024, 4096])
 def test_fused_train_step_layer_chains_match_the_launch_by_launch_plan(B):
     """the bf16 fused step runs its sample-local layer runs (residual encoders, attention value / output
     projections, estimator, fusion stages, evidence heads -- complete_project.py:60-118, 120-184, 307-418 -- and their dX runs) as
-    launches of the layer-chain kernel (mmdeer_chain).  Same tape, same arithmetic per layer; the one difference is the summation
-    order inside LayerNorm's variance (1 fp32 ulp in rstd), which now and then flips a bf16 rounding that the following bf16
-    layers amplify -- so: equal loss to 2e-4, every stored activation equal except for a few bf16 ulps on a small fraction of the
-    elements, gradients equal in direction and norm."""
+    launches of the layer-chain kernel (mmdeer_chain).  The FORWARD is the launch-by-launch plan's bit for bit: every tensor of the
+    tape (activations, pre-LayerNorm rows, LayerNorm statistics, evidence), the loss, the ECE bin counts -- GEMM accumulation order,
+    epilogues, dropout masks and (csrc/ln_rows.h) the LayerNorm arithmetic are one statement executed by both plans.  The backward's
+    dX products and masks are the same too; its LayerNorm backward sums the two row means in another lane order (1 fp32 ulp, now and
+    then a flipped bf16 rounding of a dz element), the LayerNorm gamma / beta partials are grouped per workgroup, and the audio input
+    projection's weight gradient runs on another kernel (padded rows): gradients agree to 2e-3 of each tensor's largest element with
+    cosine 1 - 1e-6."""
     import copy
     m1, _ = _train_model("bf16")
     m2 = copy.deepcopy(m1)
@@ -450,20 +453,18 @@ def test_fused_train_step_layer_chains_match_the_launch_by_launch_plan(B):
     torch.cuda.synchronize()
     T1, T2 = l1["_keep"][0], l2["_keep"][0]
     assert not T1["chain"] and T2["chain"]
-    assert float(l2["total_loss"]) == pytest.approx(float(l1["total_loss"]), rel=2e-4)
-    assert int((l1["ece_bin_counts"] - l2["ece_bin_counts"]).abs().sum()) <= 2
-    for key in ("E", "VV", "S", "X", "H1", "H2", "AV", "T", "R2", "fused", "H0", "H3"):
-        a, c = T1[key].float(), T2[key].float()
-        assert torch.isfinite(c).all(), key
-        scale = float(a.abs().max())
-        assert float((a - c).abs().max()) <= 0.02 * scale, (key, float((a - c).abs().max()), scale)          # a few bf16 ulps
-        assert float((a - c).norm() / a.norm()) < 3e-3, (key, float((a - c).norm() / a.norm()))       # ... on a small fraction of the elements
+    assert float(l2["total_loss"]) == float(l1["total_loss"])
+    assert torch.equal(l1["ece_bin_counts"], l2["ece_bin_counts"])
+    for key in ("E", "VV", "S", "X", "H1", "H2", "pre", "AV", "T", "r", "w4", "u4", "R2", "G", "fused", "fused32", "H0", "H3", "ev", "planes"):
+        assert torch.equal(T1[key], T2[key]), (key, int((T1[key] != T2[key]).sum()))
+    for name in ("av", "tri"):
+        for a, c in zip(T1[name], T2[name]):
+            assert torch.equal(a, c), name
     for t1, t2 in zip(T1["enc"], T2["enc"]):
-        for a, c in zip(t1["h"] + t1["y"], t2["h"] + t2["y"]):
-            assert float((a.float() - c.float()).abs().max()) <= 0.02 * float(a.float().abs().max())
-            assert float((a.float() - c.float()).norm() / a.float().norm()) < 3e-3
+        for a, c in zip(t1["h"] + t1["y"] + [t1["y0"], t1["m0"], t1["r0"]], t2["h"] + t2["y"] + [t2["y0"], t2["m0"], t2["r0"]]):
+            assert torch.equal(a, c)
         for (ma, ra), (mc, rc) in zip(t1["st"], t2["st"]):
-            assert torch.allclose(ma, mc, rtol=1e-3, atol=1e-3) and torch.allclose(ra, rc, rtol=1e-3, atol=1e-3)
+            assert torch.equal(ma, mc) and torch.equal(ra, rc)
     seen = 0
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         g1, g2 = p1.grad.double().flatten(), p2.grad.double().flatten()
@@ -471,8 +472,8 @@ def test_fused_train_step_layer_chains_match_the_launch_by_launch_plan(B):
         if float(g1.norm()) == 0.0:
             assert float(g2.norm()) == 0.0, n
             continue
-        cos, ratio = float((g1 @ g2) / (g1.norm() * g2.norm())), float(g2.norm() / g1.norm())
-        assert cos > 0.998 and 0.95 < ratio < 1.05, (n, cos, ratio)
+        cos = float((g1 @ g2) / (g1.norm() * g2.norm()))
+        assert float((g1 - g2).abs().max()) <= 2e-3 * float(g1.abs().max()) and cos > 1 - 1e-6, (n, float((g1 - g2).abs().max()), float(g1.abs().max()), cos)
         seen += 1
     assert seen >= 100
 

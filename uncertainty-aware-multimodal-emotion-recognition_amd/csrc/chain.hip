@@ -55,6 +55,7 @@
 #include "chain.h"
 #include "options.h"
 #include "nig_dev.h"
+#include "ln_rows.h"
 
 namespace mmdeer {
 namespace {
@@ -195,23 +196,15 @@ struct ChainLnOut {
 };
 
 // sum over the 32 lanes of a wave half, result in every lane of the half
-__device__ __forceinline__ float half_sum(float v, int lane) {
-  v = row_sum(v);
-  v += dpp_read<0x142, 0xA>(v);    // row_bcast:15 -> rows 1 and 3 add the total of the row below
-  const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
-  const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-  return lane < 32 ? lo : hi;
-}
+__device__ __forceinline__ float half_sum(float v, int lane) { return ln_half_sum(v, lane); }
 
 // LayerNorm of a finished panel in place, plus everything the backward pass wants of it: raw rows, normalised rows, fp32
 // copy, mean, rstd.  32 lanes per row (a wave takes two rows, the eight waves of the workgroup 16): lane l of a half owns
-// the 16-byte chunks l, l + 32 of its row.
+// the 16-byte chunks l, l + 32 of its row.  The arithmetic is ln_rows.h's (shared with the stand-alone forward kernel).
 template <int NKT>
 __device__ __forceinline__ void chain_ln(unsigned char* pan, int img, int r, bool valid, long long grow, int lane, const float* vec,
                                          const ChainLnOut& o_, const unsigned char* res) {
-#pragma clang fp contract(off)   // the same arithmetic, operation by operation, as the LayerNorm block of gemm_ln.hip
   constexpr int KD = NKT * 64, NC = NKT / 4;   // chunks per lane
-  constexpr float inv_k = 1.0f / (float)KD;
   const f32x4* gam = reinterpret_cast<const f32x4*>(vec + o_.gb_off);
   const f32x4* bet = gam + KD / 4;
   const int l32 = lane & 31;
@@ -219,42 +212,22 @@ __device__ __forceinline__ void chain_ln(unsigned char* pan, int img, int r, boo
   bf16_t* xln = o_.xln;
   float* out32 = o_.out32;
   const int lds_ = o_.ld_stash;
-  float x[NC * 8];
   unsigned char* cell[NC];
+  u32x4 raw[NC];
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const int c = l32 + 32 * j;               // chunk of the row: image c >> 3, slot (c & 7) ^ (r & 7)
     cell[j] = pan + (c >> 3) * img + r * 128 + (((c & 7) ^ (r & 7)) * 16);
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(cell[j]);
-    if (valid && stash) store_wt16(stash + grow * lds_ + c * 8, raw);
-    x[8 * j + 0] = __uint_as_float(raw.x << 16); x[8 * j + 1] = __uint_as_float(raw.x & 0xFFFF0000u);
-    x[8 * j + 2] = __uint_as_float(raw.y << 16); x[8 * j + 3] = __uint_as_float(raw.y & 0xFFFF0000u);
-    x[8 * j + 4] = __uint_as_float(raw.z << 16); x[8 * j + 5] = __uint_as_float(raw.z & 0xFFFF0000u);
-    x[8 * j + 6] = __uint_as_float(raw.w << 16); x[8 * j + 7] = __uint_as_float(raw.w & 0xFFFF0000u);
+    raw[j] = *reinterpret_cast<const u32x4*>(cell[j]);
+    if (valid && stash) store_wt16(stash + grow * lds_ + c * 8, raw[j]);
   }
-  // Row statistics in the order gemm_ln.hip uses (so both launch plans give the same bits): per 8-element chunk a fixed tree,
-  // q[g] = chunk of image g + chunk of image g + 4, t[g] = sum of q[g] over the 8 chunk positions (DPP), (t0 + t1) + (t2 + t3).
-  // Here lane (g = l32 >> 3, position l32 & 7) owns exactly the two chunks of q[g].
-  auto chunk_sum = [](const float* v) -> float { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); };
-  float q = chunk_sum(x);
-  if constexpr (NC == 2) q += chunk_sum(x + 8);
-  const float mu = half_sum(q, lane) * inv_k;
-  float d[NC * 8];
-#pragma unroll
-  for (int e = 0; e < NC * 8; ++e) { const float t = x[e] - mu; d[e] = t * t; }
-  float qv = chunk_sum(d);
-  if constexpr (NC == 2) qv += chunk_sum(d + 8);
-  const float var = half_sum(qv, lane) * inv_k;
-  const float rs = 1.0f / __builtin_sqrtf(var + 1e-5f);
+  float x[NC * 8], mu, rs;
+  ln_row_stats<NC>(raw, lane, x, mu, rs);
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const int c = l32 + 32 * j;
-    const f32x4 ga = gam[2 * c], gb2 = gam[2 * c + 1], ba = bet[2 * c], bb = bet[2 * c + 1];
     float o[8];
-    o[0] = (x[8 * j + 0] - mu) * rs * ga.x + ba.x; o[1] = (x[8 * j + 1] - mu) * rs * ga.y + ba.y;
-    o[2] = (x[8 * j + 2] - mu) * rs * ga.z + ba.z; o[3] = (x[8 * j + 3] - mu) * rs * ga.w + ba.w;
-    o[4] = (x[8 * j + 4] - mu) * rs * gb2.x + bb.x; o[5] = (x[8 * j + 5] - mu) * rs * gb2.y + bb.y;
-    o[6] = (x[8 * j + 6] - mu) * rs * gb2.z + bb.z; o[7] = (x[8 * j + 7] - mu) * rs * gb2.w + bb.w;
+    ln_chunk_out(x + 8 * j, mu, rs, gam[2 * c], gam[2 * c + 1], bet[2 * c], bet[2 * c + 1], o);
     u32x4 packed{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
     if (res) {
       // residual block (reference complete_project.py:73, x + LayerNorm(...)): the layer's input panel has the geometry of this one;

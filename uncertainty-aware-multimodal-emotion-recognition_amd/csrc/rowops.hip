@@ -1,6 +1,7 @@
 // Row-wise HBM-bound kernels for gfx950: every global access is an 8- or 16-byte vector per lane,
 // one wave (64 lanes) owns one row, reductions are wave shuffles (no LDS on the per-row path).
 #include "rowops.h"
+#include "ln_rows.h"
 
 namespace mmdeer {
 
@@ -150,6 +151,40 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* y, void* out, f
       if (out32) *reinterpret_cast<f32x4*>(out32 + base + c) = o;
     }
   }
+}
+
+// bf16 rows of 256 or 512 columns: 32 lanes per row (two rows per wave, eight per block), the arithmetic of ln_rows.h -- the statement
+// the layer-chain kernel executes on its LDS panel (chain.hip: chain_ln), so a LayerNorm gives the same bits as a launch of its own and
+// as a layer end of a chain (Stack B's chain plan against its launch-by-launch plan: tests/test_gpu_stackb.py).
+template <int NC>
+__global__ __launch_bounds__(256) void ln_fwd_rows2_kernel(const bf16_t* y, bf16_t* out, float* out32, float* mean, float* rstd,
+                                                           const float* gamma, const float* beta, int M) {
+  constexpr int KD = NC * 256;
+  const int lane = threadIdx.x & 63, l32 = lane & 31;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + (lane >> 5);
+  const bool valid = row < M;
+  const long long base = (long long)(valid ? row : M - 1) * KD;      // clamped: no load under a per-lane branch
+  u32x4 raw[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) raw[j] = *reinterpret_cast<const u32x4*>(y + base + (l32 + 32 * j) * 8);
+  float x[NC * 8], mu, rs;
+  ln_row_stats<NC>(raw, lane, x, mu, rs);
+  const f32x4* gam = reinterpret_cast<const f32x4*>(gamma);
+  const f32x4* bet = reinterpret_cast<const f32x4*>(beta);
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int c = l32 + 32 * j;
+    float o[8];
+    ln_chunk_out(x + 8 * j, mu, rs, gam[2 * c], gam[2 * c + 1], bet[2 * c], bet[2 * c + 1], o);
+    if (valid) {
+      *reinterpret_cast<u32x4*>(out + base + c * 8) = u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+      if (out32) {
+        *reinterpret_cast<f32x4*>(out32 + base + c * 8) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(out32 + base + c * 8 + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      }
+    }
+  }
+  if (valid && l32 == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
 // ------------------------------------------------------------------ LayerNorm backward (+ ReLU/dropout mask)
@@ -366,6 +401,16 @@ int launch_ln_fwd(const void* y, void* out, float* out32, float* mean, float* rs
                   const float* beta, int M, int N, int act_f32, hipStream_t s) {
   MMDEER_CHECK(N % 4 == 0 && N <= LN_MAX_VEC * 256, "layernorm: N=%d unsupported (multiple of 4, <= 1024)", N);
   if (M == 0) return 0;
+  if (!act_f32 && (N == 256 || N == 512)) {
+    MMDEER_CHECK(((uintptr_t)y % 16) == 0 && ((uintptr_t)out % 16) == 0 && (!out32 || ((uintptr_t)out32 % 16) == 0) && ((uintptr_t)gamma % 16) == 0 &&
+                     ((uintptr_t)beta % 16) == 0, "layernorm: 16-byte aligned rows / vectors");
+    const bf16_t* yb = reinterpret_cast<const bf16_t*>(y);
+    bf16_t* ob = reinterpret_cast<bf16_t*>(out);
+    if (N == 256) hipLaunchKernelGGL(ln_fwd_rows2_kernel<1>, dim3((M + 7) / 8), dim3(256), 0, s, yb, ob, out32, mean, rstd, gamma, beta, M);
+    else hipLaunchKernelGGL(ln_fwd_rows2_kernel<2>, dim3((M + 7) / 8), dim3(256), 0, s, yb, ob, out32, mean, rstd, gamma, beta, M);
+    MMDEER_HIP(hipGetLastError());
+    return 0;
+  }
   const int grid = (M + 3) / 4;
 #define LN_FWD(F, NV, EX) hipLaunchKernelGGL((ln_fwd_kernel<F, NV, EX>), dim3(grid), dim3(256), 0, s, y, out, out32, mean, rstd, gamma, beta, M, N)
   if (act_f32) { if (N == 256) LN_FWD(true, 1, true); else if (N == 512) LN_FWD(true, 2, true); else LN_FWD(true, LN_MAX_VEC, false); }
