@@ -279,7 +279,7 @@ int mmdeer_pack_transposed_batch(int n, const float* const* src, const int32_t* 
 /* nn.LayerNorm(N), eps 1e-5 (fusion.py:102, 220, 305) */
 int mmdeer_layernorm_fwd(const void* y, void* out, float* out32, float* mean, float* rstd, const float* gamma,
                          const float* beta, int M, int N, int act_f32, void* stream);
-int mmdeer_layernorm_bwd_nparts(int M);
+int mmdeer_layernorm_bwd_nparts(int M);   /* ceil(M / 16): one partial slab per 16 consecutive rows */
 /* dz = (y > 0) * mask_scale * LayerNorm'(dout): the ReLU (+ dropout, mask_scale = 1 / (1 - p)) of the Linear-ReLU-Dropout-LayerNorm
  * blocks folded in; mask_scale <= 0: no mask (a LayerNorm behind a plain Linear, encoders.py:113-114).  partial: scratch of
  * mmdeer_layernorm_bwd_nparts(M) * 2 * N floats ([part][d gamma row | d beta row]); with dgamma = dbeta = NULL the fold of

@@ -433,13 +433,11 @@ def test_fused_train_step_equals_the_autograd_path(compute, B):
 def test_fused_train_step_layer_chains_match_the_launch_by_launch_plan(B):
     """the bf16 fused step runs its sample-local layer runs (residual encoders, attention value / output
     projections, estimator, fusion stages, evidence heads -- complete_project.py:60-118, 120-184, 307-418 -- and their dX runs) as
-    launches of the layer-chain kernel (mmdeer_chain).  The FORWARD is the launch-by-launch plan's bit for bit: every tensor of the
-    tape (activations, pre-LayerNorm rows, LayerNorm statistics, evidence), the loss, the ECE bin counts -- GEMM accumulation order,
-    epilogues, dropout masks and (csrc/ln_rows.h) the LayerNorm arithmetic are one statement executed by both plans.  The backward's
-    dX products and masks are the same too; its LayerNorm backward sums the two row means in another lane order (1 fp32 ulp, now and
-    then a flipped bf16 rounding of a dz element), the LayerNorm gamma / beta partials are grouped per workgroup, and the audio input
-    projection's weight gradient runs on another kernel (padded rows): gradients agree to 2e-3 of each tensor's largest element with
-    cosine 1 - 1e-6."""
+    launches of the layer-chain kernel (mmdeer_chain).  It is the launch-by-launch plan BIT FOR BIT, forward and backward: every tensor
+    of the tape (activations, pre-LayerNorm rows, LayerNorm statistics, evidence), the loss, the ECE bin counts and every gradient.
+    GEMM accumulation order, epilogues and dropout masks the chain kernel shares with the GEMM kernels; the LayerNorm forward /
+    backward row arithmetic and the fold of the gamma / beta partials over 16-row groups are one statement (csrc/ln_rows.h) executed by
+    the chain on its LDS panel and by the stand-alone bf16 kernels on rows in memory."""
     import copy
     m1, _ = _train_model("bf16")
     m2 = copy.deepcopy(m1)
@@ -467,14 +465,9 @@ def test_fused_train_step_layer_chains_match_the_launch_by_launch_plan(B):
             assert torch.equal(ma, mc) and torch.equal(ra, rc)
     seen = 0
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
-        g1, g2 = p1.grad.double().flatten(), p2.grad.double().flatten()
-        assert torch.isfinite(g2).all(), n
-        if float(g1.norm()) == 0.0:
-            assert float(g2.norm()) == 0.0, n
-            continue
-        cos = float((g1 @ g2) / (g1.norm() * g2.norm()))
-        assert float((g1 - g2).abs().max()) <= 2e-3 * float(g1.abs().max()) and cos > 1 - 1e-6, (n, float((g1 - g2).abs().max()), float(g1.abs().max()), cos)
-        seen += 1
+        assert torch.isfinite(p2.grad).all(), n
+        assert torch.equal(p1.grad, p2.grad), (n, float((p1.grad - p2.grad).abs().max()), float(p1.grad.abs().max()))
+        seen += float(p1.grad.abs().max()) > 0
     assert seen >= 100
 
 

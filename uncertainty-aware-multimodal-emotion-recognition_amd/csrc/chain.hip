@@ -259,97 +259,41 @@ struct ChainLnbIn {
   float mu, rs;
 };
 
-// LayerNorm BACKWARD of a finished 16-row panel in place (ln_bwd_kernel of rowops.hip restated on the panel): d = panel,
-// xhat = (y - mean) rstd, g = d gamma, dy = (g - mean(g) - xhat mean(g xhat)) rstd, masked by (y > 0) * scale when the
-// LayerNorm sits behind Linear-ReLU-Dropout; dz replaces d in the panel and goes to the workspace.  The column sums of
-// d xhat and d over the workgroup's rows (gamma / beta gradients) are formed deterministically: each wave adds its two rows
-// in LDS (lower half writes, upper half reads and adds -- one wave's LDS operations execute in order), the workgroup's eight waves are
-// summed column by column in a fixed order.  `red` = 16 KiB of LDS (the idle input panel).
-// Row part (one call per 16-row pass): dz of this lane's row; its d * xhat and d are ADDED to gacc / bacc (this lane's chunks,
-// summed over the passes -- a 32-row panel is two passes).  Fold part: chain_ln_bwd_fold.
+// LayerNorm BACKWARD of a finished 16-row panel in place: d = panel, dz replaces d in the panel and goes to the workspace; the row
+// arithmetic and the fold of the gamma / beta partials are ln_rows.h's (shared with the stand-alone bf16 kernel ln_bwd_rows16_kernel of
+// rowops.hip).  Row part (one call per 16-row pass): dz of this lane's row; its d * xhat and d are ADDED to gacc / bacc (this lane's
+// chunks, summed over the passes -- a 32-row panel is two passes).  `red` of the fold = 16 KiB x NKT / 4 of LDS scratch.
 template <int NKT>
 __device__ __forceinline__ void chain_ln_bwd(unsigned char* pan, int img, int lane, int r, bool valid, long long grow, const float* gam,
                                              const ChainLnbIn& in, float ms, bf16_t* dz, float (&gacc)[NKT * 2], float (&bacc)[NKT * 2]) {
-#pragma clang fp contract(off)
   constexpr int KD = NKT * 64, NC = NKT / 4;
-  constexpr float inv_k = 1.0f / (float)KD;
   const int l32 = lane & 31;
-  float d[NC * 8], xh[NC * 8], gd[NC * 8], yy[NC * 8];
   unsigned char* cell[NC];
-  float s1 = 0.f, s2 = 0.f;
+  u32x4 draw[NC], yraw[NC], packed[NC];
+  float gg[NC * 8];
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const int c = l32 + 32 * j;
     cell[j] = pan + (c >> 3) * img + r * 128 + (((c & 7) ^ (r & 7)) * 16);
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(cell[j]);
-    const u32x4 yr = in.y[j];
-    const unsigned dw[4] = {raw.x, raw.y, raw.z, raw.w}, yw[4] = {yr.x, yr.y, yr.z, yr.w};
+    draw[j] = *reinterpret_cast<const u32x4*>(cell[j]);
+    yraw[j] = in.y[j];
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam + 8 * c), g1 = *reinterpret_cast<const f32x4*>(gam + 8 * c + 4);
-    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      d[8 * j + 2 * e] = __uint_as_float(dw[e] << 16); d[8 * j + 2 * e + 1] = __uint_as_float(dw[e] & 0xFFFF0000u);
-      yy[8 * j + 2 * e] = __uint_as_float(yw[e] << 16); yy[8 * j + 2 * e + 1] = __uint_as_float(yw[e] & 0xFFFF0000u);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      xh[8 * j + e] = (yy[8 * j + e] - in.mu) * in.rs;
-      gd[8 * j + e] = d[8 * j + e] * gg[e];
-      s1 += gd[8 * j + e];
-      s2 += gd[8 * j + e] * xh[8 * j + e];
-    }
+    gg[8 * j] = g0.x; gg[8 * j + 1] = g0.y; gg[8 * j + 2] = g0.z; gg[8 * j + 3] = g0.w;
+    gg[8 * j + 4] = g1.x; gg[8 * j + 5] = g1.y; gg[8 * j + 6] = g1.z; gg[8 * j + 7] = g1.w;
   }
-  const float m1 = half_sum(s1, lane) * inv_k, m2 = half_sum(s2, lane) * inv_k;
+  ln_bwd_row<NC>(draw, yraw, gg, in.mu, in.rs, ms, lane, valid ? 1.f : 0.f, packed, gacc, bacc);
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const int c = l32 + 32 * j;
-    float o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float dy = (gd[8 * j + e] - m1 - xh[8 * j + e] * m2) * in.rs;
-      o[e] = ms > 0.f ? (yy[8 * j + e] > 0.f ? dy * ms : 0.f) : dy;
-    }
-    const u32x4 packed{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
-    *reinterpret_cast<u32x4*>(cell[j]) = packed;
-    if (valid) store_wt16(dz + grow * KD + c * 8, packed);
+    *reinterpret_cast<u32x4*>(cell[j]) = packed[j];
+    if (valid) store_wt16(dz + grow * KD + c * 8, packed[j]);
   }
-  // ---- gamma / beta contributions of this row (rows past the batch contribute nothing)
-  const float live = valid ? 1.f : 0.f;
-#pragma unroll
-  for (int e = 0; e < NC * 8; ++e) { gacc[e] += d[e] * xh[e] * live; bacc[e] += d[e] * live; }
 }
 
-// gamma / beta partial sums over the workgroup's rows from the lanes' accumulated contributions: every lane writes its row's
-// contribution to `red` (16 rows x KD floats of LDS scratch), one barrier, then thread `col` adds the 16 rows of its column in a
-// fixed order -- (row 2w + row 2w + 1) per wave pair of rows, then ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)) -- the order of the
-// first version of this fold, which paired the rows through dependent LDS read-modify-writes (4.1k cycles per LayerNorm; stamps).
 template <int NKT>
 __device__ __forceinline__ void chain_ln_bwd_fold(float* red, int wave, int lane, int tid, const float (&gacc)[NKT * 2],
                                                   const float (&bacc)[NKT * 2], float* slab) {
-#pragma clang fp contract(off)
-  constexpr int KD = NKT * 64, NC = NKT / 4;
-  const int l32 = lane & 31;
-  float* mine = red + (2 * wave + (lane >> 5)) * KD;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      const int c = l32 + 32 * j;
-      f32x4* dst = reinterpret_cast<f32x4*>(mine + 8 * c);
-      if (pass == 0) { dst[0] = f32x4{gacc[8 * j], gacc[8 * j + 1], gacc[8 * j + 2], gacc[8 * j + 3]}; dst[1] = f32x4{gacc[8 * j + 4], gacc[8 * j + 5], gacc[8 * j + 6], gacc[8 * j + 7]}; }
-      else { dst[0] = f32x4{bacc[8 * j], bacc[8 * j + 1], bacc[8 * j + 2], bacc[8 * j + 3]}; dst[1] = f32x4{bacc[8 * j + 4], bacc[8 * j + 5], bacc[8 * j + 6], bacc[8 * j + 7]}; }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int col = tid; col < KD; col += 512) {
-      float w[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) w[q] = red[(2 * q) * KD + col] + red[(2 * q + 1) * KD + col];
-      slab[pass * KD + col] = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();      // everyone has read `red` before the next pass (or the next LayerNorm) overwrites it
-  }
+  ln_bwd_fold16<NKT / 4>(red, wave, lane, tid, gacc, bacc, slab);
 }
 
 // The head's last-layer backward as the prologue of a backward chain (ChainNig, chain.h): the arithmetic of nig_bwd_kernel

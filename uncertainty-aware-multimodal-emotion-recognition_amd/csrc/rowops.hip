@@ -187,6 +187,40 @@ __global__ __launch_bounds__(256) void ln_fwd_rows2_kernel(const bf16_t* y, bf16
   if (valid && l32 == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// bf16 rows of 256 or 512 columns, backward: a workgroup of 8 waves takes 16 consecutive rows (two per wave, 32 lanes per row) -- the
+// geometry of a 16-sample layer-chain workgroup --, the row arithmetic and the fold of the gamma / beta partials are ln_rows.h's: dz and
+// the partial slab [block][2][N] come out bit for bit as from the chain's layer end (chain.hip: chain_ln_bwd).
+template <int NC>
+__global__ __launch_bounds__(512) void ln_bwd_rows16_kernel(const bf16_t* dout, const bf16_t* y, const float* mean, const float* rstd, const float* gamma,
+                                                            bf16_t* dz, float* partial, int M, float mask_scale) {
+  constexpr int KD = NC * 256;
+  __shared__ __attribute__((aligned(16))) float red[16 * KD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31;
+  const int row = blockIdx.x * 16 + 2 * wave + (lane >> 5);
+  const bool valid = row < M;
+  const int rr = valid ? row : M - 1;                 // clamped: no load under a per-lane branch
+  const long long base = (long long)rr * KD;
+  u32x4 draw[NC], yraw[NC], packed[NC];
+  float gg[NC * 8], gacc[NC * 8], bacc[NC * 8];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int c = l32 + 32 * j;
+    draw[j] = *reinterpret_cast<const u32x4*>(dout + base + c * 8);
+    yraw[j] = *reinterpret_cast<const u32x4*>(y + base + c * 8);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + 8 * c), g1 = *reinterpret_cast<const f32x4*>(gamma + 8 * c + 4);
+    gg[8 * j] = g0.x; gg[8 * j + 1] = g0.y; gg[8 * j + 2] = g0.z; gg[8 * j + 3] = g0.w;
+    gg[8 * j + 4] = g1.x; gg[8 * j + 5] = g1.y; gg[8 * j + 6] = g1.z; gg[8 * j + 7] = g1.w;
+  }
+#pragma unroll
+  for (int e = 0; e < NC * 8; ++e) gacc[e] = bacc[e] = 0.f;
+  ln_bwd_row<NC>(draw, yraw, gg, mean[rr], rstd[rr], mask_scale, lane, valid ? 1.f : 0.f, packed, gacc, bacc);
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) *reinterpret_cast<u32x4*>(dz + base + (l32 + 32 * j) * 8) = packed[j];
+  }
+  ln_bwd_fold16<NC>(red, wave, lane, tid, gacc, bacc, partial + (long long)blockIdx.x * 2 * KD);
+}
+
 // ------------------------------------------------------------------ LayerNorm backward (+ ReLU/dropout mask)
 template <bool F32, int NV, bool EXACT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dout, const void* y, const float* mean, const float* rstd,
@@ -420,16 +454,28 @@ int launch_ln_fwd(const void* y, void* out, float* out32, float* mean, float* rs
   return 0;
 }
 
+// one partial slab per 16 rows (uncapped since round 4: the bf16 kernel below and the layer chains both sum 16 consecutive rows per
+// workgroup, so that the two give the same gamma / beta gradients bit for bit)
 int ln_bwd_nparts(int M) {
-  int g = (M + 15) / 16;
-  if (g < 1) g = 1;
-  return g > 256 ? 256 : g;
+  const int g = (M + 15) / 16;
+  return g < 1 ? 1 : g;
 }
 
 int launch_ln_bwd(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
                   void* dz, float* partial, int M, int N, int act_f32, float mask_scale, hipStream_t s) {
   MMDEER_CHECK(N % 4 == 0 && N <= LN_MAX_VEC * 256, "layernorm: N=%d unsupported (multiple of 4, <= 1024)", N);
   const int grid = ln_bwd_nparts(M);
+  if (!act_f32 && (N == 256 || N == 512) && M > 0) {
+    MMDEER_CHECK(((uintptr_t)dout % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)dz % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)partial % 16) == 0,
+                 "layernorm backward: 16-byte aligned rows / vectors");
+    const bf16_t* db = reinterpret_cast<const bf16_t*>(dout);
+    const bf16_t* yb = reinterpret_cast<const bf16_t*>(y);
+    bf16_t* zb = reinterpret_cast<bf16_t*>(dz);
+    if (N == 256) hipLaunchKernelGGL(ln_bwd_rows16_kernel<1>, dim3(grid), dim3(512), 0, s, db, yb, mean, rstd, gamma, zb, partial, M, mask_scale);
+    else hipLaunchKernelGGL(ln_bwd_rows16_kernel<2>, dim3(grid), dim3(512), 0, s, db, yb, mean, rstd, gamma, zb, partial, M, mask_scale);
+    MMDEER_HIP(hipGetLastError());
+    return 0;
+  }
 #define LN_BWD(F, NV, EX) hipLaunchKernelGGL((ln_bwd_kernel<F, NV, EX>), dim3(grid), dim3(256), 0, s, dout, y, mean, rstd, gamma, dz, partial, M, N, mask_scale)
   if (act_f32) { if (N == 256) LN_BWD(true, 1, true); else if (N == 512) LN_BWD(true, 2, true); else LN_BWD(true, LN_MAX_VEC, false); }
   else { if (N == 256) LN_BWD(false, 1, true); else if (N == 512) LN_BWD(false, 2, true); else LN_BWD(false, LN_MAX_VEC, false); }

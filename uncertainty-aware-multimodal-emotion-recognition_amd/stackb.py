@@ -456,10 +456,10 @@ class CompleteDEERModel(nn.Module):
         # bf16 compute: the feature blocks are rounded to bf16 once here (the GEMM loaders would round them on the fly anyway)
         # so that the input-projection weight gradients run on the LDS-DMA kernel with the rest of their group
         xdt = torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
-        lean = st.get("frag") is not None and getattr(self, "train_plan", "auto") != "ops"
+        lean = self.compute_dtype == "bf16"       # (both plans of the bf16 step: the same weight-gradient kernel for the input projection)
         xs = [x.detach() if (lean and x.shape[1] % 64) else x.detach().to(xdt).contiguous() for x in xs]
         if lean:
-            # layer-chain plan: rows of a width the chain's DMA cannot take (the 84-wide audio block) live in a persistent buffer
+            # bf16 step: rows of a width the chain's DMA cannot take (the 84-wide audio block) live in a persistent buffer
             # zero-padded to a multiple of 64 columns -- one converting copy per step, and the input projection's weight gradient
             # reads 16-byte aligned rows
             for i, x in enumerate(xs):

@@ -490,7 +490,7 @@ def backward(model, T: Dict, g4: torch.Tensor, flat=None) -> Dict[str, torch.Ten
     dSX = new(3 * B, 2 * ENC) if Fg is not None else None        # chain plan: [d self | d cross], the input rows of the attention dX run
     dX = dSX[:, ENC:] if Fg is not None else new(3 * B, ENC)
     a.ld_dcross = 2 * ENC if Fg is not None else 0
-    unc8 = new(B, 8) if (Fg is not None and B >= 2) else None     # the uncertainties as a bf16 GEMM operand (a by-product of the kernel below)
+    unc8 = new(B, 8) if (flat is not None and not f32 and B >= 2) else None     # the uncertainties as a bf16 GEMM operand (a by-product of the kernel below; both plans of the bf16 fused step)
     a.unc8 = _ptr(unc8)
     dlog8, dz8e, dh2 = new(B, 8), new(3 * B, 8), new(3 * B, ENC // 4)
     a.d_av, a.d_text = dAV.data_ptr(), dtext.data_ptr()
