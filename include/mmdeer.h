@@ -630,8 +630,9 @@ int mmdeer_stackb_forward(const mmdeer_stackb_forward_args* a);
  * the nn.Linear weight; dX = dY W: its transpose [K_lin][N_lin], i.e. N = in_features, K = out_features).
  * A layer is one or more segments writing disjoint column ranges of one output panel; the last carries end_layer = 1.
  * Limits: <= MMDEER_CHAIN_MAX_SEGS segments, 8 layers, 16 bias / gamma / beta vectors of 4864 floats in total; N % 64 == 0,
- * K in {64, 128, 256, 384, 512, 768 (16-sample workgroups, one row block only)}, N % 128 == 0 or K % 128 == 0, <= 4 column tiles
- * (of 128, or 64 when N % 128 != 0) per segment; panel width <= 768 columns (16-sample workgroups) or 512 (32-sample). */
+ * K in {64, 128, 256, 384, 512, 768 (16-sample workgroups only)}; <= 4 column tiles per segment, of 128 columns, or of 64 when
+ * N % 128 != 0 (then K must be 128 or 256); panel width <= 768 columns (16-sample workgroups) or 512 (32-sample).  Anything else
+ * is refused with a message before a launch. */
 #define MMDEER_CHAIN_MAX_SEGS 12
 typedef struct mmdeer_chain_seg {
   const void* W;            /* fragment-major image of the segment's [N][K] bf16 matrix */

@@ -512,6 +512,97 @@ def test_layer_chain_operator_against_torch(rows, ts):
     assert torch.allclose(m0, ry0.mean(1), atol=1e-4) and torch.allclose(r0, 1 / torch.sqrt(ry0.var(1, unbiased=False) + 1e-5), rtol=1e-4)
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_layer_chain_operator_random_tables(seed):
+    """mmdeer_chain over randomly drawn segment tables (every instantiated depth K / 64 in {1, 2, 4, 6, 8, 12}, 64- and 128-column tiles,
+    layers of one to three segments writing column ranges of one panel and reading column ranges of the previous one, ReLU, masks,
+    LayerNorm with and without the residual, ragged row counts, both workgroup sizes) against plain PyTorch on the same
+    bf16-rounded operands."""
+    from mmdeer.chainops import Chain, FragImages
+    from mmdeer.opseq import Exec
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(100 + seed)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    ts = int(rng.choice([16, 32]))
+    cap = 768 if ts == 16 else 512
+    rows = int(rng.integers(1, 5 * ts))
+    K0 = int(rng.choice([64, 128, 256, 384, 512] + ([768] if ts == 16 else [])))
+    x = rnd(rows, K0).bfloat16()
+    F = FragImages(dev)
+    layers, width = [], K0
+    for li in range(int(rng.integers(2, 5))):
+        segs, nout = [], 0
+        ln = bool(rng.integers(0, 2))
+        nseg = 1 if ln else int(rng.integers(1, 4))
+        for si in range(nseg):
+            # K: a window of the input panel; N: multiples of 64 (64-column tiles, N % 128 != 0, exist for K = 128 and 256)
+            ks = [k for k in (64, 128, 256, 384, 512, 768) if k <= width and (k != 768 or ts == 16)]
+            K = int(rng.choice(ks))
+            kin = int(rng.integers(0, (width - K) // 64 + 1)) * 64
+            ns = [n for n in ((256, 512) if ln else (64, 128, 192, 256, 384, 512)) if nout + n <= cap and (n % 128 == 0 or K in (128, 256)) and (n // (128 if n % 128 == 0 else 64)) <= 4]
+            if not ns:
+                break
+            N = int(rng.choice(ns))
+            W = rnd(N, K, sc=1.0 / np.sqrt(K)).bfloat16()
+            b = rnd(N, sc=0.2) if rng.integers(0, 2) else None
+            relu = int(rng.integers(0, 2))
+            mask = rnd(rows, N).bfloat16() if (rng.integers(0, 3) == 0 and not ln) else None
+            key = f"w{li}.{si}"
+            F.add(key, W, N, K)
+            segs.append(dict(key=key, W=W, b=b, N=N, K=K, kin=kin, nout_off=nout, relu=relu, mask=mask, ms=float(rng.choice([1.0, 1.25]))))
+            nout += N
+        if not segs:
+            break
+        residual = bool(ln and nout == width and rng.integers(0, 2))
+        gam, bet = (1 + rnd(nout, sc=0.1), rnd(nout, sc=0.1)) if ln else (None, None)
+        layers.append(dict(segs=segs, nout=nout, ln=ln, residual=residual, gam=gam, bet=bet))
+        width = nout
+    F.finish(); F.refresh()
+    ex = Exec("bf16", None)
+    ch = Chain(ex, x, K0, K0, rows, ts=ts)
+    new = lambda *s, d=torch.bfloat16: torch.zeros(*s, dtype=d, device=dev)
+    outs = []
+    for L in layers:
+        for sg in L["segs"]:
+            ch.seg(F(sg["key"]), sg["N"], sg["K"], bias=sg["b"], relu=sg["relu"], kin=sg["kin"], nout_off=sg["nout_off"],
+                   mask=sg["mask"], ldm=sg["N"], mscale=sg["ms"])
+        y = new(rows, L["nout"])
+        if L["ln"]:
+            h, m, r = new(rows, L["nout"]), new(rows, d=torch.float32), new(rows, d=torch.float32)
+            ch.end(L["nout"], stash=y, ld_stash=L["nout"], ln=(L["gam"], L["bet"], h, m, r), residual=int(L["residual"]))
+            outs.append((y, h))
+        else:
+            ch.end(L["nout"], stash=y, ld_stash=L["nout"])
+            outs.append((y, None))
+    ch.launch()
+    torch.cuda.synchronize()
+    bf = lambda t: t.bfloat16().float()
+    cur = x.float()
+    for L, (y, h) in zip(layers, outs):
+        ref = torch.zeros(rows, L["nout"], device=dev)
+        for sg in L["segs"]:
+            v = cur[:, sg["kin"]:sg["kin"] + sg["K"]] @ sg["W"].float().T
+            if sg["b"] is not None:
+                v = v + sg["b"]
+            if sg["relu"]:
+                v = torch.relu(v)
+            if sg["mask"] is not None:
+                v = torch.where(sg["mask"].float() > 0, v * sg["ms"], torch.zeros_like(v))
+            ref[:, sg["nout_off"]:sg["nout_off"] + sg["N"]] = v
+        ref = bf(ref)
+        scale = max(float(ref.abs().max()), 1e-3)
+        assert float((y.float() - ref).abs().max()) <= 2e-2 * scale, ("pre", seed, float((y.float() - ref).abs().max()), scale)
+        if L["ln"]:
+            n = bf(torch.nn.functional.layer_norm(y.float(), (L["nout"],), L["gam"], L["bet"], 1e-5))      # from the chain's own rows: no compounding
+            if L["residual"]:
+                n = bf(n + cur)
+            assert float((h.float() - n).abs().max()) <= 2e-2 * max(float(n.abs().max()), 1e-3), ("ln", seed)
+            cur = h.float()
+        else:
+            cur = y.float()
+
+
 def test_layer_chain_operator_refuses_what_it_does_not_instantiate():
     """mmdeer_chain validates its tables on the host: unsupported widths, panels that do not fit, a residual on a layer that changes
     the geometry all fail with a message instead of launching."""
