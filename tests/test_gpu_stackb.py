@@ -603,6 +603,52 @@ def test_layer_chain_operator_random_tables(seed):
             cur = y.float()
 
 
+def test_repack_operator_writes_the_documented_layouts():
+    """mmdeer_repack against the index formulas of include/mmdeer.h / csrc/chain.h, restated in numpy: fragment-major images of S and
+    of S^T (16-byte granule ((wt * (K / 64) + kt) * 2 + c) * 64 + lane = M[16 wt + (lane & 15)][64 kt + 32 c + 8 (lane >> 4) .. + 8)),
+    zero columns past cols_valid with an odd source stride (the 84-wide audio projection), row-major placements into a zero-filled
+    area (a column slice, padded rows, a block-diagonal stack) -- what mmdeer/chainops.py: FragImages asks of it."""
+    from mmdeer.chainops import FragImages
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    S = (torch.randn(192, 128, generator=g)).bfloat16().to(dev)
+    A = (torch.randn(32, 84, generator=g)).bfloat16().to(dev)             # 84 valid columns, rows of 84 elements (not 16-byte aligned)
+    Wn = (torch.randn(16, 67, generator=g)).bfloat16().to(dev)            # a 64-column slice of 67-wide rows
+    F = FragImages(dev)
+    F.add("S", S, 192, 128)
+    F.add("S.T", S, 192, 128, transpose=1)                                 # the image of S^T [128][192]
+    F.add("A", A, 32, 128, ld_src=84, cols_valid=84)
+    F.area("slice", 16, 64); F.place("slice", Wn, 16, 64, ld_src=67)
+    F.area("bd", 16, 256)
+    for d in range(2):
+        F.place("bd", S[8 * d:8 * d + 4], 4, 128, row0=8 * d, col0=128 * d)
+    F.finish(); F.refresh()
+    torch.cuda.synchronize()
+
+    def frag(M):                                                            # numpy restatement of the fragment-major order
+        R, K = M.shape
+        out = np.zeros(R * K, dtype=M.dtype)
+        for wt in range(R // 16):
+            for kt in range(K // 64):
+                for c in range(2):
+                    for lane in range(64):
+                        l = ((wt * (K // 64) + kt) * 2 + c) * 64 + lane
+                        r, k0 = 16 * wt + (lane & 15), 64 * kt + 32 * c + 8 * (lane >> 4)
+                        out[8 * l:8 * l + 8] = M[r, k0:k0 + 8]
+        return out
+    raw = lambda t: t.cpu().view(torch.int16).numpy()
+    assert np.array_equal(raw(F("S")), frag(raw(S)))
+    assert np.array_equal(raw(F("S.T")), frag(np.ascontiguousarray(raw(S).T)))
+    assert np.array_equal(raw(F("S", 64)), frag(raw(S)[64:]))              # a sub-image: 16-row blocks of the matrix are contiguous
+    Ap = np.zeros((32, 128), dtype=np.int16); Ap[:, :84] = raw(A)
+    assert np.array_equal(raw(F("A")), frag(Ap))
+    assert np.array_equal(raw(F.mat("slice")), raw(Wn)[:, :64])
+    bd = np.zeros((16, 256), dtype=np.int16)
+    for d in range(2):
+        bd[8 * d:8 * d + 4, 128 * d:128 * d + 128] = raw(S)[8 * d:8 * d + 4]
+    assert np.array_equal(raw(F.mat("bd")), bd)
+
+
 def test_layer_chain_operator_refuses_what_it_does_not_instantiate():
     """mmdeer_chain validates its tables on the host: unsupported widths, panels that do not fit, a residual on a layer that changes
     the geometry all fail with a message instead of launching."""
