@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--output_dir", default="./results")
     ap.add_argument("--compute_dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--graph", action="store_true", help="replay the training step as a captured HIP graph (TrainingConfig.use_graph: "
+                    "one graph per batch shape, the ragged tail batch runs eagerly); GPU only")
     ap.add_argument("--stack", default="c", choices=["c", "b"],
                     help="which class the script's name CompleteDEERModel resolves to: c = multimodal_deer.MultimodalDEER (the model "
                          "the reference trains, fused HIP step), b = complete_project.CompleteDEERModel (operator-sequence training)")
@@ -90,7 +92,7 @@ def main():
     tc = TrainingConfig(learning_rate=cfg["training"]["learning_rate"], batch_size=bs, num_epochs=cfg["training"]["num_epochs"],
                         weight_decay=cfg["training"]["weight_decay"], gradient_clip=cfg["training"]["gradient_clip"],
                         output_dir=os.path.join(exp_dir, "models"), log_dir=os.path.join(exp_dir, "logs"),
-                        checkpoint_dir=os.path.join(exp_dir, "checkpoints"))
+                        checkpoint_dir=os.path.join(exp_dir, "checkpoints"), use_graph=bool(args.graph))
     trainer = DEERTrainer(model, tc, device)
     report = {"config": cfg, "mode": args.mode}
     if args.mode in ("full", "train"):

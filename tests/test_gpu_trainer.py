@@ -280,6 +280,41 @@ def test_trainer_graph_mode_matches_eager_mode(tmp_path, n):
         assert torch.allclose(p1, p2, rtol=1e-4, atol=1e-6), n
 
 
+@pytest.mark.parametrize("n", [96, 100])
+def test_trainer_graph_mode_matches_eager_mode_stack_b(tmp_path, n):
+    """DEERTrainer on Stack B (complete_project.CompleteDEERModel, the model the reference script trains) with use_graph=True: the fused
+    step replayed as a captured HIP graph + FlatAdamW follows the eager trainer's trajectory -- same data, same dropout steps (the
+    capture's one eager warm-up IS the first batch's step), same kernels.  n = 100 leaves a ragged tail batch that runs eagerly between
+    the replays."""
+    import copy
+
+    from torch.utils.data import DataLoader, TensorDataset
+
+    from mmdeer import stackb
+
+    b = synth.make_batch(n, seed=22)
+    ds = TensorDataset(*(torch.from_numpy(b[k]) for k in ("audio", "video", "text", "targets")))
+    m1 = stackb.CompleteDEERModel(stackb.ModelConfig(), compute_dtype="bf16").to("cuda:0")
+    m2 = copy.deepcopy(m1)
+    hist = []
+    for m, graph in ((m1, False), (m2, True)):
+        cfg = TrainingConfig(batch_size=32, num_epochs=1, output_dir=str(tmp_path / f"o{graph}"), log_dir=str(tmp_path / f"l{graph}"),
+                             checkpoint_dir=str(tmp_path / f"c{graph}"), use_graph=graph)
+        tr = DEERTrainer(m, cfg, device="cuda:0")
+        assert tr.fused_b
+        loaders = {"iemocap": DataLoader(ds, batch_size=32, shuffle=False)}
+        h = []
+        for _ in range(3):
+            h.append(tr.train_epoch(loaders)["total_loss"])
+            h.append(tr.validate_epoch(loaders)["val_loss"])
+        hist.append(h)
+        if graph:
+            assert len(tr._graphs_b) == 1
+    assert hist[0] == pytest.approx(hist[1], rel=1e-6)
+    for (name, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1, p2), name
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_graph_replay_with_fused_optimizer_trains(dtype):
     """capture_train_step + FusedAdamW as a training loop: the loss on a fixed batch goes down, every replay draws a

@@ -494,10 +494,13 @@ class CompleteDEERModel(nn.Module):
         d["_keep"] = (T, g4, stats, y)
         return d
 
-    def capture_train_step_fused(self, audio, video, text, targets):
+    def capture_train_step_fused(self, audio, video, text, targets, warmup: int = 2):
         """``train_step_fused`` for this batch shape as ONE HIP graph (fresh dropout masks per replay through the device
         counter).  ``replay(a, v, t, y)`` copies new data into the static inputs and returns the (static) loss dict; the
-        optimiser step (``optim.FlatAdamW.step``: two launches) follows eagerly, as for Stack C."""
+        optimiser step (``optim.FlatAdamW.step``: two launches) follows eagerly, as for Stack C.  The capture is preceded by
+        ``warmup`` eager steps on this batch (each a real training step with the dropout step it would have had); the last
+        one's loss dict is ``replay.first`` and its gradients are in the flat buffer -- a trainer that captures on the first batch of
+        a shape (``warmup=1``) takes them as that batch's step, and the replays continue the same mask stream."""
         dev = audio.device
         # feature blocks handed over in the compute dtype stay in it (bf16 blocks resident in HBM: no conversion launch inside the graph)
         keep = torch.bfloat16 if self.compute_dtype == "bf16" else None
@@ -518,9 +521,10 @@ class CompleteDEERModel(nn.Module):
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        first = None
         with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
+            for _ in range(max(1, int(warmup))):
+                first = step()
                 self._train_step += 1
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(dev)
@@ -543,7 +547,7 @@ class CompleteDEERModel(nn.Module):
             shadow[0] = int(self._train_step) - 1
             return loss
 
-        replay.graph, replay.static_inputs, replay.loss, replay.counter = graph, static, loss, counter
+        replay.graph, replay.static_inputs, replay.loss, replay.counter, replay.first = graph, static, loss, counter, first
         return replay
 
     def _forward_eval(self, audio_features, video_features, text_features) -> Dict[str, torch.Tensor]:

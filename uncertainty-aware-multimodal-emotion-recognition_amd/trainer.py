@@ -32,7 +32,7 @@ class TrainingConfig:
     num_epochs: int = 100
     scheduler_type: str = "cosine"
     fused_optimizer: bool = True   # clip + AdamW + weight pack on the device (optim.FusedAdamW); False: torch.optim.AdamW
-    use_graph: bool = False        # replay train_step as a captured HIP graph for full batches of one shape (needs fused_optimizer)
+    use_graph: bool = False        # replay train_step (Stack B: train_step_fused) as a captured HIP graph for full batches of one shape (needs fused_optimizer)
     warmup_epochs: int = 5
     patience: int = 10
     evidence_weight: float = 1.0
@@ -146,6 +146,20 @@ class DEERTrainer:
             dst.copy_(src, non_blocking=True)
         return replay()
 
+    def _graph_step_b(self, a, v, t, y):
+        """Stack B (fused step): one captured graph per (batch size, dtype); the capture's single eager warm-up IS the first batch's
+        step (same dropout step as the eager trainer would have used), the replays continue the mask stream."""
+        key = (a.shape[0], a.dtype)
+        if not hasattr(self, "_graphs_b"):
+            self._graphs_b = {}
+        replay = self._graphs_b.get(key)
+        if replay is None:
+            if self._graphs_b and key[0] < max(k[0] for k in self._graphs_b):
+                return None                      # a smaller tail batch: not worth a capture
+            replay = self._graphs_b[key] = self.model.capture_train_step_fused(a, v, t, y, warmup=1)
+            return replay.first
+        return replay(a, v, t, y)
+
     # ---- one epoch (training.py:176-245)
     def train_epoch(self, train_loaders: Dict[str, Iterable]) -> Dict[str, float]:
         self.model.train()
@@ -158,7 +172,9 @@ class DEERTrainer:
             for batch in loader:
                 a, v, t, y = unpack_batch(batch, self.device)
                 if self.fused_b:
-                    ld = self.model.train_step_fused(a, v, t, y)
+                    ld = self._graph_step_b(a, v, t, y) if (self.config.use_graph and a.is_cuda) else None
+                    if ld is None:
+                        ld = self.model.train_step_fused(a, v, t, y)
                     norms.append(self.optimizer.step(grad_scale=w))    # weighted_loss = total_loss * weight (:211-212) as a gradient scale
                     bs = a.shape[0]
                     sums += torch.stack([ld[k].double() for k in keys]) * bs
