@@ -148,3 +148,50 @@ def test_step_capture_with_a_live_process_group_and_an_in_graph_exchange():
             assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_stack_b_trainer_with_a_gradient_exchange(tmp_path):
+    """Data parallel for Stack B's fused training step: DEERTrainer exchanges the model's flat gradient buffer between the (replayed)
+    step and FlatAdamW.  On a 1-rank group the mean over ranks is the identity, so the trainer with the communicator (both exchange
+    algorithms, eager and graph mode) must end with exactly the parameters of the trainer without one."""
+    import copy
+
+    import torch.distributed as dist
+    from torch.utils.data import DataLoader, TensorDataset
+
+    from mmdeer import stackb, synth
+    from mmdeer.parallel import BucketedAllReduce
+    from mmdeer.trainer import DEERTrainer, TrainingConfig
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        dev = torch.device("cuda", 0)
+        b = synth.make_batch(96, seed=8)
+        ds = TensorDataset(*(torch.from_numpy(b[k]) for k in ("audio", "video", "text", "targets")))
+        m0 = stackb.CompleteDEERModel(stackb.ModelConfig(), compute_dtype="bf16").to(dev)
+        runs = []
+        for tag, algo, graph in (("none", None, False), ("ar", "allreduce", False), ("rs", "rs_ag", True)):
+            m = copy.deepcopy(m0)
+            comm = None
+            if algo is not None:
+                comm = BucketedAllReduce(device=dev, force=True, payload="fp32")
+                comm.algo = algo
+            cfg = TrainingConfig(batch_size=32, num_epochs=1, output_dir=str(tmp_path / f"o{tag}"), log_dir=str(tmp_path / f"l{tag}"),
+                                 checkpoint_dir=str(tmp_path / f"c{tag}"), use_graph=graph)
+            tr = DEERTrainer(m, cfg, device=dev, comm=comm)
+            assert tr.fused_b
+            loaders = {"iemocap": DataLoader(ds, batch_size=32, shuffle=False)}
+            losses = [tr.train_epoch(loaders)["total_loss"] for _ in range(2)]
+            runs.append((losses, m))
+        for losses, m in runs[1:]:
+            assert losses == pytest.approx(runs[0][0], rel=1e-6)
+            for (n, p1), (_, p2) in zip(runs[0][1].named_parameters(), m.named_parameters()):
+                assert torch.equal(p1, p2), n
+        with pytest.raises(NotImplementedError):
+            m = copy.deepcopy(m0)
+            DEERTrainer(m, TrainingConfig(fused_optimizer=False, output_dir=str(tmp_path / "x"), log_dir=str(tmp_path / "y"), checkpoint_dir=str(tmp_path / "z")),
+                        device=dev, comm=BucketedAllReduce(device=dev, force=True))      # the autograd route has no flat gradient buffer
+    finally:
+        dist.destroy_process_group()

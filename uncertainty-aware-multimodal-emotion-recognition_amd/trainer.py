@@ -68,18 +68,24 @@ class DEERTrainer:
         # local rows -- the mask hash is a function of (dropout_seed, step, site, LOCAL row, column).  Unless the caller chose
         # a dropout_seed, rank r gets seed + 1000003 r (what bench.py does for its ranks).
         world = int(getattr(comm, "world", 1) or 1) if comm is not None else 1
-        if world > 1 and hasattr(model, "config") and getattr(model.config, "dropout_seed", None) is None:
+        if world > 1 and hasattr(model, "config") and getattr(model.config, "dropout_seed", None) in (None, 0):
             import torch.distributed as dist
             rank = int(getattr(comm, "rank", dist.get_rank(getattr(comm, "group", None)) if dist.is_initialized() else 0))
-            model.config.dropout_seed = int(model.config.seed) + 1000003 * rank
+            if getattr(model.config, "dropout_seed", None) is None or rank:      # (Stack B's ModelConfig defaults to 0: rank 0 keeps it)
+                model.config.dropout_seed = int(getattr(model.config, "seed", 0)) + 1000003 * rank
         # Stack B (stackb.CompleteDEERModel) trains through autograd: forward -> compute_loss -> backward into .grad, then
         # clip_grad_norm_ + torch.optim.AdamW exactly as training.py:205-224; Stack C has the fused step + flat buffer
         self.generic = not hasattr(model, "flat_grad")
         # ... unless it offers the fused step (stackb.CompleteDEERModel.train_step_fused: the same operator sequence without
         # autograd, gradients in a flat buffer) and the fused optimiser is wanted: 0.94 ms against 2.95 ms per step at B = 4096
         self.fused_b = self.generic and hasattr(model, "train_step_fused") and bool(self.config.fused_optimizer) and self.device.type == "cuda"
-        if self.generic and comm is not None:
-            raise NotImplementedError("data-parallel training is built for MultimodalDEER (Stack C); Stack B trains on one device")
+        # data parallel: the exchange is one call on the flat gradient buffer between the step and the optimiser -- Stack C's, and the
+        # fused Stack B step's (its flat buffer: CompleteDEERModel._flat); the autograd route of Stack B has no flat buffer
+        if self.generic and comm is not None and not self.fused_b:
+            raise NotImplementedError("data-parallel training needs a flat gradient buffer: MultimodalDEER (Stack C), or Stack B with "
+                                      "fused_optimizer on a GPU")
+        if self.fused_b and getattr(comm, "exact_global", False):
+            raise NotImplementedError("the exact-global loss mode exchanges Stack C's loss statistics inside the step; Stack B trains with DDP semantics")
         self.optimizer = self._create_optimizer()
         self.scheduler = self._create_scheduler()
         self.current_epoch = 0
@@ -175,6 +181,10 @@ class DEERTrainer:
                     ld = self._graph_step_b(a, v, t, y) if (self.config.use_graph and a.is_cuda) else None
                     if ld is None:
                         ld = self.model.train_step_fused(a, v, t, y)
+                    if self.comm is not None:            # mean of the ranks' gradients (DDP semantics), in place on the flat buffer
+                        flat_g = self.model._flat(self.device)["g"]
+                        self.comm.launch(flat_g)
+                        self.comm.wait(flat_g)
                     norms.append(self.optimizer.step(grad_scale=w))    # weighted_loss = total_loss * weight (:211-212) as a gradient scale
                     bs = a.shape[0]
                     sums += torch.stack([ld[k].double() for k in keys]) * bs
