@@ -248,8 +248,8 @@ def bench_stackb_train(args, dev, world, rank):
     """--workload stackb_train: samples/sec of the Stack B (complete_project.CompleteDEERModel) training step -- forward with dropout +
     MultiTaskDEERLoss + backward as ONE HIP graph (the sample-local layer runs as launches of the layer-chain kernel in bf16), and
     beside it the same step with the eager FlatAdamW optimiser step, the launch-by-launch plan of the same model on the same box
-    (--dtype bf16 only) and the launch count of the graph.  Every rank trains its own replica on its own shard (no collective here:
-    the data-parallel exchange of this workload is the trainer's, not the bench's)."""
+    (--dtype bf16 only).  With more than one rank (or the 1-rank rehearsal MMDEER_FORCE_COMM=1) every step ends with the exchange of the
+    model's flat gradient buffer, host-enqueued behind the replayed graph (what DEERTrainer does for Stack B): mean over the ranks."""
     import copy
 
     from mmdeer import stackb, synth
@@ -262,9 +262,23 @@ def bench_stackb_train(args, dev, world, rank):
     if args.dtype == "bf16":
         a, v, t = a.bfloat16(), v.bfloat16(), t.bfloat16()        # bf16 feature blocks resident in HBM, as the north-star line
 
+    force_comm = os.environ.get("MMDEER_FORCE_COMM") == "1" and "RANK" in os.environ
+    comm = None
+    if world > 1 or force_comm:
+        from mmdeer.parallel import BucketedAllReduce
+        comm = BucketedAllReduce(device=dev, force=force_comm, payload=args.grad_comm)
+
     def timed(m, with_opt):
         opt = FlatAdamW(m, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0)
-        rep = m.capture_train_step_fused(a, v, t, y)
+        graph_step = m.capture_train_step_fused(a, v, t, y)
+        flat_g = m._flat(dev)["g"]
+
+        def rep():
+            ld = graph_step()
+            if comm is not None:
+                comm.launch(flat_g)
+                comm.wait(flat_g)
+            return ld
         for _ in range(max(W, 3)):
             rep(); opt.step()
         if world > 1:
@@ -306,6 +320,7 @@ def bench_stackb_train(args, dev, world, rank):
                                   f"B={B} per GPU, Xavier-initialised weights; optimiser step excluded from `value` and reported beside it",
                       "launch": "hip-graph replay", "parallelism": f"replicas x{world}",
                       "plan": "layer chains (mmdeer_chain)" if st.get("frag") is not None else "launch by launch"},
+           "grad_exchange": "none" if comm is None else f"{comm.algo} of the flat gradient buffer ({comm.payload} payload), host-enqueued behind the graph replay",
            "train_step_with_optimizer_ms": round(dt_opt / K * 1e3, 4), "final_loss": round(loss, 6),
            "roofline": {"bound": "mfma", "achieved": round(flops * K / dt / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                         "frac": round(flops * K / dt / peak, 4), "traffic": None,
