@@ -82,6 +82,34 @@ def test_layer_chain_operator_validates_its_table_on_the_host():
     assert lib.mmdeer_repack(j, 0, None) == 0
 
 
+def test_frag_images_job_table_on_the_host():
+    """mmdeer/chainops.py: FragImages lays its images out in one buffer and describes them to mmdeer_repack -- offsets, shapes, sub-images
+    and the refusals are host logic (no launch here)."""
+    from mmdeer.chainops import FragImages
+    cpu = torch.device("cpu")
+    W = torch.zeros(256, 84, dtype=torch.bfloat16)
+    V = torch.zeros(512, 256, dtype=torch.bfloat16)
+    F = FragImages(cpu)
+    F.add("w", W, 256, 128, ld_src=84, cols_valid=84)            # zero-padded to K = 128
+    F.add("v", V, 512, 256)
+    F.add("v.T", V, 512, 256, transpose=1)
+    F.area("bd", 24, 384)
+    F.place("bd", V[:4], 4, 128, row0=8, col0=128)
+    with pytest.raises(ValueError):
+        F.add("bad", W, 256, 84)                                 # columns of a fragment-major image: multiples of 64
+    with pytest.raises(ValueError):
+        F.place("bd", V[:4], 4, 128, row0=22)                    # past the area
+    F.finish()
+    assert F.off["w"] == 0 and F.off["v"] == 256 * 128 and all(o % 64 == 0 for o in F.off.values())
+    assert F.shape["v.T"] == (256, 512) and F("v.T").numel() == 256 * 512
+    assert F("v", 64).numel() == (512 - 64) * 256 and F("v", 64).data_ptr() == F("v").data_ptr() + 2 * 64 * 256
+    assert F.mat("bd").shape == (24, 384)
+    jobs = {name: F.jobs[i] for i, (name, *_) in enumerate(F.specs)}
+    assert (jobs["w"].ld_src, jobs["w"].cols, jobs["w"].cols_valid, jobs["w"].layout, jobs["w"].transpose) == (84, 128, 84, 1, 0)
+    assert (jobs["v.T"].transpose, jobs["v.T"].layout) == (1, 1)
+    assert (jobs["bd"].layout, jobs["bd"].ld_dst, jobs["bd"].dst_col) == (0, 384, 128) and jobs["bd"].dst == F.buf.data_ptr() + 2 * (F.off["bd"] + 8 * 384)
+
+
 def test_parameter_table_matches_python_spec():
     lib = _lib.load()
     offs, total = param_offsets()
