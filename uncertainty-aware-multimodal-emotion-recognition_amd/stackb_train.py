@@ -13,6 +13,12 @@ backward regenerates them): ResidualBlock (:68), MultiHeadAttention attention we
 head) because every softmax is over a single key), UncertaintyEstimator (:186, p = 0.2 whatever the config says),
 weight_network (:237), the two fusion stages (:318, 328) and the prediction heads (:379, 382).
 
+Two launch plans write the same tape and the same gradients, bit for bit (tests/test_gpu_stackb.py): launch by launch as described above
+(``model.train_plan = 'ops'``; fp32; geometries the chain kernel does not instantiate), and -- the default of the bf16 fused step -- every
+sample-local run of layers as ONE launch of the layer-chain kernel (``mmdeer_chain``, csrc/chain.hip; host side ``chainops.py``): the three
+encoders, the attention blocks' value / output projections, the estimator, the two fusion stages, the heads' first two layers, and the dX
+run of each of them: 16 chain launches, 49 launches per step instead of ~170.
+
 Layout conventions are those of the inference executor (csrc/stackb.hip): encoder outputs in column blocks of one (B, 768)
 matrix whose (3B, 256) reading is the row set of the shared-weight attention layers; heads stacked along N.
 """
